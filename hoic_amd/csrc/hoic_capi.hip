@@ -1,0 +1,637 @@
+// hoic_capi.hip — kernels + the C-ABI of include/hoic.h (libhoic_hip.so, gfx950 only).
+//
+// One workgroup = one wavefront = one environment; a launch covers all envs (grid = n_envs).  Inside a
+// launch the whole env step (HandObjMimic4.step, uhc/envs/ho_im4.py:611-662) runs fused: 15 substeps of
+// control glue + dynamics + contact solve + integration, then contact averaging, the residual-force QP,
+// termination, reward and the 617-float observation.  There is no CPU path in this library.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "hoic_env.h"
+
+static thread_local std::string g_err;
+static void set_err(const std::string& s) { g_err = s; }
+extern "C" const char* hoic_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return HOIC_ERR_DEVICE; } } while (0)
+
+// ------------------------------------------------------------------------------------------------ kernels
+__device__ void load_state(const DevModel& m, const DevState& st, Work& w, int env) {
+  const int tid = threadIdx.x;
+  if (tid < NQP) { w.qpos[tid] = st.qpos[(size_t)env * NQP + tid]; w.qlag[tid] = st.qlag[(size_t)env * NQP + tid]; }
+  if (tid < NV) {
+    w.qvel[tid] = st.qvel[(size_t)env * NV + tid]; w.vlag[tid] = st.vlag[(size_t)env * NV + tid];
+    w.warm[tid] = st.warm[(size_t)env * NV + tid];
+    w.ctrl[tid] = 0.f; w.applied[tid] = 0.f; w.qacc[tid] = 0.f;
+  }
+  for (int k = tid; k < NV * LD; k += NT) w.M[k] = 0.f;
+  if (tid < NHG) { for (int i = 0; i < 12; i++) w.rec_sum[tid][i] = 0.f; w.rec_cnt[tid] = 0; }
+  if (tid == 0) { w.ncon = 0; w.nlim = 0; w.nrow = 0; w.n_avg = 0; w.solver_iter = 0; w.fail = 0; }
+  __syncthreads();
+}
+__device__ void store_state(const DevState& st, const Work& w, int env) {
+  const int tid = threadIdx.x;
+  if (tid < NQP) { st.qpos[(size_t)env * NQP + tid] = w.qpos[tid]; st.qlag[(size_t)env * NQP + tid] = w.qlag[tid]; }
+  if (tid < NV) {
+    st.qvel[(size_t)env * NV + tid] = w.qvel[tid]; st.vlag[(size_t)env * NV + tid] = w.vlag[tid];
+    st.warm[(size_t)env * NV + tid] = w.warm[tid];
+  }
+}
+
+// mj_forward dynamics on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
+__device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, int* overflow) {
+  const int tid = threadIdx.x;
+  dev_forward_kin(m, w, w.qpos, w.qvel, overflow);
+  dev_make_constraint(m, w, w.qpos, w.qvel);
+  if (tid < NV) {
+    float fs = 0.f;
+    if (tid < m.nv) {
+      float act = 0.f;
+      for (int u = 0; u < m.nu; u++) if (m.act_dofid[u] == tid) act += w.ctrl[u];
+      fs = w.passive[tid] - w.bias[tid] + w.applied[tid] + act;
+    }
+    w.fsmooth[tid] = fs; w.asmooth[tid] = fs;
+    for (int k = 0; k < NV; k++) w.H[tid * LD + k] = (tid < m.nv && k < m.nv) ? w.M[tid * LD + k] : 0.f;
+    if (tid >= m.nv) w.H[tid * LD + tid] = 1.f;
+  }
+  __syncthreads();
+  spd_solve32(w.H, w.asmooth, w.T);
+  dev_solve(m, w, cfg.c.solver_iterations);
+  float bad = 0.f;
+  if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
+  return !(wave_max(bad) > 0.f);
+}
+
+// semi-implicit Euler with implicit joint damping; also records the pre-integration state (lag) and warm start
+__device__ void dev_euler(const DevModel& m, Work& w) {
+  const int tid = threadIdx.x;
+  if (tid < NV) {
+    for (int k = 0; k < NV; k++) w.H[tid * LD + k] = (tid < m.nv && k < m.nv) ? w.M[tid * LD + k] : 0.f;
+    w.H[tid * LD + tid] = (tid < m.nv) ? (w.M[tid * LD + tid] + m.timestep * m.dof_damping[tid]) : 1.f;
+    w.tv[tid] = (tid < m.nv) ? (w.fsmooth[tid] + w.fcon[tid]) : 0.f;
+  }
+  __syncthreads();
+  spd_solve32(w.H, w.tv, w.T);
+  const float h = m.timestep;
+  if (tid < NQP) w.qlag[tid] = w.qpos[tid];
+  if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
+  __syncthreads();
+  if (tid < m.nv) w.qvel[tid] += h * w.tv[tid];
+  __syncthreads();
+  if (tid < m.njnt) {
+    const int qa = m.jnt_qposadr[tid], da = m.jnt_dofadr[tid];
+    if (m.jnt_type[tid] == HOIC_JNT_FREE) {
+      for (int i = 0; i < 3; i++) w.qpos[qa + i] += h * w.qvel[da + i];
+      float wv[3] = {w.qvel[da + 3], w.qvel[da + 4], w.qvel[da + 5]};
+      const float ang = normalize3(wv) * h;
+      if (ang != 0.f) {
+        float s, c;
+        sincosf(0.5f * ang, &s, &c);
+        float dq[4] = {c, s * wv[0], s * wv[1], s * wv[2]}, qo[4] = {w.qpos[qa + 3], w.qpos[qa + 4], w.qpos[qa + 5], w.qpos[qa + 6]}, qn[4];
+        mulquat(qo, dq, qn);
+        normquat(qn);
+        for (int i = 0; i < 4; i++) w.qpos[qa + 3 + i] = qn[i];
+      }
+    } else w.qpos[qa] += h * w.qvel[da];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+                                                       DevExpert ex, DevState st, const float* __restrict__ action,
+                                                       float* __restrict__ obs, float* __restrict__ reward,
+                                                       float* __restrict__ reward_info, int* __restrict__ flags,
+                                                       float* __restrict__ percent, const int* __restrict__ next_seq,
+                                                       const int* __restrict__ next_start) {
+  __shared__ Work w;
+  const DevModel& m = *mp; const DevConfig& cfg = *cp;
+  const int env = blockIdx.x, tid = threadIdx.x;
+  load_state(m, st, w, env);
+  if (tid < NV) w.action[tid] = fminf(fmaxf(action[(size_t)env * HOIC_ACT_DIM + tid], -1.f), 1.f);   // ho_im4.py:613
+  __syncthreads();
+  const int seq = st.seq[env];
+  ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], st.start[env], st.cur_t[env]};
+  float vf[3], vt[3];
+  for (int i = 0; i < 3; i++) {
+    vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
+    vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
+  }
+  int* ovf = &st.overflow[env];
+  // quantities of the previous forward pass (one-substep lag): recompute them from the lagged state
+  dev_forward_kin(m, w, w.qlag, w.vlag, tid == 0 ? ovf : nullptr);
+  for (int g = tid; g < m.ngeom; g += NT) {
+    for (int i = 0; i < 3; i++) w.old_gxpos[g][i] = w.gxpos[g][i];
+    for (int i = 0; i < 9; i++) w.old_gxmat[g][i] = w.gxmat[g][i];
+  }
+  if (tid < 6) w.old_objvel[tid] = w.qvel[m.nv - 6 + tid];
+  __syncthreads();
+  bool ok = true;
+  const int nsub = cfg.c.sim_step;
+  for (int i = 0; i < nsub; i++) {
+    dev_pd_torque(m, cfg, w, ev);        // :518-523
+    dev_applied(m, cfg, w, vf, vt);      // :526-540
+    dev_record_contact(m, w);            // :543
+    ok = dev_forward_dyn(m, cfg, w, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
+    if (!ok) break;
+    dev_euler(m, w);                     //              ... + Euler
+  }
+  float rfc_score = 0.f;
+  if (ok) {
+    const float dt = (float)nsub * m.timestep, idt = 1.f / dt;
+    if (tid < 6) w.obj_avg_acc[tid] = (w.qvel[m.nv - 6 + tid] - w.old_objvel[tid]) * idt;        // :554
+    for (int g = tid; g < m.ngeom; g += NT) {
+      for (int i = 0; i < 3; i++) w.gvel[g][i] = (w.gxpos[g][i] - w.old_gxpos[g][i]) * idt;       // :555
+      float Rd[9], aa[3];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+          float s = 0.f;
+          for (int k = 0; k < 3; k++) s += w.gxmat[g][3 * i + k] * w.old_gxmat[g][3 * j + k];
+          Rd[3 * i + j] = s;
+        }
+      dev_matrix_to_axis_angle(Rd, aa);                                                         // :556-559
+      for (int i = 0; i < 3; i++) w.gangvel[g][i] = aa[i] * idt;
+    }
+    __syncthreads();
+    dev_classify_contact(m, w);                                                                 // :562
+    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt);                     // :631
+    if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
+  }
+  if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
+    if (tid < NQP) w.qpos[tid] = w.qlag[tid];
+    if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
+    __syncthreads();
+    dev_kinematics(m, w, w.qpos);
+  }
+  ev.cur_t += 1;                                                                                // :641
+  float df[5];
+  dev_ho_diff(m, w, ev, df);
+  const bool body_fail = df[0] > cfg.c.pos_diff_thresh || df[1] > cfg.c.rot_diff_thresh || df[2] > cfg.c.jpos_diff_thresh ||
+                         df[3] > cfg.c.obj_pos_diff_thresh || df[4] > cfg.c.obj_rot_diff_thresh;
+  bool fail = !ok;
+  if (cfg.mode_train) fail = fail || body_fail;                                                 // :655-656
+  const int expert_len = ev.len - ev.start;
+  const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
+  const bool done = fail || end;
+  float rw[10];
+  dev_reward(m, cfg, w, ev, rfc_score, rw);
+  float r = rw[0];
+  if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                     // agent_handmimic.py:479-480
+  if (tid == 0) {
+    reward[env] = r;
+    flags[4 * env] = fail; flags[4 * env + 1] = end; flags[4 * env + 2] = done; flags[4 * env + 3] = w.solver_iter;
+    percent[env] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
+    st.rfc_score[env] = rfc_score;
+  }
+  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)env * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
+  if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
+    const int ns = next_seq[env], nst = next_start[env];
+    dev_reset_state(m, w, ex, ns, nst);
+    dev_kinematics(m, w, w.qpos);
+    ev.off = ex.seq_off[ns]; ev.len = ex.seq_len[ns]; ev.start = nst; ev.cur_t = 0;
+    if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
+  }
+  dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
+  store_state(st, w, env);
+  if (tid == 0) st.cur_t[env] = ev.cur_t;
+}
+
+__global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restrict__ mp, DevExpert ex, DevState st,
+                                                        const int* __restrict__ env_ids, const int* __restrict__ seqs,
+                                                        const int* __restrict__ starts, float* __restrict__ obs) {
+  __shared__ Work w;
+  const DevModel& m = *mp;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int env = env_ids ? env_ids[k] : k;
+  const int seq = seqs[k], start = starts[k];
+  if (tid < NQP) w.qpos[tid] = 0.f;
+  __syncthreads();
+  dev_reset_state(m, w, ex, seq, start);
+  dev_kinematics(m, w, w.qpos);
+  ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], start, 0};
+  if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
+  store_state(st, w, env);
+  if (tid == 0) { st.cur_t[env] = 0; st.start[env] = start; st.seq[env] = seq; st.rfc_score[env] = 0.f; }
+}
+
+__global__ __launch_bounds__(NT) void hoic_set_state_kernel(const DevModel* __restrict__ mp, DevState st,
+                                                            const float* __restrict__ qpos, const float* __restrict__ qvel) {
+  const int env = blockIdx.x, tid = threadIdx.x, nq = mp->nq, nv = mp->nv;
+  if (tid < NQP) { const float v = tid < nq ? qpos[(size_t)env * nq + tid] : 0.f; st.qpos[(size_t)env * NQP + tid] = v; st.qlag[(size_t)env * NQP + tid] = v; }
+  if (tid < NV) {
+    const float v = tid < nv ? qvel[(size_t)env * nv + tid] : 0.f;
+    st.qvel[(size_t)env * NV + tid] = v; st.vlag[(size_t)env * NV + tid] = v; st.warm[(size_t)env * NV + tid] = 0.f;
+  }
+}
+__global__ __launch_bounds__(NT) void hoic_get_state_kernel(const DevModel* __restrict__ mp, DevState st, float* __restrict__ qpos,
+                                                            float* __restrict__ qvel, int* __restrict__ cur_t) {
+  const int env = blockIdx.x, tid = threadIdx.x, nq = mp->nq, nv = mp->nv;
+  if (qpos && tid < nq) qpos[(size_t)env * nq + tid] = st.qpos[(size_t)env * NQP + tid];
+  if (qvel && tid < nv) qvel[(size_t)env * nv + tid] = st.qvel[(size_t)env * NV + tid];
+  if (cur_t && tid == 0) cur_t[env] = st.cur_t[env];
+}
+
+struct ProbeArgs {
+  const float *qpos, *qvel, *ctrl, *applied, *warm;
+  int do_step;
+  float *xpos, *xquat, *gxpos, *gxmat, *qM, *bias, *contacts, *asmooth, *qacc, *qpos_out, *qvel_out;
+  int *ncon, *iters;
+};
+__global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp, ProbeArgs a) {
+  __shared__ Work w;
+  const DevModel& m = *mp; const DevConfig& cfg = *cp;
+  const int env = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < NV * LD; k += NT) w.M[k] = 0.f;
+  if (tid < NQP) w.qpos[tid] = tid < m.nq ? a.qpos[(size_t)env * m.nq + tid] : 0.f;
+  if (tid < NV) {
+    w.qvel[tid] = tid < m.nv ? a.qvel[(size_t)env * m.nv + tid] : 0.f;
+    w.ctrl[tid] = (a.ctrl && tid < m.nu) ? a.ctrl[(size_t)env * m.nu + tid] : 0.f;
+    w.applied[tid] = (a.applied && tid < m.nv) ? a.applied[(size_t)env * m.nv + tid] : 0.f;
+    w.warm[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;
+  }
+  if (tid == 0) { w.ncon = 0; w.nlim = 0; w.nrow = 0; w.solver_iter = 0; }
+  __syncthreads();
+  const bool ok = dev_forward_dyn(m, cfg, w, nullptr);
+  if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
+  if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
+  if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
+  if (a.gxmat) for (int k = tid; k < m.ngeom * 9; k += NT) a.gxmat[(size_t)env * m.ngeom * 9 + k] = w.gxmat[k / 9][k % 9];
+  if (a.qM) for (int k = tid; k < m.nv * m.nv; k += NT) a.qM[(size_t)env * m.nv * m.nv + k] = w.M[(k / m.nv) * LD + k % m.nv];
+  if (a.bias && tid < m.nv) a.bias[(size_t)env * m.nv + tid] = w.bias[tid];
+  if (a.asmooth && tid < m.nv) a.asmooth[(size_t)env * m.nv + tid] = w.asmooth[tid];
+  if (a.qacc && tid < m.nv) a.qacc[(size_t)env * m.nv + tid] = w.qacc[tid];
+  if (a.ncon && tid == 0) a.ncon[env] = w.ncon;
+  if (a.iters && tid == 0) a.iters[env] = ok ? w.solver_iter : -1;
+  if (a.contacts) {
+    for (int c = tid; c < HOIC_PROBE_MAXCON; c += NT) {
+      float* r = a.contacts + ((size_t)env * HOIC_PROBE_MAXCON + c) * 16;
+      if (c < w.ncon) {
+        const int p = w.c_pair[c];
+        r[0] = w.c_dist[c];
+        for (int i = 0; i < 3; i++) r[1 + i] = w.c_pos[c][i];
+        for (int i = 0; i < 9; i++) r[4 + i] = w.c_frame[c][i];
+        r[13] = (float)m.pair_geom1[p]; r[14] = (float)m.pair_geom2[p]; r[15] = (float)m.pair_condim[p];
+      } else for (int i = 0; i < 16; i++) r[i] = 0.f;
+    }
+  }
+  if (a.do_step && ok) dev_euler(m, w);
+  if (a.qpos_out && tid < m.nq) a.qpos_out[(size_t)env * m.nq + tid] = w.qpos[tid];
+  if (a.qvel_out && tid < m.nv) a.qvel_out[(size_t)env * m.nv + tid] = w.qvel[tid];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct hoic_sim {
+  int n_envs = 0, device = 0;
+  DevModel hm;            // host copy
+  DevModel* d_model = nullptr;
+  DevConfig hcfg;
+  DevConfig* d_cfg = nullptr;
+  DevExpert ex{};
+  std::vector<void*> ex_allocs;
+  DevState st{};
+  int *d_iota_seq = nullptr, *d_iota_start = nullptr;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = -1.f;
+  bool has_expert = false;
+};
+
+namespace {
+struct Blob {
+  const char* p; size_t n;
+  const hoic_blob_entry* find(const char* name) const {
+    const hoic_blob_header* h = (const hoic_blob_header*)p;
+    const hoic_blob_entry* e = (const hoic_blob_entry*)(p + sizeof(hoic_blob_header));
+    for (int i = 0; i < h->nentries; i++) if (strncmp(e[i].name, name, 32) == 0) return &e[i];
+    return nullptr;
+  }
+  bool f64(const char* name, std::vector<double>& out) const {
+    const hoic_blob_entry* e = find(name);
+    if (!e || e->dtype != 0) { set_err(std::string("model blob: missing float64 array ") + name); return false; }
+    out.resize(e->nbytes / 8);
+    memcpy(out.data(), p + e->offset, e->nbytes);
+    return true;
+  }
+  bool i32(const char* name, std::vector<int>& out) const {
+    const hoic_blob_entry* e = find(name);
+    if (!e || e->dtype != 1) { set_err(std::string("model blob: missing int32 array ") + name); return false; }
+    out.resize(e->nbytes / 4);
+    memcpy(out.data(), p + e->offset, e->nbytes);
+    return true;
+  }
+};
+template <size_t N> bool cpf(const Blob& b, const char* name, float (&dst)[N]) {
+  std::vector<double> v;
+  if (!b.f64(name, v) || v.size() > N) { if (v.size() > N) set_err(std::string("model blob: too large: ") + name); return false; }
+  for (size_t i = 0; i < v.size(); i++) dst[i] = (float)v[i];
+  return true;
+}
+template <size_t N, size_t K> bool cpf2(const Blob& b, const char* name, float (&dst)[N][K]) {
+  std::vector<double> v;
+  if (!b.f64(name, v) || v.size() > N * K) { if (v.size() > N * K) set_err(std::string("model blob: too large: ") + name); return false; }
+  for (size_t i = 0; i < v.size(); i++) dst[i / K][i % K] = (float)v[i];
+  return true;
+}
+template <size_t N> bool cpi(const Blob& b, const char* name, int (&dst)[N]) {
+  std::vector<int> v;
+  if (!b.i32(name, v) || v.size() > N) { if (v.size() > N) set_err(std::string("model blob: too large: ") + name); return false; }
+  for (size_t i = 0; i < v.size(); i++) dst[i] = v[i];
+  return true;
+}
+bool geti(const Blob& b, const char* name, int& dst) { std::vector<int> v; if (!b.i32(name, v) || v.empty()) return false; dst = v[0]; return true; }
+bool getf(const Blob& b, const char* name, float& dst) { std::vector<double> v; if (!b.f64(name, v) || v.empty()) return false; dst = (float)v[0]; return true; }
+
+void kb_from_solref(const double* solref_in, const double* solimp, double timestep, bool friction, float& K, float& B) {
+  double ref[2] = {solref_in[0], solref_in[1]};
+  double dmax = std::min(std::max(solimp[1], 0.0001), 0.9999);
+  if ((ref[0] > 0) != (ref[1] > 0)) { ref[0] = 0.02; ref[1] = 1; }
+  if (ref[0] > 0 && ref[0] < 2 * timestep) ref[0] = 2 * timestep;
+  double k, bb;
+  if (friction) k = 0;
+  else if (ref[0] > 0) k = 1.0 / std::max(1e-15, dmax * dmax * ref[0] * ref[0] * ref[1] * ref[1]);
+  else k = -ref[0] / std::max(1e-15, dmax * dmax);
+  if (ref[1] > 0) bb = 2.0 / std::max(1e-15, dmax * ref[0]);
+  else bb = -ref[1] / std::max(1e-15, dmax);
+  K = (float)k; B = (float)bb;
+}
+
+bool build_model(const void* blob, size_t nbytes, DevModel& m) {
+  if (nbytes < sizeof(hoic_blob_header) || memcmp(blob, HOIC_BLOB_MAGIC, 8) != 0) { set_err("model blob: bad magic"); return false; }
+  Blob b{(const char*)blob, nbytes};
+  memset(&m, 0, sizeof(m));
+  if (!geti(b, "nbody", m.nbody) || !geti(b, "njnt", m.njnt) || !geti(b, "nq", m.nq) || !geti(b, "nv", m.nv) ||
+      !geti(b, "nu", m.nu) || !geti(b, "ngeom", m.ngeom) || !geti(b, "npair", m.npair)) return false;
+  if (m.nbody > NB || m.njnt > NJ || m.nq > HOIC_MAX_NQ || m.nv > NV || m.nu > NU || m.ngeom > NG || m.npair > NPAIR) {
+    set_err("model blob: exceeds compiled capacities"); return false;
+  }
+  if (!geti(b, "hand_body0", m.hand_body0) || !geti(b, "obj_body", m.obj_body) || !geti(b, "hand_geom0", m.hand_geom0) ||
+      !geti(b, "hand_geom1", m.hand_geom1) || !geti(b, "obj_geom0", m.obj_geom0) || !geti(b, "obj_geom1", m.obj_geom1) ||
+      !geti(b, "hand_nq", m.hand_nq) || !geti(b, "hand_nv", m.hand_nv)) return false;
+  if (m.hand_geom1 - m.hand_geom0 + 1 != NHG) { set_err("model blob: expected 19 hand collision geoms"); return false; }
+  if (!getf(b, "timestep", m.timestep) || !getf(b, "meaninertia", m.meaninertia) || !getf(b, "hand_mass", m.hand_mass)) return false;
+  if (!cpf(b, "gravity", m.gravity)) return false;
+  if (!cpi(b, "body_parent", m.body_parent) || !cpi(b, "body_depth", m.body_depth) || !cpi(b, "body_jntadr", m.body_jntadr) ||
+      !cpi(b, "body_jntnum", m.body_jntnum) || !cpi(b, "body_dofadr", m.body_dofadr) || !cpi(b, "body_dofnum", m.body_dofnum)) return false;
+  if (!cpf2(b, "body_pos", m.body_pos) || !cpf2(b, "body_quat", m.body_quat) || !cpf2(b, "body_ipos", m.body_ipos) ||
+      !cpf2(b, "body_iquat", m.body_iquat) || !cpf(b, "body_mass", m.body_mass) || !cpf2(b, "body_inertia", m.body_inertia)) return false;
+  if (!cpi(b, "jnt_type", m.jnt_type) || !cpi(b, "jnt_qposadr", m.jnt_qposadr) || !cpi(b, "jnt_dofadr", m.jnt_dofadr) ||
+      !cpi(b, "jnt_bodyid", m.jnt_bodyid) || !cpi(b, "jnt_limited", m.jnt_limited)) return false;
+  if (!cpf2(b, "jnt_pos", m.jnt_pos) || !cpf2(b, "jnt_axis", m.jnt_axis) || !cpf2(b, "jnt_range", m.jnt_range) ||
+      !cpf(b, "jnt_margin", m.jnt_margin) || !cpf2(b, "jnt_solimp", m.jnt_solimp) || !cpf(b, "qpos0", m.qpos0)) return false;
+  if (!cpi(b, "dof_bodyid", m.dof_bodyid) || !cpi(b, "dof_jntid", m.dof_jntid)) return false;
+  if (!cpf(b, "dof_armature", m.dof_armature) || !cpf(b, "dof_damping", m.dof_damping) || !cpf(b, "dof_frictionloss", m.dof_frictionloss)) return false;
+  if (!cpi(b, "act_dofid", m.act_dofid)) return false;
+  if (!cpi(b, "geom_type", m.geom_type) || !cpi(b, "geom_bodyid", m.geom_bodyid) || !cpi(b, "geom_meshid", m.geom_meshid)) return false;
+  if (!cpf2(b, "geom_size", m.geom_size) || !cpf2(b, "geom_pos", m.geom_pos) || !cpf2(b, "geom_quat", m.geom_quat) ||
+      !cpf(b, "geom_rbound", m.geom_rbound)) return false;
+  if (!cpi(b, "pair_geom1", m.pair_geom1) || !cpi(b, "pair_geom2", m.pair_geom2) || !cpi(b, "pair_condim", m.pair_condim)) return false;
+  if (!cpf2(b, "pair_solimp", m.pair_solimp) || !cpf(b, "pair_margin", m.pair_margin) || !cpf(b, "pair_gap", m.pair_gap)) return false;
+  std::vector<double> dsolref, dsolimp, jsolref, jsolimp, psolref, psolimp, pfric, invw, binvw;
+  std::vector<int> dparent, weld;
+  if (!b.f64("dof_solref", dsolref) || !b.f64("dof_solimp", dsolimp) || !b.f64("jnt_solref", jsolref) || !b.f64("jnt_solimp", jsolimp) ||
+      !b.f64("pair_solref", psolref) || !b.f64("pair_solimp", psolimp) || !b.f64("pair_friction", pfric) ||
+      !b.f64("dof_invweight0", invw) || !b.f64("body_invweight0", binvw) || !b.i32("dof_parentid", dparent)) return false;
+  std::vector<double> impr;
+  double impratio = 1.0;
+  if (b.f64("impratio", impr) && !impr.empty()) impratio = impr[0];
+  // tree bookkeeping
+  m.nlevel = 0;
+  for (int i = 0; i < m.nbody; i++) m.nlevel = std::max(m.nlevel, m.body_depth[i]);
+  for (int i = 0; i < m.nbody; i++) {
+    int e = i + 1;
+    while (e < m.nbody && m.body_depth[e] > m.body_depth[i]) e++;
+    m.body_subtree[i] = e - i;
+  }
+  std::vector<int> lastdof;
+  if (!b.i32("body_lastdof", lastdof)) return false;
+  for (int i = 0; i < m.nbody; i++) {
+    unsigned mask = 0;
+    for (int d = lastdof[i]; d >= 0; d = dparent[d]) mask |= 1u << d;
+    m.body_dofmask[i] = mask;
+  }
+  m.nM = 0;
+  for (int i = 0; i < m.nv; i++)
+    for (int j = i; j >= 0; j = dparent[j]) {
+      if (m.nM >= 256) { set_err("model blob: too many mass-matrix entries"); return false; }
+      m.mi[m.nM] = (unsigned char)i; m.mj[m.nM] = (unsigned char)j; m.nM++;
+    }
+  // constraint constants
+  for (int i = 0; i < m.nv; i++) {
+    float K;
+    kb_from_solref(&dsolref[2 * i], &dsolimp[5 * i], m.timestep, true, K, m.dof_flB[i]);
+    double s0 = std::min(std::max(dsolimp[5 * i], 0.0001), 0.9999), s1 = std::min(std::max(dsolimp[5 * i + 1], 0.0001), 0.9999);
+    double imp = (s0 == s1 || dsolimp[5 * i + 2] <= 1e-15) ? 0.5 * (s0 + s1) : s0;   // pos = margin = 0 -> x = 0
+    m.dof_flR[i] = (float)std::max(1e-15, (1 - imp) * invw[i] / imp);
+  }
+  for (int j = 0; j < m.njnt; j++) {
+    kb_from_solref(&jsolref[2 * j], &jsolimp[5 * j], m.timestep, false, m.jnt_K[j], m.jnt_B[j]);
+    m.jnt_diag[j] = (float)invw[m.jnt_dofadr[j]];
+    if (m.jnt_limited[j] && m.jnt_type[j] != HOIC_JNT_FREE && m.jnt_range[j][1] - m.jnt_range[j][0] <= 2 * m.jnt_margin[j]) {
+      set_err("model blob: joint range narrower than twice its margin is not supported"); return false;
+    }
+  }
+  for (int p = 0; p < m.npair; p++) {
+    kb_from_solref(&psolref[2 * p], &psolimp[5 * p], m.timestep, false, m.pair_K[p], m.pair_B[p]);
+    const double* f = &pfric[5 * p];
+    m.pair_mu[p][0] = (float)f[0]; m.pair_mu[p][1] = (float)f[1]; m.pair_mu[p][2] = (float)f[2];
+    const int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
+    const double tran = binvw[2 * b1] + binvw[2 * b2];
+    if (m.pair_condim[p] == 1) m.pair_Rscale[p] = (float)tran;
+    else {
+      const double mu = f[0] * std::sqrt(1.0 / std::max(1e-15, impratio));
+      m.pair_Rscale[p] = (float)(2 * mu * mu * (tran + f[0] * f[0] * tran));
+    }
+    const int t1 = m.geom_type[m.pair_geom1[p]], t2 = m.geom_type[m.pair_geom2[p]];
+    if (t1 == HOIC_GEOM_MESH || t2 == HOIC_GEOM_MESH) { /* convex-mesh pairs: not in this round's kernel */ }
+  }
+  std::vector<int> mva, mvn; std::vector<double> mv;
+  if (b.i32("mesh_vertadr", mva) && b.i32("mesh_vertnum", mvn) && b.f64("mesh_vert", mv)) {
+    for (size_t i = 0; i < mva.size() && i < HOIC_MAX_MESH; i++) { m.mesh_vertadr[i] = mva[i]; m.mesh_vertnum[i] = mvn[i]; }
+    for (size_t i = 0; i < mv.size() && i < (size_t)MAXMESHV * 3; i++) m.mesh_vert[i / 3][i % 3] = (float)mv[i];
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t n_envs, int32_t device_id) {
+  if (!model_blob || n_envs <= 0) { set_err("hoic_create: bad arguments"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("hoic_create: no HIP device (this library has no CPU path)"); return nullptr; }
+  if (hipSetDevice(device_id) != hipSuccess) { set_err("hoic_create: hipSetDevice failed"); return nullptr; }
+  hoic_sim* s = new hoic_sim();
+  s->n_envs = n_envs; s->device = device_id;
+  if (!build_model(model_blob, nbytes, s->hm)) { delete s; return nullptr; }
+  memset(&s->hcfg, 0, sizeof(s->hcfg));
+  hoic_env_config& c = s->hcfg.c;
+  c.pos_diff_thresh = 0.1f; c.rot_diff_thresh = 1.0f; c.jpos_diff_thresh = 0.1f; c.obj_pos_diff_thresh = 0.1f; c.obj_rot_diff_thresh = 1.0f;
+  c.residual_force_scale = 2.5f; c.residual_torque_scale = 0.125f; c.sim_step = 15; c.future_w_size = 5;
+  c.residual_force = 1; c.explain_force = 1; c.surface_contact = 1; c.pd_rel = 1; c.solver_iterations = 8;
+  for (int i = 0; i < NU; i++) { c.jkp[i] = i < 3 ? 50.f : (i < 6 ? 5.f : 1.f); c.jkd[i] = 0.1f * c.jkp[i]; c.torque_lim[i] = c.jkp[i]; }
+  for (int j = 0; j < s->hm.hand_nq && j < NU; j++) {   // ho_im4.py:103-107
+    const float lo = s->hm.jnt_range[j][0], hi = s->hm.jnt_range[j][1];
+    s->hcfg.base_pose[j] = 0.5f * (hi + lo);
+    s->hcfg.ctrl_scale[j] = (hi - s->hcfg.base_pose[j]) * (j >= 6 ? 1.2f : 1.f);
+  }
+  const float wk0[16] = {0.25f, 0.2f, 0.1f, 0.45f, 0.2f, 0.4f, 0.1f, 0.5f, 3.f, 3.f, 0.05f, 6.f, 10.f, 1.f, 0.05f, 1.f};
+  memcpy(s->hcfg.rp.wk, wk0, sizeof(wk0));
+  s->hcfg.mode_train = 1;
+  bool ok = hipMalloc(&s->d_model, sizeof(DevModel)) == hipSuccess && hipMalloc(&s->d_cfg, sizeof(DevConfig)) == hipSuccess;
+  const size_t n = (size_t)n_envs;
+  ok = ok && hipMalloc(&s->st.qpos, n * NQP * 4) == hipSuccess && hipMalloc(&s->st.qlag, n * NQP * 4) == hipSuccess &&
+       hipMalloc(&s->st.qvel, n * NV * 4) == hipSuccess && hipMalloc(&s->st.vlag, n * NV * 4) == hipSuccess &&
+       hipMalloc(&s->st.warm, n * NV * 4) == hipSuccess && hipMalloc(&s->st.cur_t, n * 4) == hipSuccess &&
+       hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
+       hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess;
+  if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
+  hipMemcpy(s->d_model, &s->hm, sizeof(DevModel), hipMemcpyHostToDevice);
+  hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice);
+  hipMemset(s->st.qpos, 0, n * NQP * 4); hipMemset(s->st.qlag, 0, n * NQP * 4); hipMemset(s->st.qvel, 0, n * NV * 4);
+  hipMemset(s->st.vlag, 0, n * NV * 4); hipMemset(s->st.warm, 0, n * NV * 4); hipMemset(s->st.cur_t, 0, n * 4);
+  hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
+  hipMemset(s->st.overflow, 0, n * 4);
+  hipDeviceSynchronize();
+  return s;
+}
+
+extern "C" void hoic_destroy(hoic_sim* s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  for (void* p : s->ex_allocs) hipFree(p);
+  void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->d_iota_seq, s->d_iota_start};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  delete s;
+}
+
+extern "C" int32_t hoic_num_envs(const hoic_sim* s) { return s ? s->n_envs : 0; }
+extern "C" int32_t hoic_obs_dim(const hoic_sim* s) { (void)s; return HOIC_OBS_DIM; }
+extern "C" int32_t hoic_action_dim(const hoic_sim* s) { (void)s; return HOIC_ACT_DIM; }
+
+extern "C" int32_t hoic_set_config(hoic_sim* s, const hoic_env_config* cfg) {
+  if (!s || !cfg) { set_err("hoic_set_config: null"); return HOIC_ERR_ARG; }
+  if (cfg->future_w_size != 5) { set_err("hoic_set_config: future_w_size must be 5 (obs layout)"); return HOIC_ERR_ARG; }
+  if (cfg->sim_step <= 0 || cfg->solver_iterations <= 0) { set_err("hoic_set_config: sim_step/solver_iterations"); return HOIC_ERR_ARG; }
+  s->hcfg.c = *cfg;
+  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_set_reward_params(hoic_sim* s, const hoic_reward_params* rp) {
+  if (!s || !rp) { set_err("hoic_set_reward_params: null"); return HOIC_ERR_ARG; }
+  s->hcfg.rp = *rp;
+  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_set_mode(hoic_sim* s, int32_t train) {
+  if (!s) return HOIC_ERR_ARG;
+  s->hcfg.mode_train = train ? 1 : 0;
+  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
+  return HOIC_OK;
+}
+
+template <typename T> static T* upload(hoic_sim* s, const T* h, size_t n) {
+  T* d = nullptr;
+  if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+  hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
+  s->ex_allocs.push_back(d);
+  return d;
+}
+extern "C" int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* seq_len, const float* hand_dof,
+                                   const float* hand_dof_vel, const float* obj_pose, const float* obj_vel,
+                                   const float* obj_angvel, const float* body_pos, const float* body_quat) {
+  if (!s || n_seq <= 0 || !seq_len || !hand_dof || !hand_dof_vel || !obj_pose || !obj_vel || !obj_angvel || !body_pos || !body_quat) {
+    set_err("hoic_set_expert: bad arguments"); return HOIC_ERR_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (void* p : s->ex_allocs) hipFree(p);
+  s->ex_allocs.clear();
+  std::vector<int> off(n_seq);
+  size_t T = 0;
+  for (int i = 0; i < n_seq; i++) { if (seq_len[i] < 8) { set_err("hoic_set_expert: sequence shorter than 8 frames"); return HOIC_ERR_ARG; } off[i] = (int)T; T += seq_len[i]; }
+  const int nh = s->hm.hand_nq;
+  DevExpert& x = s->ex;
+  x.n_seq = n_seq; x.total = (int)T;
+  x.seq_off = upload(s, off.data(), n_seq); x.seq_len = upload(s, seq_len, n_seq);
+  x.hand_dof = upload(s, hand_dof, T * nh); x.hand_dof_vel = upload(s, hand_dof_vel, T * nh);
+  x.obj_pose = upload(s, obj_pose, T * 7); x.obj_vel = upload(s, obj_vel, T * 3); x.obj_angvel = upload(s, obj_angvel, T * 3);
+  x.body_pos = upload(s, body_pos, T * NHB * 3); x.body_quat = upload(s, body_quat, T * NHB * 4);
+  if (!x.seq_off || !x.seq_len || !x.hand_dof || !x.hand_dof_vel || !x.obj_pose || !x.obj_vel || !x.obj_angvel || !x.body_pos || !x.body_quat) {
+    set_err("hoic_set_expert: hipMalloc failed"); return HOIC_ERR_DEVICE;
+  }
+  s->has_expert = true;
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, const int32_t* d_seq, const int32_t* d_start,
+                              float* d_obs_out, void* stream) {
+  if (!s || !d_seq || !d_start || n <= 0 || n > s->n_envs) { set_err("hoic_reset: bad arguments"); return HOIC_ERR_ARG; }
+  if (!s->has_expert) { set_err("hoic_reset: set_expert has not been called"); return HOIC_ERR_STATE; }
+  hipLaunchKernelGGL(hoic_reset_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->ex, s->st, d_env_ids, d_seq, d_start, d_obs_out);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, float* d_reward, float* d_reward_info,
+                             int32_t* d_flags, float* d_percent, const int32_t* d_next_seq, const int32_t* d_next_start,
+                             void* stream) {
+  if (!s || !d_action || !d_obs || !d_reward || !d_reward_info || !d_flags || !d_percent) { set_err("hoic_step: null pointer"); return HOIC_ERR_ARG; }
+  if ((d_next_seq == nullptr) != (d_next_start == nullptr)) { set_err("hoic_step: next_seq/next_start must come together"); return HOIC_ERR_ARG; }
+  if (!s->has_expert) { set_err("hoic_step: set_expert has not been called"); return HOIC_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  if (s->timing) hipEventRecord(s->ev0, st);
+  hipLaunchKernelGGL(hoic_step_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start);
+  if (s->timing) hipEventRecord(s->ev1, st);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_get_state(hoic_sim* s, float* d_qpos, float* d_qvel, int32_t* d_cur_t, void* stream) {
+  if (!s) return HOIC_ERR_ARG;
+  hipLaunchKernelGGL(hoic_get_state_kernel, dim3(s->n_envs), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->st, d_qpos, d_qvel, d_cur_t);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_set_state(hoic_sim* s, const float* d_qpos, const float* d_qvel, void* stream) {
+  if (!s || !d_qpos || !d_qvel) { set_err("hoic_set_state: null"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_set_state_kernel, dim3(s->n_envs), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->st, d_qpos, d_qvel);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_get_rfc_score(hoic_sim* s, float* d_score, void* stream) {
+  if (!s || !d_score) return HOIC_ERR_ARG;
+  HIPCHK(hipMemcpyAsync(d_score, s->st.rfc_score, (size_t)s->n_envs * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const float* d_qvel, const float* d_ctrl,
+                                      const float* d_applied, const float* d_warm, int32_t do_step, float* d_xpos,
+                                      float* d_xquat, float* d_geom_xpos, float* d_geom_xmat, float* d_qM, float* d_bias,
+                                      int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
+                                      float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream) {
+  if (!s || n <= 0 || !d_qpos || !d_qvel) { set_err("hoic_probe_forward: bad arguments"); return HOIC_ERR_ARG; }
+  ProbeArgs a{d_qpos, d_qvel, d_ctrl, d_applied, d_warm, do_step, d_xpos, d_xquat, d_geom_xpos, d_geom_xmat, d_qM, d_bias,
+              d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_ncon, d_solver_iter};
+  hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->d_cfg, a);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_enable_timing(hoic_sim* s, int32_t enable) {
+  if (!s) return HOIC_ERR_ARG;
+  if (enable && !s->ev0) { HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); }
+  s->timing = enable != 0;
+  return HOIC_OK;
+}
+extern "C" float hoic_last_step_ms(hoic_sim* s) {
+  if (!s || !s->timing || !s->ev1) return -1.f;
+  if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.f;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.f;
+  return ms;
+}

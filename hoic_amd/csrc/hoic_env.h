@@ -1,0 +1,436 @@
+// hoic_env.h — the environment step around the dynamics: HandObjMimic4 as device code.
+//
+// Mirrors uhc/envs/ho_im4.py: compute_torque (:412-486) with compute_desired_accel (:393-410), gravity
+// compensation (:526-536), rfc_obj (:488-501), record_contact/classify_contact (:883-889, :567-597), the
+// 15-substep finite differences (:553-559), solve_rfc (:941-1083), calc_ho_diff + termination (:664-688,
+// :646-662), get_full_obs_v5 (:280-356) and ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-1047).
+// The one-substep lag of body poses / M / bias / contacts is reproduced by keeping
+// the state before the last integration (qlag, vlag) and re-running the forward pass on it.
+#pragma once
+#include "hoic_types.h"
+#include "hoic_math.h"
+#include "hoic_dynamics.h"
+#include "hoic_collide.h"
+#include "hoic_solver.h"
+
+struct ExpertView {
+  const DevExpert* ex;
+  int off, len, start, cur_t;
+  HD int frame(int delta) const {
+    int ind = cur_t + delta + start;
+    ind = ind < len - 1 ? ind : len - 1;
+    return off + ind;
+  }
+};
+
+// ---- position + velocity stages of the forward pass on state (q, v); leaves M, bias, contacts, S in LDS
+__device__ void dev_forward_kin(const DevModel& m, Work& w, const float* q, const float* v, int* overflow) {
+  dev_kinematics(m, w, q);
+  dev_mass_matrix(m, w);
+  dev_bias(m, w, v);
+  dev_collision(m, w, overflow);
+}
+
+// ---- stable PD torque (ho_im4.py:412-486) using M and bias currently in LDS (i.e. lagged)
+__device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const ExpertView& ev) {
+  const int tid = threadIdx.x, n = m.hand_nv;
+  const float dt = m.timestep;
+  float err = 0.f, kp = 0.f, kd = 0.f;
+  if (tid < n) {
+    const float* ref = ev.ex->hand_dof + (size_t)ev.frame(0) * m.hand_nq;
+    float target;
+    if (tid < 3) target = ref[tid] + 0.1f * w.action[tid];
+    else if (tid < 6) target = ref[tid] + 0.3f * w.action[tid];
+    else target = (cfg.c.pd_rel ? ref[tid] : cfg.base_pose[tid]) + cfg.ctrl_scale[tid] * w.action[tid];
+    err = w.qpos[tid] + w.qvel[tid] * dt - target;
+    if (tid >= 3) {
+      while (err > 3.14159265358979f) err -= 6.28318530717959f;
+      while (err < -3.14159265358979f) err += 6.28318530717959f;
+    }
+    kp = cfg.c.jkp[tid]; kd = cfg.c.jkd[tid];
+  }
+  if (tid < NV) {
+    for (int k = 0; k < NV; k++) w.H[tid * LD + k] = (tid < n && k < n) ? w.M[tid * LD + k] : 0.f;
+    w.H[tid * LD + tid] = (tid < n) ? (w.M[tid * LD + tid] + kd * dt) : 1.f;
+    w.tv[tid] = (tid < n) ? (-w.bias[tid] - kp * err - kd * w.qvel[tid]) : 0.f;
+  }
+  __syncthreads();
+  spd_solve32(w.H, w.tv, w.T);
+  if (tid < NV) {
+    float tq = 0.f;
+    if (tid < n) {
+      tq = -kp * err - kd * (w.qvel[tid] + w.tv[tid] * dt);
+      tq = fminf(fmaxf(tq, -cfg.c.torque_lim[tid]), cfg.c.torque_lim[tid]);
+    }
+    w.ctrl[tid] = tq;
+  }
+  __syncthreads();
+}
+
+// ---- generalized applied forces: gravity compensation + residual object wrench, lagged Jacobians
+__device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
+  const int tid = threadIdx.x;
+  if (tid < NV) {
+    float s = 0.f;
+    if (tid < m.nv) {
+      const float f[3] = {0.f, 0.f, m.hand_mass * 9.8f}, z[3] = {0.f, 0.f, 0.f};
+      s = dev_apply_ft_dof(m, w, tid, 3, f, z, w.gxpos[2]);                       // ho_im4.py:527-535
+      if (cfg.c.residual_force) s += dev_apply_ft_dof(m, w, tid, m.obj_body, vf, vt, &w.qpos[m.hand_nq]);  // :492-500
+    }
+    w.applied[tid] = s;
+  }
+  __syncthreads();
+}
+
+// ---- record_contact (ho_im4.py:883-889): lane = hand geom, deterministic accumulation order
+__device__ void dev_record_contact(const DevModel& m, Work& w) {
+  const int tid = threadIdx.x;
+  if (tid < NHG) {
+    const int g = m.hand_geom0 + tid;
+    for (int c = 0; c < w.ncon; c++) {
+      const int p = w.c_pair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+      if (g1 == g && g2 >= m.obj_geom0 && g2 <= m.obj_geom1) {
+        for (int i = 0; i < 3; i++) w.rec_sum[tid][i] += w.c_pos[c][i];
+        for (int i = 0; i < 9; i++) w.rec_sum[tid][3 + i] += w.c_frame[c][i];
+        w.rec_cnt[tid]++;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// uhc/utils/transforms.py:414 matrix_to_axis_angle
+HD void dev_matrix_to_axis_angle(const float* mm, float* aa) {
+  float qa[4] = {1.f + mm[0] + mm[4] + mm[8], 1.f + mm[0] - mm[4] - mm[8], 1.f - mm[0] + mm[4] - mm[8], 1.f - mm[0] - mm[4] + mm[8]};
+  int best = 0;
+  for (int i = 0; i < 4; i++) qa[i] = qa[i] > 0.f ? sqrtf(qa[i]) : 0.f;
+  for (int i = 1; i < 4; i++) if (qa[i] > qa[best]) best = i;
+  float q[4];
+  if (best == 0) { q[0] = qa[0] * qa[0]; q[1] = mm[7] - mm[5]; q[2] = mm[2] - mm[6]; q[3] = mm[3] - mm[1]; }
+  else if (best == 1) { q[0] = mm[7] - mm[5]; q[1] = qa[1] * qa[1]; q[2] = mm[3] + mm[1]; q[3] = mm[2] + mm[6]; }
+  else if (best == 2) { q[0] = mm[2] - mm[6]; q[1] = mm[3] + mm[1]; q[2] = qa[2] * qa[2]; q[3] = mm[5] + mm[7]; }
+  else { q[0] = mm[3] - mm[1]; q[1] = mm[6] + mm[2]; q[2] = mm[7] + mm[5]; q[3] = qa[3] * qa[3]; }
+  const float den = 1.f / (2.f * fmaxf(qa[best], 0.1f));
+  for (int i = 0; i < 4; i++) q[i] *= den;
+  const float nrm = sqrtf(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float half = atan2f(nrm, q[0]), ang = 2.f * half;
+  const float s = fabsf(ang) < 1e-6f ? 0.5f - ang * ang / 48.f : sinf(half) / ang;
+  for (int i = 0; i < 3; i++) aa[i] = q[1 + i] / s;
+}
+
+// ---- classify_contact (ho_im4.py:567-597)
+__device__ void dev_classify_contact(const DevModel& m, Work& w) {
+  const int tid = threadIdx.x;
+  const bool has = tid < NHG && w.rec_cnt[tid] > 0;
+  const unsigned long long mask = __ballot(has);
+  const int idx = __popcll(mask & ((1ull << tid) - 1ull));
+  if (tid == 0) w.n_avg = __popcll(mask);
+  if (has) {
+    float f[12];
+    const float inv = 1.f / (float)w.rec_cnt[tid];
+    for (int i = 0; i < 12; i++) f[i] = w.rec_sum[tid][i] * inv;
+    float* n = f + 3; float* t1 = f + 6; float* t2 = f + 9;
+    const float nn = 1.f / sqrtf(dot3(n, n));
+    for (int i = 0; i < 3; i++) n[i] *= nn;
+    const float ex[3] = {1.f, 0.f, 0.f}, ey[3] = {0.f, 1.f, 0.f};
+    if (fabsf(n[0]) >= 1e-5f) cross3(n, ex, t1); else cross3(n, ey, t1);
+    float tn = 1.f / sqrtf(dot3(t1, t1));
+    for (int i = 0; i < 3; i++) t1[i] *= tn;
+    cross3(n, t1, t2);
+    tn = 1.f / sqrtf(dot3(t2, t2));
+    for (int i = 0; i < 3; i++) t2[i] *= tn;
+    for (int i = 0; i < 12; i++) w.avg_cps[idx][i] = f[i];
+    w.avg_geom[idx] = tid + m.hand_geom0;
+    w.avg_ts[idx] = (float)w.rec_cnt[tid];
+  }
+  __syncthreads();
+}
+
+// ---- solve_rfc (ho_im4.py:941-1083) in float64: Newton on the 6-D dual of the non-negative QP
+//   min_l |l|^2/4 + b'l + 1/(2 eps) sum_i max(0, -(c_i + a_i'l))^2 ,  residual wrench = -l/2
+// (same formulation as oracle/ho_env.c; columns a_i live in registers, 6 per lane)
+#define QPC 6
+HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major, x in/out
+  double L[6][6];
+  for (int i = 0, k = 0; i < 6; i++) for (int j = 0; j <= i; j++, k++) L[i][j] = H[k];
+  for (int j = 0; j < 6; j++) {
+    double s = L[j][j];
+    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    s = s > 1e-300 ? s : 1e-300;
+    const double l = sqrt(s);
+    L[j][j] = l;
+    for (int i = j + 1; i < 6; i++) {
+      double t = L[i][j];
+      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+      L[i][j] = t / l;
+    }
+  }
+  for (int i = 0; i < 6; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i][k] * x[k]; x[i] = s / L[i][i]; }
+  for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+}
+
+__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
+  const int tid = threadIdx.x;
+  const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025, eps = 1e-7;
+  if (!cfg.c.explain_force)
+    return sqrtf(dot3(vf, vf)) + (float)w_t * sqrtf(dot3(vt, vt));
+  const int nq = m.nq, ob = m.obj_body, lastg = m.ngeom - 1;
+  double Rm[9];
+  {
+    float Rf[9];
+    quat_matrix_ref(&w.qpos[nq - 4], Rf);
+    for (int i = 0; i < 9; i++) Rm[i] = Rf[i];
+  }
+  double F[3], tau[3], I[9], ow[3], oa[3], ooa[3];
+  for (int i = 0; i < 3; i++) { ow[i] = w.gangvel[lastg][i]; oa[i] = w.obj_avg_acc[i]; ooa[i] = w.obj_avg_acc[3 + i]; }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += Rm[3 * i + k] * (double)m.body_inertia[ob][k] * Rm[3 * j + k];
+      I[3 * i + j] = s;
+    }
+  const double mass = m.body_mass[ob];
+  F[0] = mass * oa[0]; F[1] = mass * oa[1]; F[2] = mass * (oa[2] + 9.8);
+  double Iw[3], Ioa[3];
+  for (int i = 0; i < 3; i++) {
+    Iw[i] = I[3 * i] * ow[0] + I[3 * i + 1] * ow[1] + I[3 * i + 2] * ow[2];
+    Ioa[i] = I[3 * i] * ooa[0] + I[3 * i + 1] * ooa[1] + I[3 * i + 2] * ooa[2];
+  }
+  tau[0] = Ioa[0] + ow[1] * Iw[2] - ow[2] * Iw[1];
+  tau[1] = Ioa[1] + ow[2] * Iw[0] - ow[0] * Iw[2];
+  tau[2] = Ioa[2] + ow[0] * Iw[1] - ow[1] * Iw[0];
+  if (w.n_avg == 0)
+    return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + w_t * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
+  const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.n_avg * npt * 4;
+  const double inv = 1.0 / sqrt(1.0 + mu * mu);
+  double a[QPC][6], cc[QPC];
+  bool valid[QPC];
+  const double obj_p[3] = {w.qpos[nq - 7], w.qpos[nq - 6], w.qpos[nq - 5]};
+  const double obj_v[3] = {w.gvel[lastg][0], w.gvel[lastg][1], w.gvel[lastg][2]};
+#pragma unroll
+  for (int jj = 0; jj < QPC; jj++) {
+    const int col = tid + jj * NT;
+    valid[jj] = col < ncol;
+    for (int i = 0; i < 6; i++) a[jj][i] = 0.0;
+    cc[jj] = 0.0;
+    if (!valid[jj]) continue;
+    const int pt = col >> 2, e = col & 3, ci = pt / npt, j = pt % npt;
+    const float* cp = w.avg_cps[ci];
+    double pos[3], fn[3], t1[3], t2[3];
+    for (int i = 0; i < 3; i++) { pos[i] = cp[i]; fn[i] = cp[3 + i]; t1[i] = cp[6 + i]; t2[i] = cp[9 + i]; }
+    const int g1 = w.avg_geom[ci];
+    const double* dl = (j == 1 || j == 2) ? t1 : t2;
+    const double sg = (j == 0) ? 0.0 : ((j & 1) ? dx : -dx);
+    double p[3], crh[3], cro[3], rel[3], relt[3];
+    for (int k = 0; k < 3; k++) { p[k] = pos[k] + sg * dl[k]; crh[k] = p[k] - (double)w.gxpos[g1][k]; cro[k] = p[k] - obj_p[k]; }
+    const double gw[3] = {w.gangvel[g1][0], w.gangvel[g1][1], w.gangvel[g1][2]};
+    const double cvh[3] = {w.gvel[g1][0] + gw[1] * crh[2] - gw[2] * crh[1], w.gvel[g1][1] + gw[2] * crh[0] - gw[0] * crh[2],
+                           w.gvel[g1][2] + gw[0] * crh[1] - gw[1] * crh[0]};
+    const double cvo[3] = {obj_v[0] + ow[1] * cro[2] - ow[2] * cro[1], obj_v[1] + ow[2] * cro[0] - ow[0] * cro[2],
+                           obj_v[2] + ow[0] * cro[1] - ow[1] * cro[0]};
+    for (int k = 0; k < 3; k++) rel[k] = cvo[k] - cvh[k];
+    const double nn = fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2];
+    const double vn = fn[0] * rel[0] + fn[1] * rel[1] + fn[2] * rel[2];
+    for (int k = 0; k < 3; k++) relt[k] = rel[k] - vn * fn[k];
+    const double nvn = fabs(vn) * sqrt(nn), nvt = sqrt(relt[0] * relt[0] + relt[1] * relt[1] + relt[2] * relt[2]);
+    const double ts = (double)w.avg_ts[pt / 5] / (double)cfg.c.sim_step;   // cp_ts[i // 5] quirk (:1012)
+    const double d1 = relt[0] * t1[0] + relt[1] * t1[1] + relt[2] * t1[2], d2 = relt[0] * t2[0] + relt[1] * t2[1] + relt[2] * t2[2];
+    const double dirs[4] = {-d1, d1, -d2, d2};
+    int am = 0;
+    for (int k = 1; k < 4; k++) if (dirs[k] > dirs[am]) am = k;
+    const double* tt = e < 2 ? t1 : t2;
+    const double sgn = (e & 1) ? -1.0 : 1.0;
+    double xv[3];
+    for (int k = 0; k < 3; k++) xv[k] = (fn[k] + sgn * mu * tt[k]) * inv * ts;
+    a[jj][0] = xv[0]; a[jj][1] = xv[1]; a[jj][2] = xv[2];
+    a[jj][3] = swt * (cro[1] * xv[2] - cro[2] * xv[1]);
+    a[jj][4] = swt * (cro[2] * xv[0] - cro[0] * xv[2]);
+    a[jj][5] = swt * (cro[0] * xv[1] - cro[1] * xv[0]);
+    cc[jj] = ((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt);
+  }
+  const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
+  double lam[6];
+  for (int i = 0; i < 6; i++) lam[i] = -2.0 * b[i];
+  for (int it = 0; it < 60; it++) {
+    double g[6], H[21], s[QPC];
+    for (int i = 0; i < 6; i++) g[i] = 0.0;
+    for (int i = 0; i < 21; i++) H[i] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < QPC; jj++) {
+      double sk = cc[jj];
+      for (int i = 0; i < 6; i++) sk += a[jj][i] * lam[i];
+      s[jj] = sk;
+      if (valid[jj] && sk < 0.0) {
+        const double se = sk / eps;
+        for (int i = 0, k = 0; i < 6; i++) { g[i] += se * a[jj][i]; for (int j = 0; j <= i; j++, k++) H[k] += a[jj][i] * a[jj][j] / eps; }
+      }
+    }
+    for (int i = 0; i < 6; i++) g[i] = wave_sum_d(g[i]) + 0.5 * lam[i] + b[i];
+    for (int i = 0; i < 21; i++) H[i] = wave_sum_d(H[i]);
+    for (int i = 0, k = 0; i < 6; i++) { k += i; H[k] += 0.5; k++; }
+    double gn = 0, ln = 0;
+    for (int i = 0; i < 6; i++) { gn += g[i] * g[i]; ln += lam[i] * lam[i]; }
+    if (sqrt(gn) < 1e-12 * (1.0 + sqrt(ln))) break;
+    double dir[6];
+    for (int i = 0; i < 6; i++) dir[i] = -g[i];
+    chol6_solve(H, dir);
+    double gl = 0, dd = 0, bd = 0, av[QPC];
+    for (int i = 0; i < 6; i++) { gl += lam[i] * dir[i]; dd += dir[i] * dir[i]; bd += b[i] * dir[i]; }
+#pragma unroll
+    for (int jj = 0; jj < QPC; jj++) { double v = 0; for (int i = 0; i < 6; i++) v += a[jj][i] * dir[i]; av[jj] = v; }
+    double al = 1.0, lo = 0.0, hi = -1.0;
+    for (int ls = 0; ls < 60; ls++) {
+      double dphi = 0, ddphi = 0;
+#pragma unroll
+      for (int jj = 0; jj < QPC; jj++) {
+        const double sk = s[jj] + al * av[jj];
+        if (valid[jj] && sk < 0.0) { dphi += sk * av[jj] / eps; ddphi += av[jj] * av[jj] / eps; }
+      }
+      dphi = wave_sum_d(dphi) + 0.5 * (gl + al * dd) + bd; ddphi = wave_sum_d(ddphi) + 0.5 * dd;
+      if (fabs(dphi) < 1e-13 * (1.0 + fabs(bd) + fabs(gl))) break;
+      if (dphi < 0) lo = al; else hi = al;
+      double an = al - dphi / ddphi;
+      if (hi >= 0 && (an <= lo || an >= hi)) an = 0.5 * (lo + hi);
+      if (hi < 0 && an <= lo) an = 2 * al + 1e-12;
+      if (hi >= 0 && hi - lo < 1e-15 * (1 + hi)) break;
+      al = an;
+    }
+    double st = 0;
+    for (int i = 0; i < 6; i++) { lam[i] += al * dir[i]; st += al * al * dir[i] * dir[i]; }
+    if (sqrt(st) < 1e-15 * (1.0 + sqrt(ln))) break;
+  }
+  const double rf = 0.5 * sqrt(lam[0] * lam[0] + lam[1] * lam[1] + lam[2] * lam[2]);
+  const double rt = 0.5 * sqrt(lam[3] * lam[3] + lam[4] * lam[4] + lam[5] * lam[5]);
+  return (float)(rf + rt);   // |rest_force| + sqrt(w_t) |rest_torque| (:1083)
+}
+
+// ---- termination diffs (calc_ho_diff, ho_im4.py:664-688); out: pos, rot, jpos, obj, obj_rot(=0)
+__device__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& ev, float* out) {
+  const int tid = threadIdx.x, hb0 = m.hand_body0, fr = ev.frame(0);
+  const float* ep = ev.ex->body_pos + (size_t)fr * NHB * 3; const float* eq = ev.ex->body_quat + (size_t)fr * NHB * 4;
+  float s = 0.f;
+  if (tid < NHB) { float dv[3]; for (int i = 0; i < 3; i++) dv[i] = w.xpos[hb0 + tid][i] - ep[3 * tid + i]; s = sqrtf(dot3(dv, dv)); }
+  const float root = rl(s, 0);
+  out[0] = root;
+  out[2] = wave_sum(s) / (float)NHB;
+  float qi[4], qd[4], e4[4] = {eq[0], eq[1], eq[2], eq[3]};
+  quat_inv(w.xquat[hb0], qi); mulquat(e4, qi, qd);
+  out[1] = 2.f * asinf(fminf(fmaxf(sqrtf(qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]), 0.f), 1.f));
+  const float* eo = ev.ex->obj_pose + (size_t)fr * 7;
+  float dv[3];
+  for (int i = 0; i < 3; i++) dv[i] = w.qpos[m.hand_nq + i] - eo[i];
+  out[3] = sqrtf(dot3(dv, dv));
+  float eo4[4] = {eo[3], eo[4], eo[5], eo[6]};
+  quat_inv(eo4, qi); mulquat(eo4, qi, qd);   // :685 uses the expert quaternion twice
+  out[4] = 2.f * asinf(fminf(fmaxf(sqrtf(qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]), 0.f), 1.f));
+}
+
+// ---- ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-1047); out[0] reward, out[1..9] info
+__device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& w, const ExpertView& ev, float rfc_score, float* out) {
+  const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0, fr = ev.frame(0);
+  const float* wk = cfg.rp.wk;
+  const float* eq = ev.ex->hand_dof + (size_t)fr * nh; const float* evel = ev.ex->hand_dof_vel + (size_t)fr * nh;
+  const float* ebq = ev.ex->body_quat + (size_t)fr * NHB * 4; const float* ebp = ev.ex->body_pos + (size_t)fr * NHB * 3;
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  if (tid >= 6 && tid < nh) a = fabsf(w.qpos[tid] - eq[tid]);
+  if (tid < m.hand_nv) c = fabsf(w.qvel[tid] - evel[tid]);
+  if (tid < NHB) {
+    float qi[4], qd[4], e4[4] = {ebq[4 * tid], ebq[4 * tid + 1], ebq[4 * tid + 2], ebq[4 * tid + 3]};
+    quat_inv(e4, qi); mulquat(w.xquat[hb0 + tid], qi, qd);
+    const float w0 = fabsf(qd[0]) - 1.f;
+    b = sqrtf(w0 * w0 + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+    float dv[3];
+    for (int i = 0; i < 3; i++) dv[i] = w.xpos[hb0 + tid][i] - ebp[3 * tid + i];
+    d = sqrtf(dot3(dv, dv));
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+  const float pose_r = expf(-wk[8] * a / (float)(nh - 6)), wpose_r = expf(-wk[9] * b / (float)NHB);
+  const float vel_r = expf(-wk[10] * c / (float)m.hand_nv), jpos_r = expf(-wk[11] * d / (float)NHB);
+  const float* eo = ev.ex->obj_pose + (size_t)fr * 7;
+  float dv[3];
+  for (int i = 0; i < 3; i++) dv[i] = w.qpos[nh + i] - eo[i];
+  const float opos_r = expf(-wk[12] * sqrtf(dot3(dv, dv)));
+  float qi[4], qd[4], eo4[4] = {eo[3], eo[4], eo[5], eo[6]};
+  quat_inv(eo4, qi); mulquat(&w.qpos[nh + 3], qi, qd);
+  const float w0 = fabsf(qd[0]) - 1.f;
+  const float orot_r = expf(-wk[13] * sqrtf(w0 * w0 + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]));
+  float s = 0.f;
+  for (int i = 0; i < 3; i++) s += fabsf(w.qvel[m.hand_nv + i] - ev.ex->obj_vel[(size_t)fr * 3 + i]) +
+                                   fabsf(w.qvel[m.hand_nv + 3 + i] - ev.ex->obj_angvel[(size_t)fr * 3 + i]);
+  const float ovel_r = expf(-wk[14] * s / 6.f);
+  const float orfc_r = cfg.c.residual_force ? expf(-wk[15] * rfc_score) : 1.f;
+  const float hand = (wk[0] * pose_r + wk[1] * wpose_r + wk[3] * jpos_r + wk[2] * vel_r) / (wk[0] + wk[1] + wk[3] + wk[2]);
+  const float obj = (wk[4] * opos_r + wk[5] * orot_r + wk[6] * ovel_r + wk[7] * orfc_r) / (wk[4] + wk[5] + wk[6] + wk[7]);
+  out[0] = hand * obj; out[1] = pose_r; out[2] = wpose_r; out[3] = jpos_r; out[4] = vel_r; out[5] = opos_r;
+  out[6] = orot_r; out[7] = ovel_r; out[8] = orfc_r; out[9] = 1.f;
+}
+
+// ---- get_full_obs_v5(5) (ho_im4.py:280-356): 617 floats written straight to HBM, coalesced per segment
+__device__ void dev_write_obs(const DevModel& m, const Work& w, const ExpertView& ev, float* __restrict__ obs) {
+  const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0;
+  const DevExpert& x = *ev.ex;
+  float R[9], Rqi[4];
+  quat_matrix_ref(w.xquat[hb0], R);
+  quat_inv(w.xquat[hb0], Rqi);
+  const float* P = w.xpos[hb0];
+#define RT(comp, v) (R[(comp)] * (v)[0] + R[3 + (comp)] * (v)[1] + R[6 + (comp)] * (v)[2])
+  if (tid < 6) obs[tid] = R[(tid >> 1) * 3 + (tid & 1)];
+  if (tid < 20) { obs[6 + tid] = w.qpos[6 + tid]; obs[126 + tid] = w.qvel[6 + tid]; }
+  for (int t = tid; t < 100; t += NT) {
+    const int k = t / 20, i = t % 20;
+    obs[26 + t] = x.hand_dof[(size_t)ev.frame(k + 1) * nh + 6 + i] - w.qpos[6 + i];
+  }
+  if (tid < 6) { const float* v = &w.qvel[tid < 3 ? 0 : 3]; obs[146 + tid] = RT(tid % 3, v); }
+  if (tid < 5) {
+    const int fr = ev.frame(tid + 1);
+    const float* tp = x.body_pos + (size_t)fr * NHB * 3; const float* tq = x.body_quat + (size_t)fr * NHB * 4;
+    float t3[3] = {tp[0] - P[0], tp[1] - P[1], tp[2] - P[2]}, q[4], Mm[9], tq4[4] = {tq[0], tq[1], tq[2], tq[3]};
+    float* o = obs + 152 + 9 * tid;
+    for (int c = 0; c < 3; c++) o[c] = RT(c, t3);
+    mulquat(Rqi, tq4, q); quat_matrix_ref(q, Mm);
+    o[3] = Mm[0]; o[4] = Mm[1]; o[5] = Mm[3]; o[6] = Mm[4]; o[7] = Mm[6]; o[8] = Mm[7];
+  }
+  if (tid < 60) {  // component-major (3,20) block: transform_vec_batch quirk (math_utils.py:117-130)
+    const int comp = tid / 20, b = tid % 20 + 1;
+    float v[3] = {w.xpos[hb0 + b][0] - w.qpos[0], w.xpos[hb0 + b][1] - w.qpos[1], w.xpos[hb0 + b][2] - w.qpos[2]};
+    obs[197 + tid] = RT(comp, v);
+  }
+  for (int t = tid; t < 300; t += NT) {
+    const int k = t / 60, r = t % 60, comp = r / 20, b = r % 20 + 1;
+    const float* tp = x.body_pos + (size_t)ev.frame(k + 1) * NHB * 3 + 3 * b;
+    float v[3] = {tp[0] - w.xpos[hb0 + b][0], tp[1] - w.xpos[hb0 + b][1], tp[2] - w.xpos[hb0 + b][2]};
+    obs[257 + t] = RT(comp, v);
+  }
+  const float* op = &w.qpos[nh]; const float* oq = &w.qpos[nh + 3];
+  if (tid == 0) {
+    float t3[3] = {op[0] - P[0], op[1] - P[1], op[2] - P[2]}, q[4], Mm[9];
+    float* o = obs + 557;
+    for (int c = 0; c < 3; c++) o[c] = RT(c, t3);
+    mulquat(Rqi, oq, q); quat_matrix_ref(q, Mm);
+    o[3] = Mm[0]; o[4] = Mm[1]; o[5] = Mm[3]; o[6] = Mm[4]; o[7] = Mm[6]; o[8] = Mm[7];
+  }
+  if (tid < 6) { const float* v = &w.qvel[m.hand_nv + (tid < 3 ? 0 : 3)]; obs[566 + tid] = RT(tid % 3, v); }
+  if (tid < 5) {
+    const float* tp = x.obj_pose + (size_t)ev.frame(tid + 1) * 7;
+    float t3[3] = {tp[0] - op[0], tp[1] - op[1], tp[2] - op[2]}, oqi[4], q2[4], q[4], Mm[9], tq4[4] = {tp[3], tp[4], tp[5], tp[6]};
+    float* o = obs + 572 + 9 * tid;
+    for (int c = 0; c < 3; c++) o[c] = RT(c, t3);
+    quat_inv(oq, oqi); mulquat(tq4, oqi, q2); mulquat(Rqi, q2, q); quat_matrix_ref(q, Mm);
+    o[3] = Mm[0]; o[4] = Mm[1]; o[5] = Mm[3]; o[6] = Mm[4]; o[7] = Mm[6]; o[8] = Mm[7];
+  }
+#undef RT
+}
+
+// ---- reset_model (ho_im4.py:690-716): state <- expert frame `start` of sequence `seq`
+__device__ void dev_reset_state(const DevModel& m, Work& w, const DevExpert& x, int seq, int start) {
+  const int tid = threadIdx.x;
+  const int len = x.seq_len[seq], off = x.seq_off[seq];
+  const int fr = off + (start < len - 1 ? start : len - 1), nh = m.hand_nq;
+  if (tid < nh) { w.qpos[tid] = x.hand_dof[(size_t)fr * nh + tid]; w.qvel[tid] = x.hand_dof_vel[(size_t)fr * nh + tid]; }
+  if (tid < 7) w.qpos[nh + tid] = x.obj_pose[(size_t)fr * 7 + tid];
+  if (tid < 3) { w.qvel[m.hand_nv + tid] = x.obj_vel[(size_t)fr * 3 + tid]; w.qvel[m.hand_nv + 3 + tid] = x.obj_angvel[(size_t)fr * 3 + tid]; }
+  __syncthreads();
+  if (tid < NQP) w.qlag[tid] = tid < m.nq ? w.qpos[tid] : 0.f;
+  if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = 0.f; w.qacc[tid] = 0.f; }
+  __syncthreads();
+}

@@ -1,0 +1,81 @@
+// hoic_math.h — small float math helpers for the device code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define HD __device__ __forceinline__
+#define MINVALF 1e-15f
+
+HD float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+HD void cross3(const float* a, const float* b, float* o) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+HD float normalize3(float* a) {
+  float n = sqrtf(dot3(a, a));
+  if (n < 1e-20f) { a[0] = 1.f; a[1] = 0.f; a[2] = 0.f; return 0.f; }
+  float inv = 1.f / n;
+  a[0] *= inv; a[1] *= inv; a[2] *= inv;
+  return n;
+}
+HD void quat2mat(const float* q, float* R) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2.f * (x * y - w * z); R[2] = 2.f * (x * z + w * y);
+  R[3] = 2.f * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2.f * (y * z - w * x);
+  R[6] = 2.f * (x * z - w * y); R[7] = 2.f * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+HD void mulquat(const float* a, const float* b, float* o) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+HD void normquat(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < 1e-20f) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; return; }
+  float inv = 1.f / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+HD void matvec(const float* R, const float* v, float* o) {
+  float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+        z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+HD void mattvec(const float* R, const float* v, float* o) {
+  float x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+        z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+HD void matcol(const float* R, int k, float* o) { o[0] = R[k]; o[1] = R[3 + k]; o[2] = R[6 + k]; }
+
+// reference-compatible helpers (uhc/utils/transformation.py quaternion_inverse / quaternion_matrix)
+HD void quat_inv(const float* q, float* o) {
+  float n = 1.f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  o[0] = q[0] * n; o[1] = -q[1] * n; o[2] = -q[2] * n; o[3] = -q[3] * n;
+}
+HD void quat_matrix_ref(const float* qin, float* R) {
+  float n = qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3];
+  if (n < 1e-12f) { R[0] = R[4] = R[8] = 1.f; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.f; return; }
+  float s = sqrtf(2.f / n), q[4] = {qin[0] * s, qin[1] * s, qin[2] * s, qin[3] * s};
+  R[0] = 1.f - q[2] * q[2] - q[3] * q[3]; R[1] = q[1] * q[2] - q[3] * q[0]; R[2] = q[1] * q[3] + q[2] * q[0];
+  R[3] = q[1] * q[2] + q[3] * q[0]; R[4] = 1.f - q[1] * q[1] - q[3] * q[3]; R[5] = q[2] * q[3] - q[1] * q[0];
+  R[6] = q[1] * q[3] - q[2] * q[0]; R[7] = q[2] * q[3] + q[1] * q[0]; R[8] = 1.f - q[1] * q[1] - q[2] * q[2];
+}
+
+// wavefront (64-lane) reductions
+HD float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+HD double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+HD float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+HD float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }

@@ -1,0 +1,249 @@
+"""ctypes binding of the C-ABI in ``include/hoic.h`` (``libhoic_hip.so``).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is present, constructing a
+simulator raises.  PyTorch is used only for device memory and streams (tensor ``data_ptr()``s are
+handed to the C-ABI as plain pointers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhoic_hip.so")
+OBS_DIM, ACT_DIM, NQ, NV, NU, NHB, NINFO = 617, 32, 33, 32, 26, 21, 9
+PROBE_MAXCON = 32
+
+_lib = None
+
+
+class HoicError(RuntimeError):
+    pass
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [("jkp", C.c_float * 26), ("jkd", C.c_float * 26), ("torque_lim", C.c_float * 26),
+                ("pos_diff_thresh", C.c_float), ("rot_diff_thresh", C.c_float), ("jpos_diff_thresh", C.c_float),
+                ("obj_pos_diff_thresh", C.c_float), ("obj_rot_diff_thresh", C.c_float),
+                ("residual_force_scale", C.c_float), ("residual_torque_scale", C.c_float),
+                ("sim_step", C.c_int32), ("future_w_size", C.c_int32), ("residual_force", C.c_int32),
+                ("explain_force", C.c_int32), ("surface_contact", C.c_int32), ("pd_rel", C.c_int32),
+                ("solver_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RewardParams(C.Structure):
+    _fields_ = [("wk", C.c_float * 16), ("end_reward", C.c_float), ("use_end_reward", C.c_int32)]
+
+
+EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
+           "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
+           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_enable_timing",
+           "hoic_last_step_ms"]
+
+
+def build(force: bool = False) -> str:
+    """Compile libhoic_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("hoic.h", "hoic_model.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", csrc, "-s"], stderr=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and declare signatures. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HoicError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    L.hoic_create.restype = vp
+    L.hoic_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32]
+    L.hoic_destroy.argtypes = [vp]
+    L.hoic_destroy.restype = None
+    L.hoic_last_error.restype = C.c_char_p
+    for n in ("hoic_num_envs", "hoic_obs_dim", "hoic_action_dim"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = i32
+    L.hoic_set_config.argtypes = [vp, C.POINTER(EnvConfig)]
+    L.hoic_set_reward_params.argtypes = [vp, C.POINTER(RewardParams)]
+    L.hoic_set_mode.argtypes = [vp, i32]
+    L.hoic_set_expert.argtypes = [vp, i32] + [vp] * 8
+    L.hoic_reset.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.hoic_step.argtypes = [vp] + [vp] * 9
+    L.hoic_get_state.argtypes = [vp, vp, vp, vp, vp]
+    L.hoic_set_state.argtypes = [vp, vp, vp, vp]
+    L.hoic_get_rfc_score.argtypes = [vp, vp, vp]
+    L.hoic_probe_forward.argtypes = [vp, i32] + [vp] * 5 + [i32] + [vp] * 13
+    L.hoic_enable_timing.argtypes = [vp, i32]
+    L.hoic_last_step_ms.argtypes = [vp]
+    L.hoic_last_step_ms.restype = f32
+    for n in EXPORTS:
+        if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms"):
+            getattr(L, n).restype = i32
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise HoicError(f"{what} failed ({rc}): {load().hoic_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedSim:
+    """Thin owner of one ``hoic_sim`` (n_envs environments on one GPU)."""
+
+    def __init__(self, model_blob: bytes, n_envs: int, device_index: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise HoicError("no GPU visible: the batched simulator has no CPU path")
+        self.torch = torch
+        self.L = load()
+        self.n = int(n_envs)
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        from .mjcf import CompiledModel
+        self.model = CompiledModel.from_blob(model_blob)
+        self.h = self.L.hoic_create(model_blob, len(model_blob), self.n, device_index)
+        if not self.h:
+            raise HoicError("hoic_create failed: " + self.L.hoic_last_error().decode())
+        f = dict(device=self.device, dtype=torch.float32)
+        self.obs = torch.zeros(self.n, OBS_DIM, **f)
+        self.reward = torch.zeros(self.n, **f)
+        self.reward_info = torch.zeros(self.n, NINFO, **f)
+        self.flags = torch.zeros(self.n, 4, device=self.device, dtype=torch.int32)
+        self.percent = torch.zeros(self.n, **f)
+        self.seq_len = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.torch.cuda.synchronize(self.device)
+            self.L.hoic_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- configuration
+    def set_config(self, jkp, jkd, torque_lim, thresh=(0.1, 1.0, 0.1, 0.1, 1.0), rf_scale=2.5, rt_scale=0.125,
+                   sim_step=15, residual_force=True, explain_force=True, surface_contact=True, pd_rel=True,
+                   solver_iterations=8):
+        c = EnvConfig()
+        for i in range(26):
+            c.jkp[i], c.jkd[i], c.torque_lim[i] = float(jkp[i]), float(jkd[i]), float(torque_lim[i])
+        (c.pos_diff_thresh, c.rot_diff_thresh, c.jpos_diff_thresh, c.obj_pos_diff_thresh,
+         c.obj_rot_diff_thresh) = [float(x) for x in thresh]
+        c.residual_force_scale, c.residual_torque_scale = float(rf_scale), float(rt_scale)
+        c.sim_step, c.future_w_size = int(sim_step), 5
+        c.residual_force, c.explain_force, c.surface_contact = int(residual_force), int(explain_force), int(surface_contact)
+        c.pd_rel, c.solver_iterations = int(pd_rel), int(solver_iterations)
+        self.torch.cuda.synchronize(self.device)
+        _chk(self.L.hoic_set_config(self.h, C.byref(c)), "hoic_set_config")
+
+    def set_reward_params(self, wk, end_reward=0.0, use_end_reward=True):
+        r = RewardParams()
+        for i in range(16):
+            r.wk[i] = float(wk[i])
+        r.end_reward, r.use_end_reward = float(end_reward), int(use_end_reward)
+        self.torch.cuda.synchronize(self.device)
+        _chk(self.L.hoic_set_reward_params(self.h, C.byref(r)), "hoic_set_reward_params")
+
+    def set_mode(self, train: bool):
+        self.torch.cuda.synchronize(self.device)
+        _chk(self.L.hoic_set_mode(self.h, int(train)), "hoic_set_mode")
+
+    def set_expert(self, seqs):
+        """seqs: list of dicts with the DatasetSingleDepth.preprocess_seq keys."""
+        keys = ("hand_dof_seq", "hand_dof_vel_seq", "obj_pose_seq", "obj_vel_seq", "obj_angle_vel_seq",
+                "body_pos_seq", "body_quat_seq")
+        lens = np.array([s["hand_dof_seq"].shape[0] for s in seqs], dtype=np.int32)
+        cat = [np.ascontiguousarray(np.concatenate([np.asarray(s[k], dtype=np.float32).reshape(s[k].shape[0], -1)
+                                                    for s in seqs], 0)) for k in keys]
+        _chk(self.L.hoic_set_expert(self.h, len(seqs), lens.ctypes.data_as(C.c_void_p),
+                                    *[a.ctypes.data_as(C.c_void_p) for a in cat]), "hoic_set_expert")
+        self.seq_len = lens
+
+    # ---- stepping
+    def reset(self, seq, start, env_ids=None):
+        t = self.torch
+        seq = t.as_tensor(seq, dtype=t.int32, device=self.device).contiguous()
+        start = t.as_tensor(start, dtype=t.int32, device=self.device).contiguous()
+        ids = None if env_ids is None else t.as_tensor(env_ids, dtype=t.int32, device=self.device).contiguous()
+        n = seq.numel()
+        _chk(self.L.hoic_reset(self.h, _ptr(ids), n, _ptr(seq), _ptr(start), _ptr(self.obs), self._stream()), "hoic_reset")
+        return self.obs
+
+    def step(self, action, next_seq=None, next_start=None):
+        t = self.torch
+        a = action.to(device=self.device, dtype=t.float32).contiguous()
+        assert a.shape == (self.n, ACT_DIM)
+        if next_seq is not None:
+            next_seq = next_seq.to(device=self.device, dtype=t.int32).contiguous()
+            next_start = next_start.to(device=self.device, dtype=t.int32).contiguous()
+        _chk(self.L.hoic_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.reward), _ptr(self.reward_info),
+                              _ptr(self.flags), _ptr(self.percent), _ptr(next_seq), _ptr(next_start), self._stream()),
+             "hoic_step")
+        return self.obs, self.reward, self.reward_info, self.flags, self.percent
+
+    def get_state(self):
+        t = self.torch
+        qpos = t.zeros(self.n, NQ, device=self.device); qvel = t.zeros(self.n, NV, device=self.device)
+        cur_t = t.zeros(self.n, dtype=t.int32, device=self.device)
+        _chk(self.L.hoic_get_state(self.h, _ptr(qpos), _ptr(qvel), _ptr(cur_t), self._stream()), "hoic_get_state")
+        return qpos, qvel, cur_t
+
+    def set_state(self, qpos, qvel):
+        t = self.torch
+        qpos = qpos.to(device=self.device, dtype=t.float32).contiguous()
+        qvel = qvel.to(device=self.device, dtype=t.float32).contiguous()
+        _chk(self.L.hoic_set_state(self.h, _ptr(qpos), _ptr(qvel), self._stream()), "hoic_set_state")
+
+    def rfc_score(self):
+        out = self.torch.zeros(self.n, device=self.device)
+        _chk(self.L.hoic_get_rfc_score(self.h, _ptr(out), self._stream()), "hoic_get_rfc_score")
+        return out
+
+    def enable_timing(self, on=True):
+        _chk(self.L.hoic_enable_timing(self.h, int(on)), "hoic_enable_timing")
+
+    def last_step_ms(self):
+        return float(self.L.hoic_last_step_ms(self.h))
+
+    def probe_forward(self, qpos, qvel, ctrl=None, applied=None, warm=None, do_step=False):
+        """mj_forward (+ Euler) at arbitrary states; returns a dict of numpy arrays."""
+        t = self.torch
+        f = dict(device=self.device, dtype=t.float32)
+        qpos = t.as_tensor(np.asarray(qpos), **f).contiguous(); qvel = t.as_tensor(np.asarray(qvel), **f).contiguous()
+        n = qpos.shape[0]
+        cv = lambda x: None if x is None else t.as_tensor(np.asarray(x), **f).contiguous()
+        ctrl, applied, warm = cv(ctrl), cv(applied), cv(warm)
+        nb, ng = self.model.scalar("nbody"), self.model.scalar("ngeom")
+        o = dict(xpos=t.zeros(n, nb, 3, **f), xquat=t.zeros(n, nb, 4, **f), geom_xpos=t.zeros(n, ng, 3, **f),
+                 geom_xmat=t.zeros(n, ng, 9, **f), qM=t.zeros(n, NV, NV, **f), bias=t.zeros(n, NV, **f),
+                 ncon=t.zeros(n, device=self.device, dtype=t.int32), contacts=t.zeros(n, PROBE_MAXCON, 16, **f),
+                 qacc_smooth=t.zeros(n, NV, **f), qacc=t.zeros(n, NV, **f), qpos_out=t.zeros(n, NQ, **f),
+                 qvel_out=t.zeros(n, NV, **f), iters=t.zeros(n, device=self.device, dtype=t.int32))
+        _chk(self.L.hoic_probe_forward(self.h, n, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(applied), _ptr(warm), int(do_step),
+                                       _ptr(o["xpos"]), _ptr(o["xquat"]), _ptr(o["geom_xpos"]), _ptr(o["geom_xmat"]), _ptr(o["qM"]),
+                                       _ptr(o["bias"]), _ptr(o["ncon"]), _ptr(o["contacts"]), _ptr(o["qacc_smooth"]),
+                                       _ptr(o["qacc"]), _ptr(o["qpos_out"]), _ptr(o["qvel_out"]), _ptr(o["iters"]),
+                                       self._stream()), "hoic_probe_forward")
+        t.cuda.synchronize(self.device)
+        return {k: v.cpu().numpy() for k, v in o.items()}

@@ -1,0 +1,206 @@
+"""Expert-sequence preprocessing and synthetic reference motions.
+
+``preprocess_seq`` mirrors ``DatasetSingleDepth.preprocess_seq`` (uhc/data_loaders/dataset_singledepth.py:78-142):
+clamp hand DoFs to the joint limits (:100), finite-difference velocities at ``motion_freq`` with angle wrap on
+DoFs 3:6 (:152-170), object linear / angular velocity (:172-183) and forward kinematics of every frame for
+``body_pos_seq`` / ``body_quat_seq`` (:222-237) — here with a batched NumPy FK over the compiled model instead
+of one MuJoCo ``sim.forward()`` per frame.
+
+``synthetic_sequences`` generates the stand-in dataset of SURVEY.md §8(d) (the real pkl is a Google-Drive
+download, README.md:61): same schema ``{hand_pose_seq (T,26), obj_pose_seq (T,7 = xyz + wxyz)}``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import mjcf
+
+
+# ----------------------------------------------------------------------------- batched quaternion helpers
+def qmul(a, b):
+    w1, x1, y1, z1 = np.moveaxis(a, -1, 0)
+    w2, x2, y2, z2 = np.moveaxis(b, -1, 0)
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
+
+
+def qrot(q, v):
+    """rotate v by unit quaternion q (batched)."""
+    w = q[..., :1]
+    u = q[..., 1:]
+    t = 2 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+def qmat(q):
+    w, x, y, z = np.moveaxis(q, -1, 0)
+    return np.stack([np.stack([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                     np.stack([2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)], -1),
+                     np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z], -1)], -2)
+
+
+def fk_batch(model: mjcf.CompiledModel, qpos: np.ndarray):
+    """Forward kinematics for a batch of configurations -> (xpos (T,nbody,3), xquat (T,nbody,4))."""
+    A = model.arrays
+    T = qpos.shape[0]
+    nb = model.scalar("nbody")
+    xpos = np.zeros((T, nb, 3)); xquat = np.zeros((T, nb, 4)); xquat[:, :, 0] = 1
+    for b in range(1, nb):
+        p = A["body_parent"][b]; ja, jn = A["body_jntadr"][b], A["body_jntnum"][b]
+        if jn == 1 and A["jnt_type"][ja] == mjcf.JNT_FREE:
+            qa = A["jnt_qposadr"][ja]
+            pos = qpos[:, qa:qa + 3].copy(); quat = qpos[:, qa + 3:qa + 7].copy()
+            quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+        else:
+            pos = xpos[:, p] + qrot(xquat[:, p], np.broadcast_to(A["body_pos"][b], (T, 3)))
+            quat = qmul(xquat[:, p], np.broadcast_to(A["body_quat"][b], (T, 4)))
+            for j in range(ja, ja + jn):
+                anchor = pos + qrot(quat, np.broadcast_to(A["jnt_pos"][j], (T, 3)))
+                axis = qrot(quat, np.broadcast_to(A["jnt_axis"][j], (T, 3)))
+                q = qpos[:, A["jnt_qposadr"][j]] - A["qpos0"][A["jnt_qposadr"][j]]
+                if A["jnt_type"][j] == mjcf.JNT_SLIDE:
+                    pos = pos + axis * q[:, None]
+                else:
+                    ql = np.concatenate([np.cos(q / 2)[:, None], np.sin(q / 2)[:, None] * A["jnt_axis"][j][None]], 1)
+                    quat = qmul(quat, ql)
+                    pos = anchor - qrot(quat, np.broadcast_to(A["jnt_pos"][j], (T, 3)))
+            quat = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+        xpos[:, b] = pos; xquat[:, b] = quat
+    return xpos, xquat
+
+
+# ----------------------------------------------------------------------------- rotation conversions
+def matrix_to_axis_angle(R):
+    """uhc/utils/transforms.py:414 (matrix_to_quaternion :99 then quaternion_to_axis_angle :462), NumPy."""
+    R = np.asarray(R, dtype=np.float64)
+    m = R.reshape(-1, 9)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.T
+    qa = np.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)
+    qa = np.sqrt(np.maximum(qa, 0))
+    cand = np.stack([np.stack([qa[:, 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+                     np.stack([m21 - m12, qa[:, 1] ** 2, m10 + m01, m02 + m20], -1),
+                     np.stack([m02 - m20, m10 + m01, qa[:, 2] ** 2, m12 + m21], -1),
+                     np.stack([m10 - m01, m20 + m02, m21 + m12, qa[:, 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * np.maximum(qa[..., None], 0.1))
+    best = np.argmax(qa, axis=-1)
+    q = cand[np.arange(m.shape[0]), best]
+    nrm = np.linalg.norm(q[:, 1:], axis=-1, keepdims=True)
+    half = np.arctan2(nrm, q[:, :1]); ang = 2 * half
+    small = np.abs(ang) < 1e-6
+    s = np.where(small, 0.5 - ang * ang / 48, np.sin(half) / np.where(small, 1.0, ang))
+    return (q[:, 1:] / s).reshape(R.shape[:-2] + (3,))
+
+
+def compute_vel_from_seq(hand_dof_seq, obj_pose_seq, motion_freq=30):
+    """dataset_singledepth.py:152-185."""
+    hv = np.zeros_like(hand_dof_seq)
+    hv[1:] = hand_dof_seq[1:] - hand_dof_seq[:-1]
+    hv[0] = hv[1]
+    rot = hv[:, 3:6].copy()
+    while np.any(rot > np.pi):
+        rot[rot > np.pi] -= 2 * np.pi
+    while np.any(rot < -np.pi):
+        rot[rot < -np.pi] += 2 * np.pi
+    hv[:, 3:6] = rot
+    hv = hv * motion_freq
+    ov = np.zeros_like(obj_pose_seq[:, :3])
+    ov[1:] = obj_pose_seq[1:, :3] - obj_pose_seq[:-1, :3]
+    ov[0] = ov[1]
+    ov = ov * motion_freq
+    # quaternion_to_matrix (transforms.py:38) normalises by 2/|q|^2
+    q = obj_pose_seq[:, 3:]
+    Rm = qmat(q / np.linalg.norm(q, axis=1, keepdims=True))
+    rel = np.matmul(Rm[1:], np.transpose(Rm[:-1], (0, 2, 1)))
+    oav = np.zeros_like(ov)
+    oav[1:] = matrix_to_axis_angle(rel) * motion_freq
+    oav[0] = oav[1]
+    return hv, ov, oav
+
+
+def preprocess_seq(model: mjcf.CompiledModel, seq: dict, motion_freq: int = 30) -> dict:
+    """One raw sequence -> the expert dict HandObjMimic4 consumes (see module docstring)."""
+    A = model.arrays
+    nh = model.scalar("hand_nq")
+    lo, hi = A["jnt_range"][:nh, 0], A["jnt_range"][:nh, 1]
+    hand = np.clip(np.asarray(seq["hand_pose_seq"], dtype=np.float64), lo, hi)
+    obj = np.asarray(seq["obj_pose_seq"], dtype=np.float64).copy()
+    hv, ov, oav = compute_vel_from_seq(hand, obj, motion_freq)
+    T = hand.shape[0]
+    qpos = np.zeros((T, model.scalar("nq")))
+    qpos[:, :nh] = hand
+    qpos[:, nh:] = A["qpos0"][nh:]      # the reference's FK sim leaves the object at qpos0 (:228-230)
+    xpos, xquat = fk_batch(model, qpos)
+    hb0, nhb = model.scalar("hand_body0"), model.scalar("hand_nbody")
+    return {"hand_dof_seq": hand, "hand_dof_vel_seq": hv, "obj_pose_seq": obj, "obj_vel_seq": ov,
+            "obj_angle_vel_seq": oav, "body_pos_seq": xpos[:, hb0:hb0 + nhb].copy(),
+            "body_quat_seq": xquat[:, hb0:hb0 + nhb].copy(), "seq_len": T}
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def _euler_xyz_quat(e):
+    cx, cy, cz = np.cos(e / 2).T
+    sx, sy, sz = np.sin(e / 2).T
+    qx = np.stack([cx, sx, 0 * sx, 0 * sx], -1); qy = np.stack([cy, 0 * sy, sy, 0 * sy], -1)
+    qz = np.stack([cz, 0 * sz, 0 * sz, sz], -1)
+    return qmul(qmul(qx, qy), qz)
+
+
+def _slerp(q0, q1, t):
+    d = np.sum(q0 * q1, -1, keepdims=True)
+    q1 = np.where(d < 0, -q1, q1); d = np.abs(d)
+    th = np.arccos(np.clip(d, -1, 1))
+    s = np.sin(th)
+    w0 = np.where(s < 1e-6, 1 - t, np.sin((1 - t) * th) / np.where(s < 1e-6, 1, s))
+    w1 = np.where(s < 1e-6, t, np.sin(t * th) / np.where(s < 1e-6, 1, s))
+    q = w0 * q0 + w1 * q1
+    return q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+
+def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_half_height: float = 0.0165) -> dict:
+    rng = np.random.default_rng(seed)
+    A = model.arrays
+    nh = model.scalar("hand_nq")
+    t = np.arange(T) / 30.0
+    lo, hi = A["jnt_range"][:nh, 0], A["jnt_range"][:nh, 1]
+
+    def smooth(n, amp, fmax=0.5):
+        out = np.zeros((T, n))
+        for _ in range(3):
+            f = rng.uniform(0.05, fmax, n); ph = rng.uniform(0, 2 * np.pi, n); a = rng.uniform(0.2, 1.0, n) * amp / 3
+            out += a * np.sin(2 * np.pi * f * t[:, None] + ph)
+        return out
+    hand = np.zeros((T, nh))
+    hand[:, :3] = np.array([0.0, 0.0, 0.62]) + smooth(3, 0.05)
+    hand[:, 3:6] = smooth(3, 0.3)
+    mid, rng_w = 0.5 * (lo + hi), (hi - lo)
+    f = rng.uniform(0.1, 0.5, nh - 6); ph = rng.uniform(0, 2 * np.pi, nh - 6)
+    hand[:, 6:] = mid[6:] + 0.3 * rng_w[6:] * 0.5 * np.sin(2 * np.pi * f * t[:, None] + ph)
+    hand = np.clip(hand, lo, hi)
+    # object: on the table for t < 100 frames, rigidly attached under the palm (palm -z) after frame 160
+    palm_q = _euler_xyz_quat(hand[:, 3:6])
+    off = np.array([0.0, 0.045, -0.06])
+    rel_q = np.array([np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0])       # long axis of the object along palm x
+    grasp_p = hand[:, :3] + qrot(palm_q, np.broadcast_to(off, (T, 3)))
+    grasp_q = qmul(palm_q, np.broadcast_to(rel_q, (T, 4)))
+    rest_p = np.array([hand[0, 0] + rng.uniform(-0.03, 0.03), hand[0, 1] + 0.04 + rng.uniform(-0.02, 0.02), 0.5 + obj_half_height + 0.0005])
+    rest_q = np.broadcast_to(rel_q, (T, 4))
+    s = np.clip((np.arange(T) - 100) / 60.0, 0, 1)
+    s = (s * s * (3 - 2 * s))[:, None]
+    obj_p = (1 - s) * rest_p + s * grasp_p
+    obj_q = _slerp(rest_q, grasp_q, s)
+    return {"hand_pose_seq": hand, "obj_pose_seq": np.concatenate([obj_p, obj_q], 1)}
+
+
+def synthetic_sequences(model, n_seq: int = 17, T: int = 600, seed0: int = 0):
+    """17 sequences (16 train + 1 held out, agent_handmimic.py:344,444), seeds seed0..seed0+n_seq-1."""
+    return [synthetic_sequence(model, seed0 + i, T) for i in range(n_seq)]
+
+
+def synthetic_expert(model, n_seq: int = 17, T: int = 600, seed0: int = 0):
+    return [preprocess_seq(model, s) for s in synthetic_sequences(model, n_seq, T, seed0)]
+
+
+def action_tape(n_steps: int, n_envs: int = 1, seed: int = 123, scale: float = 0.2):
+    """Parity-run action tape: U(-1,1) * 0.2, seed 123."""
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-1, 1, (n_steps, n_envs, 32)) * scale).astype(np.float64)

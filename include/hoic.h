@@ -1,0 +1,118 @@
+/* hoic.h — C-ABI of the MI355X-native batched HandObjMimic simulator (libhoic_hip.so).
+ *
+ * The reference has no FFI of its own for this path: its boundary is the mujoco_py call set underneath
+ * HandObjMimic4.  Each entry point below names the reference interface it replaces.
+ * All pointers named d_* are DEVICE pointers (HBM, e.g. torch tensor .data_ptr()); everything else is
+ * host memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions return 0 on
+ * success, a negative hoic_status otherwise; they never throw.  Per-env simulation failures are reported
+ * through the `fail` output flags, like the reference's try/except around do_simulation
+ * (uhc/envs/ho_im4.py:627-637).
+ */
+#ifndef HOIC_H
+#define HOIC_H
+#include <stddef.h>
+#include <stdint.h>
+#include "hoic_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hoic_sim hoic_sim;
+
+enum hoic_status {
+  HOIC_OK = 0,
+  HOIC_ERR_ARG = -1,
+  HOIC_ERR_MODEL = -2,
+  HOIC_ERR_DEVICE = -3,
+  HOIC_ERR_STATE = -4
+};
+
+/* Environment configuration: the fields HandObjMimic4.__init__ reads from cfg
+ * (uhc/envs/ho_im4.py:46-107; values from config/release/*.yml via handmimic_config.py:75-143). */
+typedef struct hoic_env_config {
+  float jkp[HOIC_MAX_NU], jkd[HOIC_MAX_NU], torque_lim[HOIC_MAX_NU]; /* joint_params, yml:116-143 */
+  float pos_diff_thresh, rot_diff_thresh, jpos_diff_thresh, obj_pos_diff_thresh, obj_rot_diff_thresh;
+  float residual_force_scale, residual_torque_scale;
+  int32_t sim_step;        /* frame_skip, 15 */
+  int32_t future_w_size;   /* 5 (obs layout is compiled for 5) */
+  int32_t residual_force, explain_force, surface_contact;
+  int32_t pd_rel;          /* pd_type == "rel" */
+  int32_t solver_iterations; /* Newton iteration cap per substep (fp32) */
+  int32_t reserved;
+} hoic_env_config;
+
+/* Reward parameters of ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-967); refreshed every epoch by
+ * Config.update_adaptive_params (handmimic_config.py:157-195). Order:
+ * w_p,w_wp,w_v,w_j,w_op,w_or,w_ov,w_orfc, k_p,k_wp,k_v,k_j,k_op,k_or,k_ov,k_orfc */
+typedef struct hoic_reward_params {
+  float wk[16];
+  float end_reward;   /* env.end_reward, added when info['end'] (agent_handmimic.py:479-480) */
+  int32_t use_end_reward;
+} hoic_reward_params;
+
+/* ---- lifetime -----------------------------------------------------------------------------------
+ * replaces mujoco_py.load_model_from_path + MjSim(model) (mujoco_env.py:18-34) for n_envs environments */
+hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t n_envs, int32_t device_id);
+void hoic_destroy(hoic_sim* s);
+int32_t hoic_num_envs(const hoic_sim* s);
+int32_t hoic_obs_dim(const hoic_sim* s);     /* observation_space.shape[0] = 617 */
+int32_t hoic_action_dim(const hoic_sim* s);  /* action_space.shape[0] = 32 */
+const char* hoic_last_error(void);
+
+int32_t hoic_set_config(hoic_sim* s, const hoic_env_config* cfg);
+int32_t hoic_set_reward_params(hoic_sim* s, const hoic_reward_params* rp);
+int32_t hoic_set_mode(hoic_sim* s, int32_t train); /* set_mode('train'|'test'), ho_im4.py:132 */
+
+/* ---- expert motions: set_expert for every sequence at once (ho_im4.py:135; arrays are the output of
+ * DatasetSingleDepth.preprocess_seq, dataset_singledepth.py:78-142).  Host float32 arrays, sequences
+ * concatenated along time: hand_dof[T,26], hand_dof_vel[T,26], obj_pose[T,7], obj_vel[T,3],
+ * obj_angvel[T,3], body_pos[T,21,3], body_quat[T,21,4]; seq_len[n_seq] sums to T. */
+int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* seq_len, const float* hand_dof,
+                        const float* hand_dof_vel, const float* obj_pose, const float* obj_vel,
+                        const float* obj_angvel, const float* body_pos, const float* body_quat);
+
+/* ---- reset: MujocoEnv.reset + HandObjMimic4.reset_model (mujoco_env.py:95-114, ho_im4.py:690-716) for the
+ * envs listed in d_env_ids (n entries, int32; NULL = all envs in order).  d_seq / d_start: per listed env,
+ * the sequence index and start frame (agent_handmimic.py:444-452).  d_obs_out: [n_envs,617] rows of the
+ * listed envs are overwritten. */
+int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, const int32_t* d_seq, const int32_t* d_start,
+                   float* d_obs_out, void* stream);
+
+/* ---- step: HandObjMimic4.step for every env (ho_im4.py:611-662) fused with ho_mimic_reward_9.
+ * d_action [n_envs,32]; outputs: d_obs [n_envs,617], d_reward [n_envs] (custom reward incl. end reward),
+ * d_reward_info [n_envs,9], d_flags [n_envs,4] int32 = fail,end,done,reserved; d_percent [n_envs].
+ * If d_next_seq/d_next_start are non-NULL, envs that are done are reset in the same launch to that
+ * sequence/start (the sampler's next-episode draw) and d_obs holds the reset observation for them. */
+int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, float* d_reward, float* d_reward_info,
+                  int32_t* d_flags, float* d_percent, const int32_t* d_next_seq, const int32_t* d_next_start,
+                  void* stream);
+
+/* ---- state access: MjSim.get_state / set_state (mujoco_env.py:109-113) and the data.* reads of the env.
+ * d_qpos [n_envs,33], d_qvel [n_envs,32]; set_state also clears warm start and makes lagged == current. */
+int32_t hoic_get_state(hoic_sim* s, float* d_qpos, float* d_qvel, int32_t* d_cur_t, void* stream);
+int32_t hoic_set_state(hoic_sim* s, const float* d_qpos, const float* d_qvel, void* stream);
+/* rfc_score of the last step (env.rfc_score, ho_im4.py:631) */
+int32_t hoic_get_rfc_score(hoic_sim* s, float* d_score, void* stream);
+
+/* ---- probe: one mj_forward (+ optional Euler step) at given state, dumping the mjData fields the env reads
+ * (sim.forward()/sim.step() + data.qM, qfrc_bias, body_xpos, body_xquat, geom_xpos, contact[], qacc;
+ * call sites ho_im4.py:383,398-401,545,810-829,884).  Used by the parity tests.  All device pointers, any
+ * output may be NULL.  d_ctrl [n,26], d_applied [n,32], d_warm [n,32] may be NULL (zeros).
+ * d_contacts [n,HOIC_PROBE_MAXCON,16] rows: dist,pos[3],frame[9],geom1,geom2,dim. */
+#define HOIC_PROBE_MAXCON 32
+int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const float* d_qvel, const float* d_ctrl,
+                           const float* d_applied, const float* d_warm, int32_t do_step, float* d_xpos,
+                           float* d_xquat, float* d_geom_xpos, float* d_geom_xmat, float* d_qM, float* d_bias,
+                           int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
+                           float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream);
+
+/* duration in milliseconds of the most recent hoic_step kernel launch measured with HIP events on the
+ * launch stream (negative if timing was not enabled via hoic_enable_timing) */
+int32_t hoic_enable_timing(hoic_sim* s, int32_t enable);
+float hoic_last_step_ms(hoic_sim* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
