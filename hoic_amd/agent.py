@@ -1,0 +1,316 @@
+"""Agent surface of the reference, on device.
+
+``AgentHandMimic`` mirrors ``uhc/agents/agent_handmimic.py:24-535`` on top of ``AgentPPO``/``AgentPG``/``Agent``
+(uhc/khrylib/rl/agents/{agent_ppo,agent_pg,agent}.py): ``sample(min_batch_size) -> (batch, logger)``,
+``update_params(batch)``, ``optimize_policy(epoch)``, ``eval_policy``, ``save_checkpoint/load_checkpoint`` with
+the same checkpoint dict keys.  What changes is WHERE things run:
+
+* the reference forks ``num_threads`` CPU workers, each stepping one MuJoCo env with a batch-1 fp64 policy
+  forward, and pickles Memories back through a Queue (:421-535).  Here all ``n_envs`` environments advance in
+  one HIP launch per step and states/actions/rewards are written straight into device rollout buffers;
+* GAE is a reverse scan over time on device (the reference loops over >=50k samples in Python on the CPU);
+* with several GPUs every rank owns its envs and a full replica; only policy/value gradients (one flat
+  bucket each), three scalars for the advantage normalisation and the ZFilter moments cross xGMI (RCCL).
+
+Deliberate, documented differences to the reference: fixed-horizon batches (``ceil(min_batch/n_envs)`` steps of
+every env) with a value bootstrap at the cut instead of whole episodes; float32 instead of float64.
+"""
+from __future__ import annotations
+
+import math
+import os
+import pickle
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import motions
+from .config import Config
+from .env import BatchedHandObjMimic
+from .rl import MLP, BatchZFilter, PolicyGaussian, RunningStat, Value, ZFilter, estimate_advantages, ppo_loss
+
+
+class RefUnpickler(pickle.Unpickler):
+    """Loads the reference's checkpoints (their ZFilter/RunningStat pickles, uhc/utils/tools.py:7-19)."""
+
+    def find_class(self, module, name):
+        if name == "ZFilter":
+            return ZFilter
+        if name == "RunningStat":
+            return RunningStat
+        return super().find_class(module, name)
+
+
+class LoggerRL(SimpleNamespace):
+    """Fields of uhc/khrylib/rl/core/logger_rl.py the training loop reads."""
+
+
+class PPOLearner:
+    """Policy/value replicas, optimizers and the PPO update (AgentPG.update_params + AgentPPO.update_policy).
+    Device-agnostic so the multi-rank path can be exercised with gloo on CPU."""
+
+    def __init__(self, cfg: Config, state_dim, action_dim, device, dtype=torch.float32, distributed=False,
+                 update_dtype="f32", strict_reference=True):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.distributed = distributed
+        self.world, self.rank = 1, 0
+        if distributed:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.update_dtype, self.strict_reference = update_dtype, strict_reference
+        self._policy_clip_used = False
+        self.policy_net = PolicyGaussian(cfg, action_dim, state_dim).to(self.device, dtype)
+        self.value_net = Value(MLP(state_dim, cfg.value_hsize, cfg.value_htype)).to(self.device, dtype)
+        if distributed:
+            import torch.distributed as dist
+            for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
+                dist.broadcast(p.data, 0)
+        self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay)
+        self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=cfg.value_lr, weight_decay=cfg.value_weightdecay)
+        self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
+        self.opt_num_epochs = cfg.num_optim_epoch
+        self.last_losses = None
+
+    # ------------------------------------------------------------------ update (agent_pg.py:39-55, agent_ppo.py:16-64)
+    def _allreduce_grads(self, params):
+        if not self.distributed:
+            return
+        import torch.distributed as dist
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat)
+        flat.div_(self.world)
+        for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(f)
+
+    def _autocast(self):
+        if self.update_dtype == "bf16" and self.device.type == "cuda":
+            return torch.autocast("cuda", dtype=torch.bfloat16)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def update_params(self, batch):
+        t0 = time.time()
+        self.policy_net.train(); self.value_net.train()
+        T, N = batch.rewards.shape
+        states = batch.states.reshape(T * N, -1)
+        actions = batch.actions.reshape(T * N, -1)
+        with torch.no_grad(), self._autocast():
+            values = self.value_net(states).float().reshape(T, N)
+        advantages, returns = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau,
+                                                  batch.next_values, dist_group=True if self.distributed else None)
+        advantages = advantages.reshape(T * N, 1); returns = returns.reshape(T * N, 1)
+        with torch.no_grad(), self._autocast():
+            fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
+        vparams = list(self.value_net.parameters())
+        pparams = [p for p in self.policy_net.parameters() if p.requires_grad]
+        for _ in range(self.opt_num_epochs):
+            with self._autocast():
+                value_loss = (self.value_net(states).float() - returns).pow(2).mean()      # agent_pg.py:18-25
+            self.optimizer_value.zero_grad(set_to_none=True)
+            value_loss.backward()
+            self._allreduce_grads(vparams)
+            self.optimizer_value.step()
+            with self._autocast():
+                surr = ppo_loss(self.policy_net, states, actions, advantages, fixed_log_probs, self.clip_epsilon)
+            self.optimizer_policy.zero_grad(set_to_none=True)
+            surr.backward()
+            self._allreduce_grads(pparams)
+            # policy_grad_clip=[(parameters() generator, 40)] clips only on the first optimizer step of the run
+            # (agent_handmimic.py:67); strict_reference=False clips every step
+            if not (self.strict_reference and self._policy_clip_used):
+                torch.nn.utils.clip_grad_norm_(pparams, 40)
+                self._policy_clip_used = True
+            self.optimizer_policy.step()
+        self.last_losses = (float(value_loss.detach()), float(surr.detach()))
+        return time.time() - t0
+
+
+class AgentHandMimic:
+    def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
+                 n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
+                 strict_reference=True, solver_iterations=8):
+        self.cfg = self.cc_cfg = cfg
+        self.dtype = dtype
+        self.training = training
+        self.distributed = distributed
+        self.world = 1
+        self.rank = 0
+        if distributed:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device or 0)
+        self.epoch = 0
+        # data + env (setup_data_loader / setup_env, :107-123)
+        if expert_seqs is None:
+            from . import mjcf
+            expert_seqs = motions.synthetic_expert(mjcf.load_packaged(model if isinstance(model, str) else "box"))
+        self.expert_seqs = expert_seqs
+        self.seq_num = len(expert_seqs)
+        self.env = BatchedHandObjMimic(cfg, expert_seqs, model, n_envs, "train", dev_index, solver_iterations)
+        self.device = self.env.device
+        self.n_envs = n_envs
+        self.state_dim, self.action_dim = self.env.observation_space.shape[0], self.env.action_space.shape[0]
+        # nets + optimizers (:125-169)
+        self.learner = PPOLearner(cfg, self.state_dim, self.action_dim, self.device, dtype, distributed, update_dtype,
+                                  strict_reference)
+        self.policy_net, self.value_net = self.learner.policy_net, self.learner.value_net
+        self.optimizer_policy, self.optimizer_value = self.learner.optimizer_policy, self.learner.optimizer_value
+        self.running_state = BatchZFilter(self.state_dim, clip=5.0, device=self.device)
+        self.gamma = cfg.gamma
+        self.end_reward = cfg.end_reward
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(cfg.seed) + 7919 * self.rank)
+        torch.manual_seed(int(cfg.seed) + 7919 * self.rank)
+        self._obs = None
+        lens = self.env.seq_len
+        self._max_start = torch.clamp(lens - 200, min=1)     # start_idx = randint(0, len - 200), :448
+        if checkpoint_epoch > 0:
+            self.load_checkpoint(checkpoint_epoch)
+            self.epoch = checkpoint_epoch
+
+    # ------------------------------------------------------------------ episode draws (:444-448)
+    def _draw_episodes(self, n):
+        hi = max(self.seq_num - 1, 1)                        # never the last (held-out) sequence
+        seq = torch.randint(0, hi, (n,), device=self.device, generator=self.gen, dtype=torch.int64)
+        u = torch.rand(n, device=self.device, generator=self.gen)
+        start = (u * self._max_start[seq].to(u.dtype)).to(torch.int32)
+        return seq.to(torch.int32), start
+
+    # ------------------------------------------------------------------ rollout (sample / sample_process, :430-535)
+    @torch.no_grad()
+    def sample(self, min_batch_size):
+        t0 = time.time()
+        self.env.set_mode("train")
+        self.policy_net.eval()
+        N = self.n_envs
+        T = int(math.ceil(min_batch_size / N))
+        dev, dt = self.device, self.dtype
+        states = torch.empty(T, N, self.state_dim, device=dev, dtype=dt)
+        actions = torch.empty(T, N, self.action_dim, device=dev, dtype=dt)
+        rewards = torch.empty(T, N, device=dev, dtype=dt)
+        masks = torch.empty(T, N, device=dev, dtype=dt)
+        c_info = torch.zeros(9, device=dev, dtype=torch.float64)
+        n_done = torch.zeros((), device=dev, dtype=torch.float64)
+        if self._obs is None:
+            seq, start = self._draw_episodes(N)
+            self._obs = self.env.reset(seq, start)
+        obs = self._obs
+        for t in range(T):
+            state = self.running_state(obs)
+            action = self.policy_net.select_action(state)
+            nseq, nstart = self._draw_episodes(N)
+            obs, _, done, info = self.env.step(action, nseq, nstart)
+            states[t] = state; actions[t] = action
+            rewards[t] = self.env.c_reward
+            masks[t] = (~done).to(dt)
+            c_info += self.env.c_info.sum(0, dtype=torch.float64)
+            n_done += done.sum()
+        self._obs = obs
+        next_state = self.running_state(obs, update=False)
+        next_values = self.value_net(next_state).squeeze(1)
+        batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
+                                exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values)
+        steps = T * N
+        # the end reward is part of `rewards`; c_reward statistics are reported without it, like the reference
+        end_bonus = self.env.end_reward if self.end_reward else 0.0
+        cr = rewards.to(torch.float64)
+        stats = torch.stack([cr.sum(), cr.min(), cr.max(), n_done])
+        if self.distributed:
+            import torch.distributed as dist
+            tot = torch.cat([stats[[0, 3]], c_info]); dist.all_reduce(tot)
+            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:]
+            steps *= self.world
+        s = stats.cpu().numpy(); ci = c_info.cpu().numpy()
+        episodes = max(s[3], 1.0)
+        log = LoggerRL(num_steps=steps, num_episodes=int(s[3]), avg_episode_len=steps / episodes,
+                       total_c_reward=s[0], avg_c_reward=s[0] / steps, min_c_reward=s[1], max_c_reward=s[2],
+                       avg_c_info=ci / steps, avg_episode_c_reward=s[0] / episodes, sample_time=time.time() - t0,
+                       end_bonus=end_bonus)
+        return batch, log
+
+    def update_params(self, batch):
+        return self.learner.update_params(batch)
+
+    # ------------------------------------------------------------------ schedule (:264-282, :311-336)
+    def per_epoch_update(self, epoch):
+        cfg = self.cfg
+        cfg.update_adaptive_params(epoch)
+        for g in self.optimizer_policy.param_groups:
+            g["lr"] = float(cfg.adp_policy_lr)
+        if cfg.fix_std:
+            self.policy_net.action_log_std.data.fill_(float(cfg.adp_log_std))
+        self.env.update_reward_params()
+
+    def optimize_policy(self, epoch, save_model=True):
+        self.epoch = epoch
+        t0 = time.time()
+        self.per_epoch_update(epoch)
+        batch, log = self.sample(self.cfg.min_batch_size)
+        if self.cfg.end_reward:
+            self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
+        t1 = time.time()
+        self.update_params(batch)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t2 = time.time()
+        info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
+        if save_model and (epoch + 1) % self.cfg.save_n_epochs == 0 and self.rank == 0:
+            self.save_checkpoint(epoch)
+            info["log_eval"] = self.eval_policy(epoch)
+        return info
+
+    # ------------------------------------------------------------------ deterministic evaluation (:339-403)
+    @torch.no_grad()
+    def eval_policy(self, epoch=0, max_steps=10000):
+        env = self.env
+        env.set_mode("test")
+        N = self.n_envs
+        seq = torch.full((N,), self.seq_num - 1, dtype=torch.int32)
+        obs = env.reset(seq, torch.zeros(N, dtype=torch.int32))
+        res = {k: [] for k in ("reward", "info", "pred", "gt")}
+        ex = self.expert_seqs[self.seq_num - 1]
+        percent = 0.0
+        for t in range(max_steps):
+            res["gt"].append(ex["hand_dof_seq"][min(t, ex["hand_dof_seq"].shape[0] - 1)])
+            res["pred"].append(env.get_hand_qpos()[0].double().cpu().numpy())
+            state = self.running_state(obs, update=False)
+            action = self.policy_net.select_action(state, mean_action=True)
+            obs, _, done, info = env.step(action)
+            res["reward"].append(float(env.c_reward[0])); res["info"].append(env.c_info[0].double().cpu().numpy())
+            percent = float(info["percent"][0])
+            if bool(done[0]):
+                break
+        env.set_mode("train")
+        self._obs = None
+        info_m = np.array(res["info"]).mean(0)
+        gt, pred = np.array(res["gt"]), np.array(res["pred"])
+        names = ("pose_reward", "wpose_reward", "jpos_reward", "vel_reward", "obj_pos_reward", "obj_rot_reward",
+                 "obj_vel_reward", "obj_rfc_reward")
+        m = {"pose_err": float(np.linalg.norm(gt[6:] - pred[6:], axis=-1).mean()) if len(gt) > 6 else 0.0,
+             "avg_reward": float(np.mean(res["reward"])), "total_reward": float(np.sum(res["reward"])), "percent": percent}
+        m.update({n: float(info_m[i]) for i, n in enumerate(names)})
+        return m
+
+    # ------------------------------------------------------------------ checkpoints (:175-186, :234-245)
+    def save_checkpoint(self, epoch):
+        os.makedirs(self.cfg.model_dir, exist_ok=True)
+        cp = {"policy_dict": {k: v.detach().cpu() for k, v in self.policy_net.state_dict().items()},
+              "value_dict": {k: v.detach().cpu() for k, v in self.value_net.state_dict().items()},
+              "running_state": self.running_state.to_reference()}
+        path = "%s/iter_%04d.p" % (self.cfg.model_dir, epoch + 1)
+        with open(path, "wb") as f:
+            pickle.dump(cp, f)
+        return path
+
+    def load_checkpoint(self, it, path=None):
+        path = path or "%s/iter_%04d.p" % (self.cfg.model_dir, it)
+        with open(path, "rb") as f:
+            cp = RefUnpickler(f).load()
+        self.policy_net.load_state_dict({k: v.to(self.dtype) for k, v in cp["policy_dict"].items()})
+        self.value_net.load_state_dict({k: v.to(self.dtype) for k, v in cp["value_dict"].items()})
+        self.running_state = BatchZFilter.from_reference(cp["running_state"], device=self.device)

@@ -1,0 +1,212 @@
+"""Batched mirror of the reference environment surface.
+
+``BatchedHandObjMimic`` exposes what ``AgentHandMimic`` and ``ho_mimic_reward_9`` touch on ``HandObjMimic4``
+(uhc/envs/ho_im4.py:45-1102): ``reset/step/get_obs/set_expert/set_mode/seed``, the spaces, and
+the getters the reward reaches into — for ``n_envs`` environments living on one GPU, with tensors instead of
+per-env NumPy arrays.  ``HandObjMimic4`` is the single-env NumPy adapter with the reference's own signature
+(``step(a[32]) -> (obs[617], 1.0, done, {"fail","end","percent"})``).  All numerics happen in
+``libhoic_hip.so`` through ``hoic_amd.lib``; there is no CPU path here.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import lib, mjcf
+from .config import Config
+
+
+class _Space:
+    def __init__(self, dim):
+        self.shape = (dim,)
+        self.low = -np.ones(dim); self.high = np.ones(dim)
+
+
+class BatchedHandObjMimic:
+    def __init__(self, cfg: Config, expert_seqs, model: mjcf.CompiledModel | bytes | str = "box", n_envs: int = 1,
+                 mode: str = "train", device_index: int = 0, solver_iterations: int = 8):
+        import torch
+        self.torch = torch
+        self.cc_cfg = cfg
+        if isinstance(model, str):
+            blob = open(mjcf.packaged_model_path(model), "rb").read()
+        elif isinstance(model, mjcf.CompiledModel):
+            blob = model.to_blob()
+        else:
+            blob = bytes(model)
+        self.model_blob = blob
+        self.model = mjcf.CompiledModel.from_blob(blob)
+        self.model.actuator_names = self.model.actuator_names
+        self.n_envs = int(n_envs)
+        self.sim = lib.BatchedSim(blob, self.n_envs, device_index)
+        self.device = self.sim.device
+        self.sim.set_config(cfg.jkp, cfg.jkd, cfg.torque_lim,
+                            (cfg.pos_diff_thresh, cfg.rot_diff_thresh, cfg.jpos_diff_thresh, cfg.obj_pos_diff_thresh,
+                             cfg.obj_rot_diff_thresh), cfg.residual_force_scale, cfg.residual_torque_scale,
+                            sim_step=cfg.sim_step, residual_force=cfg.residual_force, explain_force=cfg.explain_force,
+                            surface_contact=cfg.surface_contact, pd_rel=(cfg.pd_type != "base"),
+                            solver_iterations=solver_iterations)
+        self.sim_step = self.frame_skip = cfg.sim_step
+        self.w_size = cfg.future_w_size
+        self.qpos_dim, self.qvel_dim = self.model.scalar("nq"), self.model.scalar("nv")
+        self.hand_qpos_dim, self.hand_qvel_dim = self.model.scalar("hand_nq"), self.model.scalar("hand_nv")
+        self.ndof = self.model.scalar("nu")
+        self.vf_dim = 6 if cfg.residual_force else 0
+        self.action_dim = self.ndof + self.vf_dim
+        self.obs_dim = lib.OBS_DIM
+        self.observation_space = _Space(self.obs_dim)
+        self.action_space = _Space(lib.ACT_DIM)
+        self.end_reward = 0.0
+        self.use_end_reward = bool(cfg.end_reward)
+        self.rfc_rate = 1.0
+        self.mode = mode
+        self.np_random = np.random.RandomState(0)
+        self.expert_seqs = None
+        self.set_expert(expert_seqs)
+        self.set_mode(mode)
+        self.update_reward_params()
+        self._last = None
+
+    # ---- reference surface
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def set_mode(self, mode):
+        self.mode = mode
+        self.sim.set_mode(mode == "train")
+
+    def set_expert(self, expert_seqs):
+        """All sequences at once (the reference swaps one sliced sequence per episode, ho_im4.py:135)."""
+        if isinstance(expert_seqs, dict):
+            expert_seqs = [expert_seqs]
+        self.expert_seqs = expert_seqs
+        self.sim.set_expert(expert_seqs)
+        self.seq_len = self.torch.as_tensor(self.sim.seq_len, device=self.device)
+
+    def update_reward_params(self):
+        """Push reward weights / end_reward (refreshed every epoch, agent_handmimic.py:264-282, 318-319)."""
+        self.sim.set_reward_params(self.cc_cfg.reward_wk(), self.end_reward, self.use_end_reward)
+
+    def reset(self, seq_idx=None, start_idx=None, env_ids=None):
+        t = self.torch
+        n = self.n_envs if env_ids is None else len(env_ids)
+        if seq_idx is None:
+            seq_idx = t.zeros(n, dtype=t.int32)
+        if start_idx is None:
+            start_idx = t.zeros(n, dtype=t.int32)
+        return self.sim.reset(seq_idx, start_idx, env_ids)
+
+    def step(self, actions, next_seq=None, next_start=None):
+        """-> (obs [n,617], env_reward (1.0), done [n] bool, info dict of tensors). The custom reward
+        (ho_mimic_reward_9, fused in the kernel) is available as ``self.c_reward`` / ``self.c_info``."""
+        obs, rew, rinfo, flags, pct = self.sim.step(actions, next_seq, next_start)
+        self.c_reward, self.c_info = rew, rinfo
+        info = {"fail": flags[:, 0] != 0, "end": flags[:, 1] != 0, "percent": pct, "solver_iter": flags[:, 3]}
+        return obs, 1.0, flags[:, 2] != 0, info
+
+    def get_obs(self):
+        return self.sim.obs
+
+    # ---- getters used by the reward / evaluation code of the reference
+    def _state(self):
+        return self.sim.get_state()
+
+    @property
+    def cur_t(self):
+        return self._state()[2]
+
+    def get_hand_qpos(self):
+        return self._state()[0][:, :self.hand_qpos_dim]
+
+    def get_hand_qvel(self):
+        return self._state()[1][:, :self.hand_qvel_dim]
+
+    def get_obj_qpos(self):
+        return self._state()[0][:, self.hand_qpos_dim:]
+
+    def get_obj_qvel(self):
+        return self._state()[1][:, self.hand_qvel_dim:]
+
+    @property
+    def rfc_score(self):
+        return self.sim.rfc_score()
+
+    def close(self):
+        self.sim.close()
+
+
+class HandObjMimic4:
+    """Single-environment adapter with the reference signature (uhc/envs/ho_im4.py:46)."""
+
+    def __init__(self, cfg, expert_seq, model_xml="box", data_specs=None, mode="train", device_index=0):
+        self._b = BatchedHandObjMimic(cfg, [expert_seq], model_xml, 1, mode, device_index)
+        self.cc_cfg = cfg
+        self.observation_space, self.action_space = self._b.observation_space, self._b.action_space
+        self.model = self._b.model
+        self.expert = expert_seq
+        self.expert_len = expert_seq["hand_dof_seq"].shape[0]
+        self.start_ind = 0
+        self.data = SimpleNamespace()
+        self.end_reward = 0.0
+        for k in ("hand_qpos_dim", "hand_qvel_dim", "ndof", "vf_dim", "qpos_dim", "qvel_dim", "w_size", "frame_skip"):
+            setattr(self, k, getattr(self._b, k))
+        self.np_random = self._b.np_random
+        self.reset()
+
+    def seed(self, s=None):
+        return self._b.seed(s)
+
+    def set_mode(self, mode):
+        self._b.set_mode(mode)
+
+    def set_expert(self, expert_seq):
+        self.expert = expert_seq
+        self.expert_len = expert_seq["hand_dof_seq"].shape[0]
+        self._b.set_expert([expert_seq])
+
+    def get_expert_attr(self, attr, ind):
+        return self.expert[attr][min(ind, self.expert_len - 1)].copy()
+
+    def _sync_data(self):
+        qpos, qvel, cur_t = self._b.sim.get_state()
+        self.data.qpos = qpos[0].double().cpu().numpy()
+        self.data.qvel = qvel[0].double().cpu().numpy()
+        self.cur_t = int(cur_t[0])
+
+    def reset(self):
+        obs = self._b.reset()
+        self._sync_data()
+        return obs[0].double().cpu().numpy()
+
+    def get_obs(self):
+        return self._b.get_obs()[0].double().cpu().numpy()
+
+    def step(self, a):
+        t = self._b.torch
+        self._b.end_reward = self.end_reward
+        obs, r, done, info = self._b.step(t.as_tensor(np.asarray(a, dtype=np.float32)[None], device=self._b.device))
+        self._sync_data()
+        self.rfc_score = float(self._b.rfc_score[0])
+        self.c_reward = float(self._b.c_reward[0])
+        self.c_info = np.append(self._b.c_info[0].double().cpu().numpy(), [])
+        return (obs[0].double().cpu().numpy(), r, bool(done[0]),
+                {"fail": bool(info["fail"][0]), "end": bool(info["end"][0]), "percent": float(info["percent"][0])})
+
+    def get_hand_qpos(self):
+        return self.data.qpos[:self.hand_qpos_dim].copy()
+
+    def get_hand_qvel(self):
+        return self.data.qvel[:self.hand_qvel_dim].copy()
+
+    def get_obj_qpos(self):
+        return self.data.qpos[self.hand_qpos_dim:].copy()
+
+    def get_obj_qvel(self):
+        return self.data.qvel[self.hand_qvel_dim:].copy()
+
+
+def ho_mimic_reward_9(env, state, action, info):
+    """Reference call shape (uhc/envs/ho_reward.py:943): the value was computed inside the fused step."""
+    return env.c_reward, env.c_info

@@ -1,0 +1,213 @@
+"""RL building blocks of the PPO update, device-resident.
+
+Mirrors (names, shapes, init and state-dict keys interchangeable with the reference's checkpoints):
+``MLP`` (uhc/khrylib/models/mlp.py:5-27), ``PolicyGaussian`` (uhc/khrylib/rl/core/policy_gaussian.py:9-33) with
+``DiagGaussian`` log-prob summed over action dims (distributions.py:21-22), ``Value`` (critic.py:5-18),
+``estimate_advantages`` (core/common.py:5-25), ``ZFilter``/``RunningStat`` (uhc/khrylib/utils/zfilter.py:7-73)
+and the PPO-clip loss (uhc/khrylib/rl/agents/agent_ppo.py:58-64).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dims=(128, 128), activation="tanh"):
+        super().__init__()
+        self.activation = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid,
+                           "gelu": nn.GELU()}[activation]
+        self.out_dim = hidden_dims[-1]
+        self.affine_layers = nn.ModuleList()
+        last = input_dim
+        for nh in hidden_dims:
+            self.affine_layers.append(nn.Linear(last, nh))
+            last = nh
+
+    def forward(self, x):
+        for affine in self.affine_layers:
+            x = self.activation(affine(x))
+        return x
+
+
+class PolicyGaussian(nn.Module):
+    def __init__(self, cfg, action_dim, state_dim):
+        super().__init__()
+        self.type = "gaussian"
+        self.net = MLP(state_dim, cfg.policy_hsize, cfg.policy_htype)
+        self.action_mean = nn.Linear(self.net.out_dim, action_dim)
+        self.action_mean.weight.data.mul_(0.1)
+        self.action_mean.bias.data.mul_(0.0)
+        self.action_log_std = nn.Parameter(torch.ones(1, action_dim) * cfg.log_std, requires_grad=not cfg.fix_std)
+
+    def forward(self, x):
+        mean = self.action_mean(self.net(x))
+        return mean, self.action_log_std.expand_as(mean)
+
+    def select_action(self, x, mean_action=False):
+        mean, log_std = self.forward(x)
+        return mean if mean_action else mean + torch.exp(log_std) * torch.randn_like(mean)
+
+    def get_log_prob(self, x, action):
+        mean, log_std = self.forward(x)
+        var = torch.exp(2 * log_std)
+        lp = -((action - mean) ** 2) / (2 * var) - log_std - 0.5 * math.log(2 * math.pi)
+        return lp.sum(1, keepdim=True)
+
+
+class Value(nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.value_head = nn.Linear(net.out_dim, 1)
+        self.value_head.weight.data.mul_(0.1)
+        self.value_head.bias.data.mul_(0.0)
+
+    def forward(self, x):
+        return self.value_head(self.net(x))
+
+
+# ----------------------------------------------------------------------------- advantages
+def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, dist_group=None):
+    """GAE(lambda) over time-major rollouts: rewards/masks/values are [T, N] (N parallel envs).
+
+    Per env this is exactly the reference recursion (core/common.py:12-19): delta_t = r_t + gamma V_{t+1} m_t - V_t,
+    A_t = delta_t + gamma tau A_{t+1} m_t with m_t = 0 at episode ends.  ``next_values`` [N] bootstraps the value after
+    the last collected step (the reference only ever sees complete episodes, so it has nothing to bootstrap;
+    pass None for that behaviour).  Returns (normalised advantages, returns), normalised with the UNBIASED std
+    over the whole batch (:22) — across all ranks if ``dist_group`` is given.
+    """
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    prev_v = torch.zeros_like(rewards[0]) if next_values is None else next_values
+    prev_a = torch.zeros_like(rewards[0])
+    for t in range(T - 1, -1, -1):
+        delta = rewards[t] + gamma * prev_v * masks[t] - values[t]
+        prev_a = delta + gamma * tau * prev_a * masks[t]
+        adv[t] = prev_a
+        prev_v = values[t]
+    returns = values + adv
+    s = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)])
+    if dist_group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(s, group=dist_group if dist_group is not True else None)
+    n = s[2]
+    mean = s[0] / n
+    var = (s[1] - n * mean * mean) / (n - 1)
+    return (adv - mean) / torch.sqrt(var), returns
+
+
+def ppo_loss(policy, states, actions, advantages, fixed_log_probs, clip_epsilon):
+    """agent_ppo.py:58-64 (exps is all-ones in the release configs, so `ind` selects everything)."""
+    log_probs = policy.get_log_prob(states, actions)
+    ratio = torch.exp(log_probs - fixed_log_probs)
+    surr1 = ratio * advantages
+    surr2 = torch.clamp(ratio, 1.0 - clip_epsilon, 1.0 + clip_epsilon) * advantages
+    return -torch.min(surr1, surr2).mean()
+
+
+# ----------------------------------------------------------------------------- observation filter
+class RunningStat:
+    """Same attributes as the reference class so pickled checkpoints interchange (zfilter.py:7-49)."""
+
+    def __init__(self, shape):
+        self._n = 0
+        self._M = np.zeros(shape)
+        self._S = np.zeros(shape)
+
+    def push(self, x):
+        x = np.asarray(x)
+        assert x.shape == self._M.shape
+        self._n += 1
+        if self._n == 1:
+            self._M[...] = x
+        else:
+            oldM = self._M.copy()
+            self._M[...] = oldM + (x - oldM) / self._n
+            self._S[...] = self._S + (x - oldM) * (x - self._M)
+
+    n = property(lambda self: self._n)
+    mean = property(lambda self: self._M)
+    var = property(lambda self: self._S / (self._n - 1) if self._n > 1 else np.square(self._M))
+    std = property(lambda self: np.sqrt(self.var))
+    shape = property(lambda self: self._M.shape)
+
+
+class ZFilter:
+    """y = clip((x - mean) / (std + 1e-8)) with running estimates (zfilter.py:52-73), NumPy, one sample at a time."""
+
+    def __init__(self, shape, demean=True, destd=True, clip=10.0):
+        self.demean, self.destd, self.clip = demean, destd, clip
+        self.rs = RunningStat(shape)
+
+    def __call__(self, x, update=True):
+        if update:
+            self.rs.push(x)
+        if self.demean:
+            x = x - self.rs.mean
+        if self.destd:
+            x = x / (self.rs.std + 1e-8)
+        if self.clip:
+            x = np.clip(x, -self.clip, self.clip)
+        return x
+
+
+class BatchZFilter:
+    """Device-resident ZFilter for [N, D] batches.
+
+    Pushing a batch merges its moments into the running ones with the pairwise (Chan) update, which gives the
+    same mean / S as pushing the N rows one at a time; every row of the batch is then normalised with the
+    statistics AFTER the whole batch (the reference normalises row i with the statistics after row i).
+    Statistics are kept in float64.  ``to_reference()`` / ``from_reference()`` convert to the pickled ZFilter.
+    """
+
+    def __init__(self, dim, clip=5.0, device="cpu"):
+        self.clip = clip
+        self.n = torch.zeros((), dtype=torch.float64, device=device)
+        self.mean = torch.zeros(dim, dtype=torch.float64, device=device)
+        self.S = torch.zeros(dim, dtype=torch.float64, device=device)
+
+    def push(self, x):
+        x = x.to(torch.float64)
+        nb = float(x.shape[0])
+        mb = x.mean(0)
+        Sb = ((x - mb) ** 2).sum(0)
+        tot = self.n + nb
+        delta = mb - self.mean
+        self.S = self.S + Sb + delta * delta * self.n * nb / tot
+        self.mean = self.mean + delta * nb / tot
+        self.n = tot
+
+    def __call__(self, x, update=True):
+        if update:
+            self.push(x)
+        # var = S/(n-1), and mean^2 when n == 1 (zfilter.py:35)
+        var = torch.where(self.n > 1, self.S / torch.clamp(self.n - 1, min=1.0), self.mean * self.mean)
+        y = (x.to(torch.float64) - self.mean) / (torch.sqrt(var) + 1e-8)
+        return torch.clamp(y, -self.clip, self.clip).to(x.dtype)
+
+    def sync(self, group=None):
+        """All-reduce the moments over ranks (replicas then share one filter; the reference keeps worker 0's)."""
+        import torch.distributed as dist
+        n, mean, S = self.n.clone(), self.mean.clone(), self.S.clone()
+        tot = n.clone(); dist.all_reduce(tot, group=group)
+        wmean = mean * n; dist.all_reduce(wmean, group=group)
+        gmean = wmean / tot
+        gS = S + n * (mean - gmean) ** 2; dist.all_reduce(gS, group=group)
+        self.n, self.mean, self.S = tot, gmean, gS
+
+    def to_reference(self):
+        z = ZFilter(tuple(self.mean.shape), clip=self.clip)
+        z.rs._n = int(self.n.item()); z.rs._M[...] = self.mean.cpu().numpy(); z.rs._S[...] = self.S.cpu().numpy()
+        return z
+
+    @classmethod
+    def from_reference(cls, z, device="cpu"):
+        f = cls(z.rs._M.shape[0], clip=z.clip, device=device)
+        f.n = torch.tensor(float(z.rs._n), dtype=torch.float64, device=device)
+        f.mean = torch.as_tensor(z.rs._M, dtype=torch.float64, device=device).clone()
+        f.S = torch.as_tensor(z.rs._S, dtype=torch.float64, device=device).clone()
+        return f

@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: two gloo ranks, each with half of a batch, must produce the same parameters as one
+process holding the whole batch (gradient all-reduce, global advantage normalisation, ZFilter moment sync)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make_batch(seed, T, N, sd, ad):
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(seed)
+    d = torch.float64
+    return SimpleNamespace(states=torch.randn(T, N, sd, generator=g, dtype=d), actions=torch.randn(T, N, ad, generator=g, dtype=d) * 0.2,
+                           rewards=torch.rand(T, N, generator=g, dtype=d), masks=(torch.rand(T, N, generator=g) > 0.1).to(d),
+                           exps=torch.ones(T, N, dtype=d), next_values=torch.randn(N, generator=g, dtype=d))
+
+
+def _cfg():
+    from hoic_amd.config import Config, release_cfg_dict
+    d = release_cfg_dict("box"); d["policy_hsize"] = [64, 32]; d["value_hsize"] = [64, 32]; d["num_optim_epoch"] = 2
+    return Config("box_future5_light_add_geom", cfg_dict=d)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hoic_amd.agent import PPOLearner
+    from hoic_amd.rl import BatchZFilter
+    torch.manual_seed(0)
+    learner = PPOLearner(_cfg(), 24, 6, "cpu", torch.float64, distributed=True)
+    full = _make_batch(1, 6, 8, 24, 6)
+    sl = slice(rank * 4, (rank + 1) * 4)
+    from types import SimpleNamespace
+    part = SimpleNamespace(**{k: (v[:, sl] if v.dim() >= 2 else v[sl]) for k, v in vars(full).items()})
+    learner.update_params(part)
+    zf = BatchZFilter(24); zf.push(full.states[:, sl].reshape(-1, 24)); zf.sync()
+    if rank == 0:
+        q.put(({k: v.numpy() for k, v in learner.policy_net.state_dict().items()},
+               {k: v.numpy() for k, v in learner.value_net.state_dict().items()}, zf.mean.numpy(), zf.S.numpy(), float(zf.n)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    pol2, val2, zmean, zS, zn = q.get(timeout=90)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from hoic_amd.agent import PPOLearner
+    from hoic_amd.rl import BatchZFilter
+    torch.manual_seed(0)
+    single = PPOLearner(_cfg(), 24, 6, "cpu", torch.float64, distributed=False)
+    full = _make_batch(1, 6, 8, 24, 6)
+    single.update_params(full)
+    for k, v in single.policy_net.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), pol2[k], atol=1e-12, err_msg=k)
+    for k, v in single.value_net.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), val2[k], atol=1e-12, err_msg=k)
+    zf = BatchZFilter(24); zf.push(full.states.reshape(-1, 24))
+    np.testing.assert_allclose(zf.mean.numpy(), zmean, atol=1e-12)
+    np.testing.assert_allclose(zf.S.numpy(), zS, atol=1e-10)
+    assert zn == float(zf.n)

@@ -1,0 +1,173 @@
+"""Host-side logic (CPU): config, motions, RL building blocks against the reference-generated goldens, the
+model blob round trip, and that the C-ABI library exports every symbol include/hoic.h declares."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+from hoic_amd import lib, mjcf, motions
+from hoic_amd.config import Config, release_cfg_dict
+from hoic_amd.rl import MLP, BatchZFilter, PolicyGaussian, Value, ZFilter, estimate_advantages, ppo_loss
+
+
+def test_config_matches_reference(cfg_golden):
+    cfg = Config("box_future5_light_add_geom")
+    np.testing.assert_allclose(cfg.jkp, cfg_golden["jkp"]); np.testing.assert_allclose(cfg.jkd, cfg_golden["jkd"])
+    np.testing.assert_allclose(cfg.torque_lim, cfg_golden["torque_lim"])
+    assert (cfg.gamma, cfg.tau) == (float(cfg_golden["gamma"]), float(cfg_golden["tau"]))
+    for ep in (0, 1, 100, 1500, 3000, 5000):          # update_adaptive_params, handmimic_config.py:157-195
+        cfg.update_adaptive_params(ep)
+        ref = cfg_golden[f"sched_{ep}"]
+        np.testing.assert_allclose(cfg.reward_wk(), ref[:16], rtol=1e-14)
+        np.testing.assert_allclose([cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr], ref[16:], rtol=1e-14)
+    assert cfg.surface_contact and cfg.explain_force
+    assert Config("bottle_future5_light_add_geom").explain_force       # default True although the yml omits it
+    with pytest.raises(NotImplementedError):
+        d = release_cfg_dict("box"); d["obs_type"] = 3; Config("x", cfg_dict=d)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/config"), reason="reference checkout not present")
+def test_config_parses_reference_yaml(cfg_golden):
+    cfg = Config("box_future5_light_add_geom", base_dir="/root/reference")
+    ours = Config("box_future5_light_add_geom")
+    for k in ("gamma", "tau", "policy_hsize", "policy_lr", "value_lr", "clip_epsilon", "min_batch_size", "num_optim_epoch",
+              "log_std", "fix_std", "sim_step", "residual_force_scale", "residual_torque_scale", "pd_type"):
+        assert getattr(cfg, k) == getattr(ours, k), k
+    assert cfg.reward_weights == ours.reward_weights
+
+
+def test_blob_roundtrip_and_compile(box_model, box_blob):
+    assert mjcf.CompiledModel.from_blob(box_model.to_blob()).to_blob() == box_model.to_blob()
+    if os.path.exists("/root/reference/assets"):
+        fresh = mjcf.compile_reference_config("/root/reference", "box")
+        for k, v in fresh.arrays.items():
+            np.testing.assert_allclose(v, box_model.arrays[k], atol=1e-15, err_msg=k)
+
+
+def test_motions_against_reference(box_model):
+    z = golden("dataset_vel.npz")
+    hv, ov, oav = motions.compute_vel_from_seq(z["hand_dof"], z["obj_pose"])      # dataset_singledepth.py:152-185
+    np.testing.assert_allclose(hv, z["hand_vel"], atol=1e-13)
+    np.testing.assert_allclose(ov, z["obj_vel"], atol=1e-13)
+    np.testing.assert_allclose(oav, z["obj_angvel"], atol=1e-12)
+    ex = motions.synthetic_expert(box_model, 2, 260)
+    assert ex[0]["body_pos_seq"].shape == (260, 21, 3) and ex[0]["body_quat_seq"].shape == (260, 21, 4)
+    A = box_model.arrays
+    assert np.all(ex[0]["hand_dof_seq"] >= A["jnt_range"][:26, 0] - 1e-12) and np.all(ex[0]["hand_dof_seq"] <= A["jnt_range"][:26, 1] + 1e-12)
+    np.testing.assert_allclose(np.linalg.norm(ex[0]["obj_pose_seq"][:, 3:], axis=1), 1, atol=1e-12)
+    # palm body position equals the slide DoFs (FK)
+    np.testing.assert_allclose(ex[1]["body_pos_seq"][:, 0], ex[1]["hand_dof_seq"][:, :3], atol=1e-12)
+
+
+def test_gae_matches_reference():
+    z = golden("gae.npz")
+    r = torch.tensor(z["rewards"])[:, None]; m = torch.tensor(z["masks"])[:, None]; v = torch.tensor(z["values"])
+    adv, ret = estimate_advantages(r, m, v, float(z["gamma"]), float(z["tau"]))      # one env: [T, 1]
+    np.testing.assert_allclose(adv.numpy(), z["advantages"], atol=1e-12)
+    np.testing.assert_allclose(ret.numpy(), z["returns"], atol=1e-12)
+
+
+def test_gae_time_major_equals_concatenated():
+    """[T, N] scan == the reference's concatenated-episode loop when every column ends with mask 0."""
+    rng = np.random.default_rng(0)
+    T, N = 17, 5
+    r = torch.tensor(rng.uniform(size=(T, N))); v = torch.tensor(rng.normal(size=(T, N)))
+    m = torch.tensor((rng.uniform(size=(T, N)) > 0.2).astype(float)); m[-1] = 0
+    adv, ret = estimate_advantages(r, m, v, 0.95, 0.95)
+    rc, mc, vc = r.T.reshape(-1, 1), m.T.reshape(-1, 1), v.T.reshape(-1, 1)
+    adv2, ret2 = estimate_advantages(rc, mc, vc, 0.95, 0.95)
+    np.testing.assert_allclose(adv.T.reshape(-1, 1).numpy(), adv2.numpy(), atol=1e-12)
+    np.testing.assert_allclose(ret.T.reshape(-1, 1).numpy(), ret2.numpy(), atol=1e-12)
+
+
+def test_ppo_update_matches_reference():
+    """Two full-batch PPO epochs (value step then clipped policy step, Adam) reproduce the reference's parameters."""
+    z = golden("ppo.npz")
+    torch.set_default_dtype(torch.float64)
+    try:
+        cfg = types.SimpleNamespace(policy_hsize=[64, 32], policy_htype="gelu", fix_std=True, log_std=-2.3)
+        pol = PolicyGaussian(cfg, 6, 24); val = Value(MLP(24, [64, 32], "gelu"))
+        pol.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("p0_")})
+        val.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("v0_")})
+        st, ac = torch.tensor(z["states"]), torch.tensor(z["actions"])
+        adv, ret = torch.tensor(z["advantages"]), torch.tensor(z["returns"])
+        with torch.no_grad():
+            flp = pol.get_log_prob(st, ac)
+        np.testing.assert_allclose(flp.numpy(), z["fixed_log_probs"], atol=1e-12)
+        assert abs(ppo_loss(pol, st, ac, adv, flp, 0.2).item() - float(z["ppo_loss0"])) < 1e-13
+        op = torch.optim.Adam(pol.parameters(), lr=5e-5); ov = torch.optim.Adam(val.parameters(), lr=3e-4)
+        for ep in range(2):
+            vl = (val(st) - ret).pow(2).mean(); ov.zero_grad(); vl.backward(); ov.step()
+            if ep == 0:
+                assert abs(vl.item() - float(z["value_loss0"])) < 1e-13
+            sl = ppo_loss(pol, st, ac, adv, flp, 0.2); op.zero_grad(); sl.backward()
+            if ep == 0:
+                torch.nn.utils.clip_grad_norm_([p for p in pol.parameters() if p.requires_grad], 40)  # generator quirk
+            op.step()
+        for k in z.files:
+            if k.startswith("p1_"):
+                np.testing.assert_allclose(pol.state_dict()[k[3:]].numpy(), z[k], atol=1e-12, err_msg=k)
+            if k.startswith("v1_"):
+                np.testing.assert_allclose(val.state_dict()[k[3:]].numpy(), z[k], atol=1e-12, err_msg=k)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_zfilter():
+    z = golden("zfilter.npz")
+    f = ZFilter((9,), clip=5)
+    ys = np.stack([f(x) for x in z["xs"]])
+    np.testing.assert_allclose(ys, z["ys"], atol=1e-13)
+    np.testing.assert_allclose(f(z["xs"][0], update=False), z["y_noupdate"], atol=1e-13)
+    # batched filter: same moments as pushing the rows one by one
+    b = BatchZFilter(9, clip=5)
+    b.push(torch.tensor(z["xs"][:7])); b.push(torch.tensor(z["xs"][7:]))
+    np.testing.assert_allclose(b.mean.numpy(), z["mean"], atol=1e-13)
+    np.testing.assert_allclose((b.S / (b.n - 1)).numpy(), z["var"], atol=1e-12)
+    ref = b.to_reference()
+    np.testing.assert_allclose(ref(z["xs"][3], update=False), b(torch.tensor(z["xs"][3:4]), update=False)[0].numpy(), atol=1e-13)
+    b1 = BatchZFilter(9, clip=5); b1.push(torch.tensor(z["xs"][:1]))
+    np.testing.assert_allclose(b1(torch.tensor(z["xs"][:1]), update=False).numpy(), 0 * z["xs"][:1], atol=1e-7)  # n == 1: var = mean^2
+
+
+def test_math_known_answers():
+    z = golden("math.npz")      # doctest values of uhc/utils/transformation.py
+    np.testing.assert_allclose(motions.qmul(np.array([4., 1, -2, 3]), np.array([8., -5, 6, 7])), z["qmul"])
+    np.testing.assert_allclose(z["qmul"], [28, -44, -14, 48])
+    q = np.array([0.99810947, 0.06146124, 0, 0])
+    np.testing.assert_allclose(motions.qmat(q / np.linalg.norm(q)), z["qmat"][:3, :3], atol=1e-9)
+
+
+def test_capi_exports_every_declared_symbol():
+    """libhoic_hip.so loads on a CPU-only box and exports exactly the functions include/hoic.h declares."""
+    lib.build()
+    hdr = open(os.path.join(ROOT, "include", "hoic.h")).read()
+    declared = set(re.findall(r"\b(hoic_[a-z_]+)\s*\(", hdr))
+    assert declared == set(lib.EXPORTS)
+    L = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    # no compute without a GPU: creation must fail loudly, not fall back
+    L.hoic_create.restype = ctypes.c_void_p
+    L.hoic_last_error.restype = ctypes.c_char_p
+    if not torch.cuda.is_available():
+        blob = open(mjcf.packaged_model_path("box"), "rb").read()
+        assert not L.hoic_create(blob, ctypes.c_size_t(len(blob)), 4, 0)
+        assert b"no HIP device" in L.hoic_last_error()
+        with pytest.raises(lib.HoicError):
+            lib.BatchedSim(blob, 4)
+
+
+def test_product_never_imports_oracle():
+    """The shipped path may not import, include, link or load anything under oracle/."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|#include\s*[<\"][^>\"]*oracle|libhoic_oracle|hoo\.", re.M)
+    for root, _, files in os.walk(os.path.join(ROOT, "hoic_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                src = open(os.path.join(root, f)).read()
+                assert not pat.search(src), f

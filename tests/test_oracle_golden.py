@@ -1,0 +1,94 @@
+"""The CPU oracle's environment glue against golden vectors captured from the reference's own Python
+(tests/golden/gen_golden.py).  float64 on both sides -> tight tolerances."""
+import numpy as np
+import pytest
+
+from conftest import cases, golden
+
+
+def _env(hoo, blob, c, cfgz):
+    e = hoo.OracleEnv(blob)
+    e.set_cfg(cfgz["jkp"], cfgz["jkd"], cfgz["torque_lim"], cfgz["thresh"])
+    e.set_expert({k[3:]: v for k, v in c.items() if k.startswith("ex_")})
+    e.set("cur_t", [int(c["cur_t"])]); e.set("start_ind", [int(c["start_ind"])])
+    e.set("qpos", c["qpos"]); e.set("qvel", c["qvel"])
+    xp = np.zeros((28, 3)); xp[:25] = c["body_xpos"]; e.set("xpos", xp)
+    xq = np.zeros((28, 4)); xq[:25] = c["body_xquat"]; e.set("xquat", xq)
+    e.set("qM", c["M"]); e.set("qfrc_bias", c["qfrc_bias"])
+    hi, lo = c["jnt_hi"], c["jnt_lo"]
+    base = (hi + lo) / 2; cs = hi - base; cs[6:] *= 1.2
+    e.set("base_pose", base); e.set("ctrl_scale", cs)
+    return e
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_obs_torque_diff_reward(oracle_lib, box_blob, cfg_golden, ci):
+    c = cases(golden("env_glue.npz"))[ci]
+    e = _env(oracle_lib, box_blob, c, cfg_golden)
+    assert e.get_obs().shape == (617,)
+    np.testing.assert_allclose(e.get_obs(), c["obs"], rtol=0, atol=5e-15)            # get_full_obs_v5, ho_im4.py:280
+    np.testing.assert_allclose(e.compute_torque(c["action"]), c["torque"], rtol=1e-12, atol=1e-13)  # :412-486
+    np.testing.assert_allclose(e.calc_ho_diff(), c["diffs"], rtol=0, atol=2e-15)     # :664-688
+    assert e.calc_ho_diff()[4] < 1e-7                                                # obj_rot_diff is identically 0 (:685)
+    e.set("rfc_score", [float(c["rfc_score"])])
+    r, info = e.reward(c["wk"])
+    assert abs(r - float(c["reward"])) < 1e-15                                       # ho_reward.py:943
+    np.testing.assert_allclose(info, c["reward_info"], rtol=0, atol=1e-15)
+
+
+def test_obs_body_block_is_component_major(oracle_lib, box_blob, cfg_golden):
+    """transform_vec_batch returns a (3, 20) array (math_utils.py:117-130): x of all bodies, then y, then z."""
+    c = cases(golden("env_glue.npz"))[0]
+    obs = c["obs"]
+    from hoic_amd.motions import qmat
+    R = qmat(c["body_xquat"][3])
+    rel = (c["body_xpos"][4:24] - c["qpos"][:3]) @ R          # rows: R^T v
+    np.testing.assert_allclose(obs[197:257].reshape(3, 20), rel.T, atol=1e-12)
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_classify_contact_and_rfc(oracle_lib, box_blob, ci):
+    c = cases(golden("rfc.npz"))[ci]
+    e = oracle_lib.OracleEnv(box_blob)
+    bm = np.zeros(28); bm[24] = c["body_mass"]; e.set("body_mass", bm)
+    bi = np.zeros((28, 3)); bi[24] = c["body_inertia"]; e.set("body_inertia", bi)
+    e.set("qpos", c["qpos"])
+    gx = np.zeros((28, 3)); gx[:23] = c["geom_xpos"]; e.set("geom_xpos", gx)
+    cs = np.zeros((28, 12)); cs[:19] = c["contact_sum"]; e.set("contact_sum", cs)
+    cc = np.zeros(28, np.int32); cc[:19] = c["contact_count"]; e.set("contact_count", cc)
+    e.classify_contact()
+    n = int(e.get("n_avg")[0])
+    assert n == len(c["avg_cp_geom"])
+    if n:
+        np.testing.assert_allclose(e.get("avg_cps")[:n], c["avg_cps"], atol=1e-14)   # ho_im4.py:567-597
+        assert np.array_equal(e.get("avg_cp_geom")[:n], c["avg_cp_geom"])
+        np.testing.assert_allclose(e.get("cp_ts")[:n], c["cp_ts"])
+    gv = np.zeros((28, 3)); gv[:23] = c["geom_avg_vel"]; e.set("geom_avg_vel", gv)
+    gw = np.zeros((28, 3)); gw[:23] = c["geom_avg_ang_vel"]; e.set("geom_avg_ang_vel", gw)
+    e.set("obj_avg_acc", c["obj_avg_acc"])
+    rf, rt, score = e.solve_rfc()
+    # the reference's QP (ho_im4.py:1063-1068) solved exactly by NNLS in the fixture; ours by the 6-D dual Newton
+    np.testing.assert_allclose(rf, c["rest_force"], atol=1e-10)
+    np.testing.assert_allclose(rt, c["rest_torque"], atol=1e-11)
+    assert abs(score - float(c["score"])) < 1e-9
+
+
+def test_nnqp_dual_against_scipy():
+    """Stand-alone check of the QP algorithm on random rank-6 problems against scipy NNLS."""
+    from scipy.optimize import nnls
+    from oracle import hoo
+    rng = np.random.default_rng(5)
+    for n in (4, 20, 100, 380):
+        A = rng.normal(size=(n, 6)); c = np.abs(rng.normal(size=n)) * 0.3; b = rng.normal(size=6); eps = 1e-7
+        lam, it = hoo.nnqp_dual(A, c, b, eps)
+        Q = 2 * A @ A.T + eps * np.eye(n); p = -2 * A @ b + c
+        L = np.linalg.cholesky(Q)
+        x, _ = nnls(L.T, -np.linalg.solve(L, p), maxiter=100 * n)
+        np.testing.assert_allclose(-lam / 2, b - A.T @ x, atol=1e-8)
+        assert it < 100
+
+
+def test_axis_angle(oracle_lib):
+    from hoic_amd.motions import matrix_to_axis_angle
+    z = golden("axis_angle.npz")
+    np.testing.assert_allclose(matrix_to_axis_angle(z["R"]), z["aa"], atol=1e-12)

@@ -1,0 +1,209 @@
+"""Physics part of the oracle.  MuJoCo is not available (parity to MuJoCo UNPINNED); these are the analytic /
+conservation checks SURVEY.md §8(c) lists, plus internal consistency of the solver (KKT)."""
+import numpy as np
+import pytest
+
+from hoic_amd import mjcf
+
+
+def _rand_state(model, rng, z=0.7):
+    A = model.arrays
+    lo, hi = A["jnt_range"][:26, 0], A["jnt_range"][:26, 1]
+    q = np.zeros(33); q[:26] = lo + (hi - lo) * rng.random(26); q[2] = z
+    q[26:29] = [0.3, 0.3, 0.9]; qq = rng.normal(size=4); q[29:] = qq / np.linalg.norm(qq)
+    return q, rng.normal(size=32)
+
+
+def test_model_constants(box_model):
+    A = box_model.arrays
+    assert (box_model.scalar("nq"), box_model.scalar("nv"), box_model.scalar("nu")) == (33, 32, 26)
+    assert box_model.scalar("nbody") == 25 and box_model.scalar("ngeom") == 23
+    assert abs(box_model.scalar("hand_mass") - 0.635) < 1e-12            # ho_im4.py:95-97
+    assert abs(A["body_mass"][24] - 125 * 8 * 0.0165 * 0.0265 * 0.049) < 1e-12
+    assert box_model.geom_names[2] == "robot0:C_palm0" and box_model.geom_names[21] == "C_box"
+    assert box_model.body_names[3] == "link_palm" and box_model.body_names[24] == "box"
+    assert (A["hand_geom0"][0], A["hand_geom1"][0], A["obj_geom0"][0], A["obj_geom1"][0]) == (2, 20, 21, 21)
+    # contact parameter mixing, hand x object
+    p = [i for i in range(box_model.scalar("npair")) if A["pair_geom1"][i] == 6 and A["pair_geom2"][i] == 21][0]
+    assert A["pair_condim"][p] == 3
+    np.testing.assert_allclose(A["pair_friction"][p], [1, 1, 0.5, 0.1, 0.1])
+    np.testing.assert_allclose(A["pair_solref"][p], [-6000, -300])
+    np.testing.assert_allclose(A["pair_solimp"][p], [0.95, 0.95, 0.001, 0.5, 2])
+    # hand geoms never collide with each other except through the 18 distinct explicit pairs
+    assert box_model.scalar("npair") - box_model.scalar("npair_dynamic") == 18
+
+
+def test_fk_zero_pose_is_body_offsets(oracle_lib, box_blob, box_model):
+    e = oracle_lib.OracleEnv(box_blob)
+    e.set("qpos", box_model.arrays["qpos0"]); e.forward()
+    xpos = e.get("xpos")
+    np.testing.assert_allclose(xpos[3], 0, atol=1e-15)
+    np.testing.assert_allclose(xpos[4], box_model.arrays["body_pos"][4], atol=1e-15)   # link_ff_pm offset in the XML
+
+
+def test_mass_matrix_and_gravity(oracle_lib, box_blob, box_model):
+    rng = np.random.default_rng(1)
+    e = oracle_lib.OracleEnv(box_blob)
+    q, v = _rand_state(box_model, rng)
+    e.set("qpos", q); e.set("qvel", np.zeros(32)); e.forward()
+    M = e.get("qM")
+    Mn = mjcf.mass_matrix_numpy(box_model, q)[0]
+    np.testing.assert_allclose(M, Mn, atol=1e-14)
+    assert np.all(np.linalg.eigvalsh(M) > 0)
+    assert np.abs(M[:26, 26:]).max() == 0                       # hand and object are separate trees
+    A = box_model.arrays
+
+    def PE(qq):
+        xi = mjcf.mass_matrix_numpy(box_model, qq)[4]
+        return 9.81 * (A["body_mass"] * xi[:, 2]).sum()
+    g = e.get("qfrc_bias")
+    for i in list(range(26)) + [26, 27, 28]:
+        dq = q.copy(); dq[i] += 1e-6
+        assert abs(g[i] - (PE(dq) - PE(q)) / 1e-6) < 1e-6
+
+
+def test_coriolis_matches_lagrangian(oracle_lib, box_blob, box_model):
+    """bias - gravity = d/dt(M) v - 1/2 d(v'Mv)/dq for the hand's slide/hinge chain (q_dot = v)."""
+    rng = np.random.default_rng(2)
+    e = oracle_lib.OracleEnv(box_blob)
+    q, v = _rand_state(box_model, rng)
+    v[26:] = 0
+    e.set("qpos", q); e.set("qvel", v); e.forward(); b = e.get("qfrc_bias").copy()
+    e.set("qvel", np.zeros(32)); e.forward(); g = e.get("qfrc_bias").copy()
+    h = 1e-6
+    dM = []
+    for k in range(26):
+        qp = q.copy(); qp[k] += h; qm = q.copy(); qm[k] -= h
+        dM.append((mjcf.mass_matrix_numpy(box_model, qp)[0] - mjcf.mass_matrix_numpy(box_model, qm)[0]) / (2 * h))
+    dM = np.array(dM)[:, :26, :26]
+    vh = v[:26]
+    c = np.einsum("kij,j,k->i", dM, vh, vh) - 0.5 * np.einsum("ijk,j,k->i", dM, vh, vh)
+    np.testing.assert_allclose((b - g)[:26], c, atol=2e-7)
+
+
+def test_free_fall_and_rest(oracle_lib, box_blob, box_model):
+    e = oracle_lib.OracleEnv(box_blob)
+    A = box_model.arrays
+    q = np.zeros(33); q[:26] = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1]); q[2] = 0.8
+    q[26:29] = [0.3, 0.0, 1.5]; q[29] = 1
+    e.set("qpos", q); e.set("qvel", np.zeros(32))
+    h = box_model.scalar("timestep")
+    for _ in range(100):
+        e.sim_step()
+    # free fall with dof frictionloss 0.001 on a 0.0224 kg (mass + armature) body: a = -(9.81*m - 0.001)/(m + arm)
+    m = A["body_mass"][24]
+    a = -(9.81 * m - 0.001) / (m + 0.001)
+    vz = e.get("qvel")[28]
+    assert abs(vz - a * 100 * h) < 1e-9
+    # drop on the table: ends at rest, upright, 4 contacts, tiny penetration
+    q[26:29] = [0.2, 0.0, 0.5 + 0.049 + 0.002]
+    e.set("qpos", q); e.set("qvel", np.zeros(32)); e.set("qacc_warmstart", np.zeros(32))
+    for _ in range(600):
+        e.sim_step()
+    qp, qv = e.get("qpos"), e.get("qvel")
+    assert abs(qp[28] - 0.549) < 1e-4 and np.abs(qv[26:]).max() < 1e-5
+    con = e.contacts()
+    tab = con[(con[:, 13] == 1) & (con[:, 14] == 21)]
+    assert len(tab) == 4 and np.all(tab[:, 0] < 0) and np.all(tab[:, 0] > -1e-4)
+    np.testing.assert_allclose(tab[:, 4:7], [[0, 0, 1]] * 4, atol=1e-12)
+
+
+def test_solver_kkt(oracle_lib, box_blob, box_model):
+    """At the solver's optimum the gradient M(a - a0) - J'f vanishes and forces obey their cones."""
+    rng = np.random.default_rng(3)
+    e = oracle_lib.OracleEnv(box_blob)
+    A = box_model.arrays
+    q = np.zeros(33); q[:26] = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1]); q[2] = 0.62
+    q[6:26] += 0.3 * rng.normal(size=20)
+    q[26:29] = [0.0, 0.05, 0.56]; q[29:] = [np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0]
+    e.set("qpos", q); e.set("qvel", rng.normal(size=32) * 0.3); e.forward()
+    nefc, ncon = int(e.get("nefc")[0]), int(e.get("ncon")[0])
+    assert ncon > 0
+    J = e.get("efc_J")[:nefc]; f = e.get("efc_force")[:nefc]
+    M = e.get("qM"); qacc = e.get("qacc"); a0 = e.get("qacc_smooth")
+    grad = M @ (qacc - a0) - J.T @ f
+    assert np.abs(grad).max() < 1e-9
+    ty = e.get("efc_type")[:nefc]
+    assert np.all(f[ty > 0] >= 0)                              # limits and contact edges push only
+    assert np.all(np.abs(f[ty == 0]) <= A["dof_frictionloss"].max() + 1e-15)
+    np.testing.assert_allclose(e.get("qfrc_constraint"), J.T @ f, atol=1e-12)
+
+
+def test_momentum_of_hand_object_contact(oracle_lib, box_blob, box_model):
+    """Contact forces are internal: with gravity off and no other constraints, J'f on the object's translational
+    dofs equals minus the net force the hand receives (checked through the contact frame sums)."""
+    rng = np.random.default_rng(4)
+    e = oracle_lib.OracleEnv(box_blob)
+    A = box_model.arrays
+    q = np.zeros(33); q[:26] = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1]); q[2] = 0.62
+    q[26:29] = [0.0, 0.045, 0.56]; q[29:] = [np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0]
+    e.set("qpos", q); e.set("qvel", np.zeros(32)); e.forward()
+    con = e.contacts()
+    hand_obj = con[(con[:, 13] >= 2) & (con[:, 13] <= 20) & (con[:, 14] == 21)]
+    assert len(hand_obj) > 0
+    # normals point from the hand geom to the object; penetration is negative distance
+    assert np.all(hand_obj[:, 0] < 0)
+    nefc = int(e.get("nefc")[0])
+    J = e.get("efc_J")[:nefc]; f = e.get("efc_force")[:nefc]
+    nf, nl = int(e.get("nf")[0]), int(e.get("nl")[0])
+    fobj = (J[nf:].T @ f[nf:])[26:29]          # without the dof friction-loss rows
+    # reconstruct the force on the object from the pyramid edges of the contacts that touch it
+    tot = np.zeros(3)
+    row = nf + nl
+    for c in con:
+        dim = int(c[15]); nr = 1 if dim == 1 else 2 * (dim - 1)
+        fr = c[4:13].reshape(3, 3); mu = [1, 1]
+        if c[14] == 21:
+            fe = f[row:row + nr]
+            if dim == 1:
+                tot += fe[0] * fr[0]
+            else:
+                tot += fe[:4].sum() * fr[0] + (fe[0] - fe[1]) * mu[0] * fr[1] + (fe[2] - fe[3]) * mu[1] * fr[2]
+                if nr == 6:
+                    tot += (fe[4] + fe[5]) * fr[0]
+        row += nr
+    np.testing.assert_allclose(fobj, tot, atol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["capsule_box", "capsule_capsule", "box_box_face", "plane_box"])
+def test_narrow_phase_geometry(oracle_lib, box_blob, box_model, case):
+    e = oracle_lib.OracleEnv(box_blob)
+    A = box_model.arrays
+    q = np.zeros(33); q[:26] = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1]); q[2] = 0.9
+    q[26:29] = [0.5, 0.5, 1.5]; q[29] = 1
+    if case == "plane_box":
+        q[26:29] = [0.5, 1.5, 0.049 - 0.001]          # off the table, 1 mm into the floor
+        e.set("qpos", q); e.forward()
+        con = e.contacts(); fl = con[(con[:, 13] == 0) & (con[:, 14] == 21)]
+        assert len(fl) == 4
+        np.testing.assert_allclose(fl[:, 0], -0.001, atol=1e-12)
+        np.testing.assert_allclose(fl[:, 3], -0.0005, atol=1e-12)   # pos is midway between corner and plane
+    elif case == "box_box_face":
+        q[26:29] = [0.2, 0.1, 0.5 + 0.049 - 0.002]
+        e.set("qpos", q); e.forward()
+        con = e.contacts(); tb = con[(con[:, 13] == 1) & (con[:, 14] == 21)]
+        assert len(tb) == 4
+        np.testing.assert_allclose(tb[:, 0], -0.002, atol=1e-12)
+        np.testing.assert_allclose(np.sort(tb[:, 1]), np.sort([0.2 - 0.0165] * 2 + [0.2 + 0.0165] * 2), atol=1e-12)
+    elif case == "capsule_box":
+        # put the box just under the index fingertip capsule (geom 8) along -z of that capsule's closest point
+        e.set("qpos", q); e.forward()
+        gp = e.get("geom_xpos")[8]; R = e.get("geom_xmat")[8].reshape(3, 3)
+        r, hl = A["geom_size"][8][0], A["geom_size"][8][1]
+        ends = np.array([gp + hl * R[:, 2], gp - hl * R[:, 2]])
+        low = ends[np.argmin(ends[:, 2])]
+        q[26:29] = [low[0], low[1], low[2] - r + 0.001 - 0.049]; q[29:] = [1, 0, 0, 0]   # top face 1 mm into the low end
+        e.set("qpos", q); e.forward()
+        con = e.contacts(); cb = con[(con[:, 13] == 8) & (con[:, 14] == 21)]
+        assert 1 <= len(cb) <= 2
+        assert abs(cb[:, 0].min() + 0.001) < 1e-9
+        deep = cb[np.argmin(cb[:, 0])]
+        np.testing.assert_allclose(deep[4:7], [0, 0, -1], atol=1e-9)      # normal from the capsule down into the box
+        np.testing.assert_allclose(deep[1:4], [low[0], low[1], low[2] - r + 0.0005], atol=1e-9)
+    else:
+        # thumb tip (geom 20) vs index tip (geom 8) is an explicit condim-1 pair: drive them together
+        e.set("qpos", q); e.forward()
+        g = e.get("geom_xpos")
+        assert np.linalg.norm(g[8] - g[20]) > 0.02
+        con = e.contacts()
+        assert not len(con[(con[:, 13] == 8) & (con[:, 14] == 20)])
