@@ -46,7 +46,7 @@ __device__ void store_state(const DevState& st, const Work& w, int env) {
 __device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, int* overflow) {
   const int tid = threadIdx.x;
   dev_forward_kin(m, w, w.qpos, w.qvel, overflow);
-  dev_make_constraint(m, w, w.qpos, w.qvel);
+  dev_make_constraint(m, w, w.qpos, w.qvel); PT(7);
   if (tid < NV) {
     float fs = 0.f;
     if (tid < m.nv) {
@@ -54,13 +54,12 @@ __device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w
       for (int u = 0; u < m.nu; u++) if (m.act_dofid[u] == tid) act += w.ctrl[u];
       fs = w.passive[tid] - w.bias[tid] + w.applied[tid] + act;
     }
-    w.fsmooth[tid] = fs; w.asmooth[tid] = fs;
-    for (int k = 0; k < NV; k++) w.H[tid * LD + k] = (tid < m.nv && k < m.nv) ? w.M[tid * LD + k] : 0.f;
-    if (tid >= m.nv) w.H[tid * LD + tid] = 1.f;
+    w.fsmooth[tid] = fs; w.asmooth[tid] = fs; w.tv2[tid] = 0.f;
   }
   __syncthreads();
-  spd_solve32(w.H, w.asmooth, w.T);
-  dev_solve(m, w, cfg.c.solver_iterations);
+  PT(20);
+  dev_hsolve(m, w, w.tv2, m.nv, false, w.asmooth); PT(8);
+  dev_solve(m, w, cfg.c.solver_iterations); PT(9);
   float bad = 0.f;
   if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
   return !(wave_max(bad) > 0.f);
@@ -70,12 +69,12 @@ __device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w
 __device__ void dev_euler(const DevModel& m, Work& w) {
   const int tid = threadIdx.x;
   if (tid < NV) {
-    for (int k = 0; k < NV; k++) w.H[tid * LD + k] = (tid < m.nv && k < m.nv) ? w.M[tid * LD + k] : 0.f;
-    w.H[tid * LD + tid] = (tid < m.nv) ? (w.M[tid * LD + tid] + m.timestep * m.dof_damping[tid]) : 1.f;
+    w.tv2[tid] = (tid < m.nv) ? m.timestep * m.dof_damping[tid] : 0.f;
     w.tv[tid] = (tid < m.nv) ? (w.fsmooth[tid] + w.fcon[tid]) : 0.f;
   }
   __syncthreads();
-  spd_solve32(w.H, w.tv, w.T);
+  PT(20);
+  dev_hsolve(m, w, w.tv2, m.nv, false, w.tv);
   const float h = m.timestep;
   if (tid < NQP) w.qlag[tid] = w.qpos[tid];
   if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
@@ -111,6 +110,10 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
   const int env = blockIdx.x, tid = threadIdx.x;
   load_state(m, st, w, env);
+#ifdef HOIC_PHASE_TIMING
+  if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
+  __syncthreads();
+#endif
   if (tid < NV) w.action[tid] = fminf(fmaxf(action[(size_t)env * HOIC_ACT_DIM + tid], -1.f), 1.f);   // ho_im4.py:613
   __syncthreads();
   const int seq = st.seq[env];
@@ -132,13 +135,15 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
   bool ok = true;
   const int nsub = cfg.c.sim_step;
   for (int i = 0; i < nsub; i++) {
-    dev_pd_torque(m, cfg, w, ev);        // :518-523
+    PT(0);
+    dev_pd_torque(m, cfg, w, ev); PT(1);       // :518-523
     dev_applied(m, cfg, w, vf, vt);      // :526-540
-    dev_record_contact(m, w);            // :543
+    dev_record_contact(m, w); PT(2);           // :543
     ok = dev_forward_dyn(m, cfg, w, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
     if (!ok) break;
-    dev_euler(m, w);                     //              ... + Euler
+    dev_euler(m, w); PT(10);                    //              ... + Euler
   }
+  PT(0);
   float rfc_score = 0.f;
   if (ok) {
     const float dt = (float)nsub * m.timestep, idt = 1.f / dt;
@@ -156,8 +161,9 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
       for (int i = 0; i < 3; i++) w.gangvel[g][i] = aa[i] * idt;
     }
     __syncthreads();
-    dev_classify_contact(m, w);                                                                 // :562
+    dev_classify_contact(m, w); PT(11);                                                        // :562
     if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt);                     // :631
+    PT(12);
     if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
   }
   if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
@@ -194,9 +200,14 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
     ev.off = ex.seq_off[ns]; ev.len = ex.seq_len[ns]; ev.start = nst; ev.cur_t = 0;
     if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
   }
+  PT(13);
   dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
   store_state(st, w, env);
   if (tid == 0) st.cur_t[env] = ev.cur_t;
+  PT(14);
+#ifdef HOIC_PHASE_TIMING
+  if (tid < 24) st.phase[(size_t)env * 24 + tid] = w.pt[tid];
+#endif
 }
 
 __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restrict__ mp, DevExpert ex, DevState st,
@@ -484,14 +495,15 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.qvel, n * NV * 4) == hipSuccess && hipMalloc(&s->st.vlag, n * NV * 4) == hipSuccess &&
        hipMalloc(&s->st.warm, n * NV * 4) == hipSuccess && hipMalloc(&s->st.cur_t, n * 4) == hipSuccess &&
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
-       hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess;
+       hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess &&
+       hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
   hipMemcpy(s->d_model, &s->hm, sizeof(DevModel), hipMemcpyHostToDevice);
   hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice);
   hipMemset(s->st.qpos, 0, n * NQP * 4); hipMemset(s->st.qlag, 0, n * NQP * 4); hipMemset(s->st.qvel, 0, n * NV * 4);
   hipMemset(s->st.vlag, 0, n * NV * 4); hipMemset(s->st.warm, 0, n * NV * 4); hipMemset(s->st.cur_t, 0, n * 4);
   hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
-  hipMemset(s->st.overflow, 0, n * 4);
+  hipMemset(s->st.overflow, 0, n * 4); hipMemset(s->st.phase, 0, n * 24 * 8);
   hipDeviceSynchronize();
   return s;
 }
@@ -501,7 +513,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->d_iota_seq, s->d_iota_start};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->d_iota_seq, s->d_iota_start};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -634,4 +646,18 @@ extern "C" float hoic_last_step_ms(hoic_sim* s) {
   float ms = -1.f;
   if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.f;
   return ms;
+}
+
+// development aid (not part of include/hoic.h): per-phase shader-cycle counters of the last step, averaged over
+// envs; all zeros unless the library was built with -DHOIC_PHASE_TIMING
+extern "C" int32_t hoicdbg_phase_cycles(hoic_sim* s, double* out24, int32_t* overflow_total) {
+  if (!s || !out24) return HOIC_ERR_ARG;
+  std::vector<long long> h((size_t)s->n_envs * 24);
+  std::vector<int> ov(s->n_envs);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(h.data(), s->st.phase, h.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ov.data(), s->st.overflow, ov.size() * 4, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 24; k++) { double a = 0; for (int e = 0; e < s->n_envs; e++) a += (double)h[(size_t)e * 24 + k]; out24[k] = a / s->n_envs; }
+  if (overflow_total) { long long t = 0; for (int v : ov) t += v; *overflow_total = (int32_t)t; }
+  return HOIC_OK;
 }

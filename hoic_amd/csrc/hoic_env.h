@@ -25,10 +25,10 @@ struct ExpertView {
 
 // ---- position + velocity stages of the forward pass on state (q, v); leaves M, bias, contacts, S in LDS
 __device__ void dev_forward_kin(const DevModel& m, Work& w, const float* q, const float* v, int* overflow) {
-  dev_kinematics(m, w, q);
-  dev_mass_matrix(m, w);
-  dev_bias(m, w, v);
-  dev_collision(m, w, overflow);
+  dev_kinematics(m, w, q); PT(3);
+  dev_mass_matrix(m, w); PT(4);
+  dev_bias(m, w, v); PT(5);
+  dev_collision(m, w, overflow); PT(6);
 }
 
 // ---- stable PD torque (ho_im4.py:412-486) using M and bias currently in LDS (i.e. lagged)
@@ -50,12 +50,12 @@ __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, 
     kp = cfg.c.jkp[tid]; kd = cfg.c.jkd[tid];
   }
   if (tid < NV) {
-    for (int k = 0; k < NV; k++) w.H[tid * LD + k] = (tid < n && k < n) ? w.M[tid * LD + k] : 0.f;
-    w.H[tid * LD + tid] = (tid < n) ? (w.M[tid * LD + tid] + kd * dt) : 1.f;
+    w.tv2[tid] = kd * dt;
     w.tv[tid] = (tid < n) ? (-w.bias[tid] - kp * err - kd * w.qvel[tid]) : 0.f;
   }
   __syncthreads();
-  spd_solve32(w.H, w.tv, w.T);
+  PT(20);
+  dev_hsolve(m, w, w.tv2, n, false, w.tv);
   if (tid < NV) {
     float tq = 0.f;
     if (tid < n) {

@@ -12,49 +12,103 @@
 #include "hoic_types.h"
 #include "hoic_math.h"
 
-// ---- dense SPD solve A x = b for n = 32 (A in LDS with stride LD, b in LDS; b is overwritten with x).
-// Lanes 0..31 hold one row each.  T is 32*LD floats of LDS scratch used to transpose the factor.
-__device__ __noinline__ void spd_solve32(const float* __restrict__ A, float* __restrict__ b, float* __restrict__ T) {
-  const int lane = threadIdx.x;
-  const int r = lane < 32 ? lane : 31;
-  float a[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) a[k] = A[r * LD + k];
-  float dinv = 0.f;
-#pragma unroll
-  for (int j = 0; j < 32; j++) {
-    float s = a[j];
-#pragma unroll
-    for (int k = 0; k < j; k++) s -= a[k] * rl(a[k], j);
-    const float dj = fmaxf(rl(s, j), 1e-30f);
-    const float inv = rsqrtf(dj);
-    a[j] = s * inv;
-    if (lane == j) dinv = inv;
+// ---- 32x32 SPD assemble + solve on the matrix core.
+// The matrix lives in ONE v_mfma_f32_32x32x2_f32 accumulator (16 VGPRs per lane; element (row, col) sits in
+// lane (col + 32*((row>>2)&1)), register (row&3) + 4*(row>>3)).  Exact f32 (an fma chain), so numerics equal
+// the VALU version.
+//   A = M (+ diag) restricted to the leading nact x nact block, identity elsewhere
+//   (+ sum over active contact rows  curv_r J_r' J_r : two rank-1 terms per MFMA, K = 2)
+// Factorisation: right-looking LDL^T, one rank-1 MFMA per pivot (64 cycles) instead of 31 readlane+FMA pairs.
+// Row j of the running matrix (= column j of L times d_j) is one value per lane, so the scaled column is also
+// the MFMA A-operand.  Columns of L are kept one register each (lane = row); the backward substitution gets
+// the transpose through the 32x33 LDS scratch `T`.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+template <int J> HD float hs_row_bcast(const f32x16& acc) {
+  constexpr int reg = (J & 3) + 4 * (J >> 3);
+  constexpr int half = (J >> 2) & 1;
+  const unsigned v = __float_as_uint(acc[reg]);
+  const u32x2v r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // .x = low half on both, .y = high half on both
+  return __uint_as_float(half ? r.y : r.x);
+}
+
+template <int J> struct HsFactor {
+  static HD void run(f32x16& acc, float (&lcol)[32], float& dinv, int col, int hi) {
+    const float u = hs_row_bcast<J>(acc);           // u[lane&31] = A[J][lane&31] = L[.][J] * d_J
+    const float d = fmaxf(rl(u, J), 1e-30f);
+    const float inv = 1.f / d;
+    const float lj = u * inv;
+    if (col == J) dinv = inv;
+    lcol[J] = lj;
+    if (J < 31) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : -lj, hi ? 0.f : u, acc, 0, 0, 0);
+    HsFactor<J + 1>::run(acc, lcol, dinv, col, hi);
   }
-  float y = b[r];
+};
+template <> struct HsFactor<32> { static HD void run(f32x16&, float (&)[32], float&, int, int) {} };
+
+// diag: 32 floats in LDS added to the diagonal; use_rows: add the active contact rows through the MFMA (the
+// caller folds friction/limit curvature into diag); b (LDS, 32) is overwritten by x.
+__device__ __forceinline__ void dev_hsolve(const DevModel& m, Work& w, const float* diag, int nact, bool use_rows, float* b) {
+  const int lane = threadIdx.x, col = lane & 31, hi = lane >> 5;
+  f32x16 acc;
+  const float dg = diag[col];     // diagonal increment of row/col `col`
 #pragma unroll
-  for (int k = 0; k < 32; k++) {
-    const float yk = rl(y, k) * rl(dinv, k);
-    if (lane == k) y = yk;
-    else if (lane > k) y -= a[k] * yk;
+  for (int reg = 0; reg < 16; reg++) {
+    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+    float v = w.M[r * LD + col];
+    if (r == col) v += dg;
+    if (r >= nact || col >= nact) v = (r == col) ? 1.f : 0.f;
+    acc[reg] = v;
   }
+  if (use_rows) {
+    for (int c = 0; c < w.ncon; c++) {
+      const int nr = w.c_nrow[c], r0 = w.c_row0[c];
+      const float* J = &w.Jc[(c * NBASIS) * LD];
+      const float jn = J[col];
+      for (int p = 0; 2 * p < nr; p++) {       // edges 2p (low half of the wave) and 2p+1 (high half)
+        const float cu0 = w.r_curv[r0 + 2 * p], cu1 = (2 * p + 1 < nr) ? w.r_curv[r0 + 2 * p + 1] : 0.f;
+        if (cu0 == 0.f && cu1 == 0.f) continue;
+        float v = jn;
+        if (nr > 1) v += (hi ? -1.f : 1.f) * w.c_mu[c][p] * J[(1 + p) * LD + col];
+        const float cu = hi ? cu1 : cu0;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cu * v, v, acc, 0, 0, 0);
+      }
+    }
+  }
+  PT(15);
+  float lcol[32], dinv = 1.f;
+  HsFactor<0>::run(acc, lcol, dinv, col, hi);
+  PT(16);
+  // forward substitution (unit lower), diagonal scaling
+  float y = b[col];
+#pragma unroll
+  for (int k = 0; k < 31; k++) {
+    const float yk = rl(y, k);
+    if (col > k) y -= lcol[k] * yk;
+  }
+  y *= dinv;
+  PT(17);
+  __syncthreads();
+  float* T = w.H;
   if (lane < 32) {
 #pragma unroll
-    for (int k = 0; k < 32; k++) T[r * LD + k] = a[k];
+    for (int k = 0; k < 32; k++) T[lane * LD + k] = lcol[k];     // row `lane` of L
   }
   __syncthreads();
-  float c[32];
 #pragma unroll
-  for (int k = 0; k < 32; k++) c[k] = T[k * LD + r];
+  for (int k = 0; k < 32; k++) lcol[k] = T[k * LD + col];        // column `col` of L (valid for k > col)
   float x = y;
 #pragma unroll
-  for (int k = 31; k >= 0; k--) {
-    const float xk = rl(x, k) * rl(dinv, k);
-    if (lane == k) x = xk;
-    else if (lane < k) x -= c[k] * xk;
+  for (int k = 31; k > 0; k--) {
+    const float xk = rl(x, k);
+    if (col < k) x -= lcol[k] * xk;
   }
+  PT(18);
+  __syncthreads();
   if (lane < 32) b[lane] = x;
   __syncthreads();
+  PT(19);
 }
 
 // impedance d(r) from solimp [MJ-doc: getimpedance]
@@ -236,39 +290,6 @@ __device__ void dev_jt_force(const DevModel& m, Work& w, float* out) {
   __syncthreads();
 }
 
-// H = M + sum_r curv_r J_r' J_r, one row per lane in registers, written to w.H
-__device__ __noinline__ void dev_build_H(const DevModel& m, Work& w) {
-  const int lane = threadIdx.x, r = lane < 32 ? lane : 31;
-  float h[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) h[k] = w.M[r * LD + k];
-  for (int c = 0; c < w.ncon; c++) {
-    const int nr = w.c_nrow[c], r0 = w.c_row0[c];
-    const float* J = &w.Jc[(c * NBASIS) * LD];
-    const float jn = J[r];
-    for (int e = 0; e < nr; e++) {
-      const float cu = w.r_curv[r0 + e];
-      if (cu == 0.f) continue;
-      float v = jn;
-      if (nr > 1) { const int k = e >> 1; v += ((e & 1) ? -1.f : 1.f) * w.c_mu[c][k] * J[(1 + k) * LD + r]; }
-      const float cv = cu * v;
-#pragma unroll
-      for (int k = 0; k < 32; k++) h[k] += cv * rl(v, k);
-    }
-  }
-  if (lane < 32) {
-#pragma unroll
-    for (int k = 0; k < 32; k++) w.H[r * LD + k] = h[k];
-  }
-  __syncthreads();
-  if (lane < m.nv) {
-    float dg = w.r_curv[lane];
-    for (int l = 0; l < w.nlim; l++) if (w.lim_dof[l] == lane) dg += w.r_curv[m.nv + l];
-    w.H[lane * LD + lane] += dg;
-  }
-  __syncthreads();
-}
-
 // ---- Newton with exact line search.  In: M, fsmooth, asmooth, warm, rows.  Out: qacc, fcon.
 __device__ void dev_solve(const DevModel& m, Work& w, int maxit) {
   const int tid = threadIdx.x;
@@ -294,13 +315,17 @@ __device__ void dev_solve(const DevModel& m, Work& w, int maxit) {
     g2 = wave_sum(g2);
     __syncthreads();
     if (sqrtf(g2) * scale < 1e-6f) break;
-    dev_build_H(m, w);
-    if (tid >= m.nv && tid < NV) {  // identity padding for unused dofs
-      for (int k = 0; k < NV; k++) { w.H[tid * LD + k] = 0.f; w.H[k * LD + tid] = 0.f; }
-      w.H[tid * LD + tid] = 1.f;
+    if (tid < NV) {   // diagonal curvature of the friction-loss and limit rows
+      float dg = 0.f;
+      if (tid < m.nv) {
+        dg = w.r_curv[tid];
+        for (int l = 0; l < w.nlim; l++) if (w.lim_dof[l] == tid) dg += w.r_curv[m.nv + l];
+      }
+      w.tv2[tid] = dg;
     }
     __syncthreads();
-    spd_solve32(w.H, w.search, w.T);
+    PT(20);
+    dev_hsolve(m, w, w.tv2, m.nv, true, w.search);
     // line-search quantities
     float gq = 0.f, hh = 0.f, g0 = 0.f;
     if (tid < m.nv) {

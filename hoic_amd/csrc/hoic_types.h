@@ -83,6 +83,7 @@ struct DevState {
   int* seq;      // [n]
   float* rfc_score;  // [n]
   int* overflow; // [n] contact-cap overflow counter
+  long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
 };
 
 // per-env LDS workspace
@@ -96,7 +97,7 @@ struct Work {
   float S[NV][6], fS[NV][6];
   float gxpos[NG][3], gxmat[NG][9], old_gxpos[NG][3], old_gxmat[NG][9];
   float old_objvel[6];
-  float M[NV * LD], H[NV * LD], T[NV * LD];
+  float M[NV * LD], H[NV * LD];
   // contacts of the current forward pass
   int ncon, nlim, nrow, pad0;
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON], c_mu[MAXCON][3], c_D[MAXCON], c_aref0[MAXCON], c_B[MAXCON];
@@ -114,4 +115,13 @@ struct Work {
   float gvel[NG][3], gangvel[NG][3], obj_avg_acc[6];
   float red[8];
   int solver_iter, fail;
+#ifdef HOIC_PHASE_TIMING
+  long long pt[24], pt_last;
+#endif
 };
+
+#ifdef HOIC_PHASE_TIMING
+#define PT(i) do { long long t_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) { w.pt[i] += t_ - w.pt_last; w.pt_last = t_; } } while (0)
+#else
+#define PT(i) do {} while (0)
+#endif
