@@ -43,15 +43,14 @@ __device__ void store_state(const DevState& st, const Work& w, int env) {
 }
 
 // mj_forward dynamics on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
-__device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, int* overflow) {
+__device__ bool dev_forward_dyn(const DevModel& m, const LaneK& lk, const DevConfig& cfg, Work& w, int* overflow) {
   const int tid = threadIdx.x;
-  dev_forward_kin(m, w, w.qpos, w.qvel, overflow);
-  dev_make_constraint(m, w, w.qpos, w.qvel); PT(7);
+  dev_forward_kin(m, lk, w, w.qpos, w.qvel, overflow);
+  dev_make_constraint(m, lk, w, w.qpos, w.qvel); PT(7);
   if (tid < NV) {
     float fs = 0.f;
     if (tid < m.nv) {
-      float act = 0.f;
-      for (int u = 0; u < m.nu; u++) if (m.act_dofid[u] == tid) act += w.ctrl[u];
+      const float act = lk.d_act >= 0 ? w.ctrl[lk.d_act] : 0.f;
       fs = w.passive[tid] - w.bias[tid] + w.applied[tid] + act;
     }
     w.fsmooth[tid] = fs; w.asmooth[tid] = fs; w.tv2[tid] = 0.f;
@@ -59,17 +58,17 @@ __device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w
   __syncthreads();
   PT(20);
   dev_hsolve(m, w, w.tv2, m.nv, false, w.asmooth); PT(8);
-  dev_solve(m, w, cfg.c.solver_iterations); PT(9);
+  dev_solve(m, lk, w, cfg.c.solver_iterations); PT(9);
   float bad = 0.f;
   if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
   return !(wave_max(bad) > 0.f);
 }
 
 // semi-implicit Euler with implicit joint damping; also records the pre-integration state (lag) and warm start
-__device__ void dev_euler(const DevModel& m, Work& w) {
+__device__ void dev_euler(const DevModel& m, const LaneK& lk, Work& w) {
   const int tid = threadIdx.x;
   if (tid < NV) {
-    w.tv2[tid] = (tid < m.nv) ? m.timestep * m.dof_damping[tid] : 0.f;
+    w.tv2[tid] = (tid < m.nv) ? m.timestep * lk.d_damp : 0.f;
     w.tv[tid] = (tid < m.nv) ? (w.fsmooth[tid] + w.fcon[tid]) : 0.f;
   }
   __syncthreads();
@@ -82,8 +81,8 @@ __device__ void dev_euler(const DevModel& m, Work& w) {
   if (tid < m.nv) w.qvel[tid] += h * w.tv[tid];
   __syncthreads();
   if (tid < m.njnt) {
-    const int qa = m.jnt_qposadr[tid], da = m.jnt_dofadr[tid];
-    if (m.jnt_type[tid] == HOIC_JNT_FREE) {
+    const int qa = lk.j_qadr, da = lk.j_dadr;
+    if (lk.j_type == HOIC_JNT_FREE) {
       for (int i = 0; i < 3; i++) w.qpos[qa + i] += h * w.qvel[da + i];
       float wv[3] = {w.qvel[da + 3], w.qvel[da + 4], w.qvel[da + 5]};
       const float ang = normalize3(wv) * h;
@@ -110,6 +109,8 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
   const int env = blockIdx.x, tid = threadIdx.x;
   load_state(m, st, w, env);
+  LaneK lk;
+  dev_load_constants(m, w, lk);
 #ifdef HOIC_PHASE_TIMING
   if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
   __syncthreads();
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
   }
   int* ovf = &st.overflow[env];
   // quantities of the previous forward pass (one-substep lag): recompute them from the lagged state
-  dev_forward_kin(m, w, w.qlag, w.vlag, tid == 0 ? ovf : nullptr);
+  dev_forward_kin(m, lk, w, w.qlag, w.vlag, tid == 0 ? ovf : nullptr);
   for (int g = tid; g < m.ngeom; g += NT) {
     for (int i = 0; i < 3; i++) w.old_gxpos[g][i] = w.gxpos[g][i];
     for (int i = 0; i < 9; i++) w.old_gxmat[g][i] = w.gxmat[g][i];
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
     dev_pd_torque(m, cfg, w, ev); PT(1);       // :518-523
     dev_applied(m, cfg, w, vf, vt);      // :526-540
     dev_record_contact(m, w); PT(2);           // :543
-    ok = dev_forward_dyn(m, cfg, w, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
+    ok = dev_forward_dyn(m, lk, cfg, w, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
     if (!ok) break;
-    dev_euler(m, w); PT(10);                    //              ... + Euler
+    dev_euler(m, lk, w); PT(10);                    //              ... + Euler
   }
   PT(0);
   float rfc_score = 0.f;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
     if (tid < NQP) w.qpos[tid] = w.qlag[tid];
     if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
     __syncthreads();
-    dev_kinematics(m, w, w.qpos);
+    dev_kinematics(m, lk, w, w.qpos);
   }
   ev.cur_t += 1;                                                                                // :641
   float df[5];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
   if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
     const int ns = next_seq[env], nst = next_start[env];
     dev_reset_state(m, w, ex, ns, nst);
-    dev_kinematics(m, w, w.qpos);
+    dev_kinematics(m, lk, w, w.qpos);
     ev.off = ex.seq_off[ns]; ev.len = ex.seq_len[ns]; ev.start = nst; ev.cur_t = 0;
     if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
   }
@@ -220,8 +221,10 @@ __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restri
   const int seq = seqs[k], start = starts[k];
   if (tid < NQP) w.qpos[tid] = 0.f;
   __syncthreads();
+  LaneK lk;
+  dev_load_constants(m, w, lk);
   dev_reset_state(m, w, ex, seq, start);
-  dev_kinematics(m, w, w.qpos);
+  dev_kinematics(m, lk, w, w.qpos);
   ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], start, 0};
   if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
   store_state(st, w, env);
@@ -265,7 +268,9 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   }
   if (tid == 0) { w.ncon = 0; w.nlim = 0; w.nrow = 0; w.solver_iter = 0; }
   __syncthreads();
-  const bool ok = dev_forward_dyn(m, cfg, w, nullptr);
+  LaneK lk;
+  dev_load_constants(m, w, lk);
+  const bool ok = dev_forward_dyn(m, lk, cfg, w, nullptr);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
   if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
       } else for (int i = 0; i < 16; i++) r[i] = 0.f;
     }
   }
-  if (a.do_step && ok) dev_euler(m, w);
+  if (a.do_step && ok) dev_euler(m, lk, w);
   if (a.qpos_out && tid < m.nq) a.qpos_out[(size_t)env * m.nq + tid] = w.qpos[tid];
   if (a.qvel_out && tid < m.nv) a.qvel_out[(size_t)env * m.nv + tid] = w.qvel[tid];
 }
@@ -455,6 +460,7 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
       const double mu = f[0] * std::sqrt(1.0 / std::max(1e-15, impratio));
       m.pair_Rscale[p] = (float)(2 * mu * mu * (tran + f[0] * f[0] * tran));
     }
+    m.pair_b1[p] = b1; m.pair_b2[p] = b2;
     const int t1 = m.geom_type[m.pair_geom1[p]], t2 = m.geom_type[m.pair_geom2[p]];
     if (t1 == HOIC_GEOM_MESH || t2 == HOIC_GEOM_MESH) { /* convex-mesh pairs: not in this round's kernel */ }
   }

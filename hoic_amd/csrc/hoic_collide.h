@@ -301,23 +301,25 @@ HD void make_frame(float* f) {
 }
 
 // ---- collision driver: lane = pair (two passes when npair > 64); contacts compacted into the workspace
-__device__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
+__device__ void dev_collision(const DevModel& m, const LaneK& lk, Work& w, int* overflow) {
   const int tid = threadIdx.x;
   if (tid == 0) w.ncon = 0;
   __syncthreads();
-  for (int base = 0; base < m.npair; base += NT) {
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+    const int base = ps * NT;
+    if (base >= m.npair) break;
     const int p = base + tid;
     LaneContacts lc;
     lc.n = 0;
-    if (p < m.npair) {
-      const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p], t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1]; const float* s1 = m.geom_size[g1];
-      const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2]; const float* s2 = m.geom_size[g2];
+    if (lk.p_t1[ps] >= 0) {
+      const int g1 = lk.p_g1[ps], g2 = lk.p_g2[ps], t1 = lk.p_t1[ps], t2 = lk.p_t2[ps];
+      const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1]; const float* s1 = lk.p_s1[ps];
+      const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2]; const float* s2 = lk.p_s2[ps];
       bool test = true;
       if (t1 != HOIC_GEOM_PLANE) {
         float dv[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-        float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + m.pair_margin[p];
-        test = dot3(dv, dv) <= bound * bound;
+        test = dot3(dv, dv) <= lk.p_bound[ps] * lk.p_bound[ps];
       }
       if (test) {
         if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_CAPSULE) col_plane_capsule(p1, R1, p2, R2, s2, lc);
@@ -328,24 +330,22 @@ __device__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
       }
       // margin filter
       int k2 = 0;
-      for (int k = 0; k < lc.n; k++)
-        if (lc.dist[k] < m.pair_margin[p]) {
-          if (k2 != k) { lc.dist[k2] = lc.dist[k]; for (int i = 0; i < 3; i++) { lc.pos[k2][i] = lc.pos[k][i]; lc.nrm[k2][i] = lc.nrm[k][i]; } }
+      for (int q = 0; q < lc.n; q++)
+        if (lc.dist[q] < lk.p_margin[ps]) {
+          if (k2 != q) { lc.dist[k2] = lc.dist[q]; for (int i = 0; i < 3; i++) { lc.pos[k2][i] = lc.pos[q][i]; lc.nrm[k2][i] = lc.nrm[q][i]; } }
           k2++;
         }
       lc.n = k2;
     }
     // exclusive prefix sum of per-lane counts over the wave
-    int cnt = lc.n, incl = cnt;
-#pragma unroll
-    for (int o = 1; o < NT; o <<= 1) { int v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+    const int cnt = lc.n, incl = wave_incl_scan(cnt);
     const int start = w.ncon + incl - cnt;
-    const int total = __shfl(incl, NT - 1);
-    for (int k = 0; k < lc.n; k++) {
-      const int c = start + k;
+    const int total = __builtin_amdgcn_readlane(incl, NT - 1);
+    for (int q = 0; q < lc.n; q++) {
+      const int c = start + q;
       if (c < MAXCON) {
-        w.c_dist[c] = lc.dist[k]; w.c_pair[c] = p;
-        for (int i = 0; i < 3; i++) { w.c_pos[c][i] = lc.pos[k][i]; w.c_frame[c][i] = lc.nrm[k][i]; }
+        w.c_dist[c] = lc.dist[q]; w.c_pair[c] = p;
+        for (int i = 0; i < 3; i++) { w.c_pos[c][i] = lc.pos[q][i]; w.c_frame[c][i] = lc.nrm[q][i]; }
         make_frame(w.c_frame[c]);
       }
     }

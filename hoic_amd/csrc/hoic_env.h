@@ -24,11 +24,11 @@ struct ExpertView {
 };
 
 // ---- position + velocity stages of the forward pass on state (q, v); leaves M, bias, contacts, S in LDS
-__device__ void dev_forward_kin(const DevModel& m, Work& w, const float* q, const float* v, int* overflow) {
-  dev_kinematics(m, w, q); PT(3);
-  dev_mass_matrix(m, w); PT(4);
-  dev_bias(m, w, v); PT(5);
-  dev_collision(m, w, overflow); PT(6);
+__device__ void dev_forward_kin(const DevModel& m, const LaneK& lk, Work& w, const float* q, const float* v, int* overflow) {
+  dev_kinematics(m, lk, w, q); PT(3);
+  dev_mass_matrix(m, lk, w); PT(4);
+  dev_bias(m, lk, w, v); PT(5);
+  dev_collision(m, lk, w, overflow); PT(6);
 }
 
 // ---- stable PD torque (ho_im4.py:412-486) using M and bias currently in LDS (i.e. lagged)
@@ -74,8 +74,8 @@ __device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, co
     float s = 0.f;
     if (tid < m.nv) {
       const float f[3] = {0.f, 0.f, m.hand_mass * 9.8f}, z[3] = {0.f, 0.f, 0.f};
-      s = dev_apply_ft_dof(m, w, tid, 3, f, z, w.gxpos[2]);                       // ho_im4.py:527-535
-      if (cfg.c.residual_force) s += dev_apply_ft_dof(m, w, tid, m.obj_body, vf, vt, &w.qpos[m.hand_nq]);  // :492-500
+      s = dev_apply_ft_dof(w, tid, 3, f, z, w.gxpos[2]);                       // ho_im4.py:527-535
+      if (cfg.c.residual_force) s += dev_apply_ft_dof(w, tid, m.obj_body, vf, vt, &w.qpos[m.hand_nq]);  // :492-500
     }
     w.applied[tid] = s;
   }

@@ -62,20 +62,46 @@ HD void quat_matrix_ref(const float* qin, float* R) {
   R[6] = q[1] * q[3] - q[2] * q[0]; R[7] = q[2] * q[3] + q[1] * q[0]; R[8] = 1.f - q[1] * q[1] - q[2] * q[2];
 }
 
-// wavefront (64-lane) reductions
+HD float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// wavefront (64-lane) reductions on the DPP crossbar (no LDS round trips): quad butterflies, half-row and row
+// mirrors give every lane of a 16-lane row the row total, four readlanes combine the rows.
+template <int CTRL> HD float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 HD float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_mov<0xb1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4e>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+HD float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xb1>(v));
+  v = fmaxf(v, dpp_mov<0x4e>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
 }
 HD double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-HD float wave_max(float v) {
+// inclusive prefix sum of a small non-negative integer over the wave (ballot-free, DPP row shifts + readlanes)
+HD int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+  int x = v;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  for (int o = 1; o < 16; o <<= 1) {
+    int t;
+    if (o == 1) t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);        // row_shr:1
+    else if (o == 2) t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    else if (o == 4) t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    else t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);               // row_shr:8
+    x += t;
+  }
+  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = lane >> 4;
+  return x + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
 }
-HD float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }

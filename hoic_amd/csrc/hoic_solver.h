@@ -37,7 +37,8 @@ template <int J> struct HsFactor {
   static HD void run(f32x16& acc, float (&lcol)[32], float& dinv, int col, int hi) {
     const float u = hs_row_bcast<J>(acc);           // u[lane&31] = A[J][lane&31] = L[.][J] * d_J
     const float d = fmaxf(rl(u, J), 1e-30f);
-    const float inv = 1.f / d;
+    float inv = __builtin_amdgcn_rcpf(d);
+    inv = inv * (2.f - d * inv);                   // one Newton step: full f32 accuracy without the IEEE divide
     const float lj = u * inv;
     if (col == J) dinv = inv;
     lcol[J] = lj;
@@ -62,15 +63,22 @@ __device__ __forceinline__ void dev_hsolve(const DevModel& m, Work& w, const flo
     acc[reg] = v;
   }
   if (use_rows) {
+    float Sc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Sc[i] = w.S[col][i];
     for (int c = 0; c < w.ncon; c++) {
       const int nr = w.c_nrow[c], r0 = w.c_row0[c];
-      const float* J = &w.Jc[(c * NBASIS) * LD];
-      const float jn = J[col];
+      const float sg = (float)((w.c_mpos[c] >> col) & 1u) - (float)((w.c_mneg[c] >> col) & 1u);
+      const float* Wn = w.c_W[c][0];
       for (int p = 0; 2 * p < nr; p++) {       // edges 2p (low half of the wave) and 2p+1 (high half)
         const float cu0 = w.r_curv[r0 + 2 * p], cu1 = (2 * p + 1 < nr) ? w.r_curv[r0 + 2 * p + 1] : 0.f;
         if (cu0 == 0.f && cu1 == 0.f) continue;
-        float v = jn;
-        if (nr > 1) v += (hi ? -1.f : 1.f) * w.c_mu[c][p] * J[(1 + p) * LD + col];
+        const float* Wt = w.c_W[c][1 + p];
+        const float sm = (nr > 1) ? (hi ? -w.c_mu[c][p] : w.c_mu[c][p]) : 0.f;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) v += Sc[i] * (Wn[i] + sm * Wt[i]);
+        v *= sg;
         const float cu = hi ? cu1 : cu0;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cu * v, v, acc, 0, 0, 0);
       }
@@ -90,7 +98,7 @@ __device__ __forceinline__ void dev_hsolve(const DevModel& m, Work& w, const flo
   y *= dinv;
   PT(17);
   __syncthreads();
-  float* T = w.H;
+  float* T = w.sc.T;
   if (lane < 32) {
 #pragma unroll
     for (int k = 0; k < 32; k++) T[lane * LD + k] = lcol[k];     // row `lane` of L
@@ -126,14 +134,32 @@ HD float dev_impedance(const float* s_in, float pos, float margin) {
   return s0 + y * (s1 - s0);
 }
 
-// ---- u[t] = Jc[t,:] . x for every stored contact-frame row t
-__device__ void dev_basis_dot(Work& w, const float* x) {
+// ---- u[c][k] = (contact-frame Jacobian row k of contact c) . x, Jacobian-free:
+// body spatial velocities V_b = sum_{d on the path of b} S[d] x[d], then W[c][k] . (V_b2 - V_b1)
+__device__ void dev_basis_dot(const DevModel& m, const LaneK& lk, Work& w, const float* x) {
+  const int tid = threadIdx.x;
+  if (tid < m.nbody) {
+    float V[6] = {0, 0, 0, 0, 0, 0};
+    unsigned mk = lk.b_mask;
+    while (mk) {
+      const int d = __ffs(mk) - 1;
+      mk &= mk - 1;
+      const float xd = x[d];
+#pragma unroll
+      for (int i = 0; i < 6; i++) V[i] += w.S[d][i] * xd;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) w.bV[tid][i] = V[i];
+  }
+  __syncthreads();
   const int nb = w.ncon * NBASIS;
-  for (int t = threadIdx.x; t < nb; t += NT) {
+  for (int t = tid; t < nb; t += NT) {
+    const int c = t / NBASIS;
+    const int b1 = w.c_b1[c], b2 = w.c_b2[c];
+    const float* W = w.c_W[c][t % NBASIS];
     float s = 0.f;
-    const float* row = &w.Jc[t * LD];
-#pragma unroll 8
-    for (int d = 0; d < NV; d++) s += row[d] * x[d];
+#pragma unroll
+    for (int i = 0; i < 6; i++) s += W[i] * (w.bV[b2][i] - w.bV[b1][i]);
     w.u[t] = s;
   }
   __syncthreads();
@@ -151,9 +177,10 @@ HD float dev_row_times(const DevModel& m, const Work& w, int r, const float* x) 
 }
 
 // per-row cost pieces: returns cost, sets force = -ds/djar and curvature
-HD float dev_row_cost(const DevModel& m, const Work& w, int r, float jar, float& force, float& curv) {
+// (rows r < nv are always evaluated by lane r, so the friction-loss constants come from the lane's registers)
+HD float dev_row_cost(const DevModel& m, const LaneK& lk, const Work& w, int r, float jar, float& force, float& curv) {
   if (r < m.nv) {
-    const float f = m.dof_frictionloss[r], R = m.dof_flR[r], D = 1.f / R;
+    const float f = lk.d_floss, R = lk.d_flR, D = 1.f / R;
     if (jar <= -R * f) { force = f; curv = 0.f; return -f * (0.5f * R * f + jar); }
     if (jar >= R * f) { force = -f; curv = 0.f; return -f * (0.5f * R * f - jar); }
     force = -D * jar; curv = D; return 0.5f * D * jar * jar;
@@ -164,28 +191,28 @@ HD float dev_row_cost(const DevModel& m, const Work& w, int r, float jar, float&
 }
 
 // ---- constraint rows for the current kinematics / contacts
-__device__ void dev_make_constraint(const DevModel& m, Work& w, const float* qpos, const float* qvel) {
+__device__ void dev_make_constraint(const DevModel& m, const LaneK& lk, Work& w, const float* qpos, const float* qvel) {
   const int tid = threadIdx.x;
   // joint limits (one side per joint can be active: every range is wider than twice the margin)
   {
     bool act = false; float dist = 0.f, sgn = 0.f;
-    if (tid < m.njnt && m.jnt_limited[tid] && m.jnt_type[tid] != HOIC_JNT_FREE) {
-      const float q = qpos[m.jnt_qposadr[tid]], dl = q - m.jnt_range[tid][0], du = m.jnt_range[tid][1] - q;
-      if (dl < m.jnt_margin[tid]) { act = true; dist = dl; sgn = 1.f; }
-      else if (du < m.jnt_margin[tid]) { act = true; dist = du; sgn = -1.f; }
+    if (lk.j_limited && lk.j_type != HOIC_JNT_FREE) {
+      const float q = qpos[lk.j_qadr], dl = q - lk.j_lo, du = lk.j_hi - q;
+      if (dl < lk.j_margin) { act = true; dist = dl; sgn = 1.f; }
+      else if (du < lk.j_margin) { act = true; dist = du; sgn = -1.f; }
     }
     const unsigned long long mask = __ballot(act);
     const int idx = __popcll(mask & ((1ull << tid) - 1ull));
     if (tid == 0) w.nlim = min(__popcll(mask), MAXLIM);
     if (act && idx < MAXLIM) {
-      const int d = m.jnt_dofadr[tid];
-      const float imp = dev_impedance(m.jnt_solimp[tid], dist, m.jnt_margin[tid]);
-      const float R = fmaxf(MINVALF, (1.f - imp) * m.jnt_diag[tid] / imp);
+      const int d = lk.j_dadr;
+      const float imp = dev_impedance(lk.j_solimp, dist, lk.j_margin);
+      const float R = fmaxf(MINVALF, (1.f - imp) * lk.j_diag / imp);
       w.lim_dof[idx] = d; w.lim_sign[idx] = sgn; w.lim_D[idx] = 1.f / R;
-      w.r_aref[m.nv + idx] = -m.jnt_B[tid] * (sgn * qvel[d]) - m.jnt_K[tid] * imp * (dist - m.jnt_margin[tid]);
+      w.r_aref[m.nv + idx] = -lk.j_B * (sgn * qvel[d]) - lk.j_K * imp * (dist - lk.j_margin);
     }
   }
-  if (tid < m.nv) w.r_aref[tid] = -m.dof_flB[tid] * qvel[tid];
+  if (tid < m.nv) w.r_aref[tid] = -lk.d_flB * qvel[tid];
   __syncthreads();
   // per-contact parameters and row layout
   {
@@ -202,43 +229,34 @@ __device__ void dev_make_constraint(const DevModel& m, Work& w, const float* qpo
       w.c_aref0[c] = -m.pair_K[p] * imp * (w.c_dist[c] - incl);
       for (int k = 0; k < 3; k++) w.c_mu[c][k] = m.pair_mu[p][k];
       w.c_nrow[c] = nrow;
+      w.c_b1[c] = m.pair_b1[p]; w.c_b2[c] = m.pair_b2[p];
     }
-    int incl_sum = nrow;
-#pragma unroll
-    for (int o = 1; o < NT; o <<= 1) { int v = __shfl_up(incl_sum, o); if (tid >= o) incl_sum += v; }
+    const int incl_sum = wave_incl_scan(nrow);
     const int row0 = m.nv + w.nlim + incl_sum - nrow;
     if (c < w.ncon) {
       w.c_row0[c] = row0;
       for (int e = 0; e < nrow; e++) { w.r_con[row0 + e] = (unsigned char)c; w.r_edge[row0 + e] = (unsigned char)e; }
     }
-    const int total = __shfl(incl_sum, NT - 1);
+    const int total = __builtin_amdgcn_readlane(incl_sum, NT - 1);
     if (tid == 0) w.nrow = m.nv + w.nlim + total;
   }
   __syncthreads();
-  // contact-frame Jacobian rows: lane = dof, loop over contacts
-  for (int c = 0; c < w.ncon; c++) {
-    if (tid < NV) {
-      const int p = w.c_pair[c];
-      const int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
-      float jn = 0.f, jt1 = 0.f, jt2 = 0.f, js = 0.f;
-      if (tid < m.nv) {
-        const float sg = (float)((m.body_dofmask[b2] >> tid) & 1u) - (float)((m.body_dofmask[b1] >> tid) & 1u);
-        if (sg != 0.f) {
-          float col[3];
-          cross3(w.S[tid], w.c_pos[c], col);
-          for (int k = 0; k < 3; k++) col[k] += w.S[tid][3 + k];
-          const float* f = w.c_frame[c];
-          jn = sg * dot3(f, col); jt1 = sg * dot3(f + 3, col); jt2 = sg * dot3(f + 6, col);
-          js = sg * dot3(f, w.S[tid]);
-        }
-      }
-      float* J = &w.Jc[(c * NBASIS) * LD];
-      J[tid] = jn; J[LD + tid] = jt1; J[2 * LD + tid] = jt2; J[3 * LD + tid] = js;
+  // wrench basis of every contact (lane = contact)
+  if (tid < w.ncon) {
+    const int c = tid, b1 = w.c_b1[c], b2 = w.c_b2[c];
+    const unsigned m1 = w.k_bmask[b1], m2 = w.k_bmask[b2];
+    w.c_mpos[c] = m2 & ~m1; w.c_mneg[c] = m1 & ~m2;
+    const float* f = w.c_frame[c];
+    for (int k = 0; k < 3; k++) {
+      float pxf[3];
+      cross3(w.c_pos[c], f + 3 * k, pxf);
+      for (int i = 0; i < 3; i++) { w.c_W[c][k][i] = pxf[i]; w.c_W[c][k][3 + i] = f[3 * k + i]; }
     }
+    for (int i = 0; i < 3; i++) { w.c_W[c][3][i] = f[i]; w.c_W[c][3][3 + i] = 0.f; }
   }
   __syncthreads();
   // reference accelerations of the contact rows
-  dev_basis_dot(w, qvel);
+  dev_basis_dot(m, lk, w, qvel);
   for (int r = m.nv + w.nlim + tid; r < w.nrow; r += NT) {
     const int c = w.r_con[r];
     w.r_aref[r] = -w.c_B[c] * dev_row_times(m, w, r, qvel) + w.c_aref0[c];
@@ -256,56 +274,64 @@ HD float dev_Mrow(const Work& w, int i, const float* x) {
 }
 
 // jar, force, curvature of every row at acceleration x; returns the constraint cost (wave-reduced)
-__device__ float dev_eval_rows(const DevModel& m, Work& w, const float* x) {
-  dev_basis_dot(w, x);
+__device__ float dev_eval_rows(const DevModel& m, const LaneK& lk, Work& w, const float* x) {
+  dev_basis_dot(m, lk, w, x);
   float cost = 0.f;
   for (int r = threadIdx.x; r < w.nrow; r += NT) {
     const float jar = dev_row_times(m, w, r, x) - w.r_aref[r];
     float f, cv;
-    cost += dev_row_cost(m, w, r, jar, f, cv);
+    cost += dev_row_cost(m, lk, w, r, jar, f, cv);
     w.r_jar[r] = jar; w.r_force[r] = f; w.r_curv[r] = cv;
   }
   __syncthreads();
   return wave_sum(cost);
 }
 
-// out[i] = (J^T force)[i] from r_force (uses u as scratch for the per-contact frame forces)
+// out[i] = (J^T force)[i] from r_force: per-contact wrench G_c = sum_k g_k W[c][k], then S[i] . sum_c sg(i,c) G_c
 __device__ void dev_jt_force(const DevModel& m, Work& w, float* out) {
   const int tid = threadIdx.x;
-  for (int t = tid; t < w.ncon * NBASIS; t += NT) {
-    const int c = t / NBASIS, k = t % NBASIS, r0 = w.c_row0[c], nr = w.c_nrow[c];
-    float g = 0.f;
-    if (k == 0) { for (int e = 0; e < nr; e++) g += w.r_force[r0 + e]; }
-    else if (nr > 1 && 2 * k - 1 < nr) g = w.c_mu[c][k - 1] * (w.r_force[r0 + 2 * (k - 1)] - w.r_force[r0 + 2 * (k - 1) + 1]);
-    w.u[t] = g;
+  if (tid < w.ncon) {
+    const int c = tid, r0 = w.c_row0[c], nr = w.c_nrow[c];
+    float g[NBASIS] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < nr; e++) g[0] += w.r_force[r0 + e];
+    if (nr > 1) for (int k = 1; 2 * k - 1 < nr; k++) g[k] = w.c_mu[c][k - 1] * (w.r_force[r0 + 2 * (k - 1)] - w.r_force[r0 + 2 * (k - 1) + 1]);
+    for (int i = 0; i < 6; i++) {
+      float s = 0.f;
+      for (int k = 0; k < NBASIS; k++) s += g[k] * w.c_W[c][k][i];
+      w.c_G[c][i] = s;
+    }
   }
   __syncthreads();
   if (tid < m.nv) {
     float s = w.r_force[tid];
     for (int l = 0; l < w.nlim; l++) if (w.lim_dof[l] == tid) s += w.lim_sign[l] * w.r_force[m.nv + l];
-    const int nb = w.ncon * NBASIS;
-    for (int t = 0; t < nb; t++) s += w.Jc[t * LD + tid] * w.u[t];
+    float G[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < w.ncon; c++) {
+      const float sg = (float)((w.c_mpos[c] >> tid) & 1u) - (float)((w.c_mneg[c] >> tid) & 1u);
+      if (sg != 0.f) for (int i = 0; i < 6; i++) G[i] += sg * w.c_G[c][i];
+    }
+    for (int i = 0; i < 6; i++) s += w.S[tid][i] * G[i];
     out[tid] = s;
   }
   __syncthreads();
 }
 
 // ---- Newton with exact line search.  In: M, fsmooth, asmooth, warm, rows.  Out: qacc, fcon.
-__device__ void dev_solve(const DevModel& m, Work& w, int maxit) {
+__device__ void dev_solve(const DevModel& m, const LaneK& lk, Work& w, int maxit) {
   const int tid = threadIdx.x;
   const float scale = 1.f / (m.meaninertia * (float)max(m.nv, 1));
   // warm start choice: cost(warm) vs cost(asmooth)
   float gw = 0.f;
   if (tid < m.nv) { const float Ma = dev_Mrow(w, tid, w.warm); gw = 0.5f * (Ma - w.fsmooth[tid]) * (w.warm[tid] - w.asmooth[tid]); }
   gw = wave_sum(gw);
-  const float cw = gw + dev_eval_rows(m, w, w.warm);
-  const float cs = dev_eval_rows(m, w, w.asmooth);
+  const float cw = gw + dev_eval_rows(m, lk, w, w.warm);
+  const float cs = dev_eval_rows(m, lk, w, w.asmooth);
   if (tid < NV) w.qacc[tid] = (tid < m.nv) ? ((cw < cs) ? w.warm[tid] : w.asmooth[tid]) : 0.f;
   __syncthreads();
   int it = 0;
   for (; it < maxit; it++) {
     if (tid < m.nv) w.Ma[tid] = dev_Mrow(w, tid, w.qacc);
-    dev_eval_rows(m, w, w.qacc);
+    dev_eval_rows(m, lk, w, w.qacc);
     dev_jt_force(m, w, w.tv);
     float g2 = 0.f;
     if (tid < NV) {
@@ -333,7 +359,7 @@ __device__ void dev_solve(const DevModel& m, Work& w, int maxit) {
       gq = (w.Ma[tid] - w.fsmooth[tid]) * w.search[tid]; hh = w.search[tid] * Ms; g0 = w.grad[tid] * w.search[tid];
     }
     gq = wave_sum(gq); hh = wave_sum(hh); g0 = wave_sum(g0);
-    dev_basis_dot(w, w.search);
+    dev_basis_dot(m, lk, w, w.search);
     float jar[NROW / NT], jv[NROW / NT];
 #pragma unroll
     for (int k = 0; k < NROW / NT; k++) {
@@ -349,13 +375,13 @@ __device__ void dev_solve(const DevModel& m, Work& w, int maxit) {
         const int r = tid + k * NT;
         if (r < w.nrow) {
           float f, cv;
-          dev_row_cost(m, w, r, jar[k] + a * jv[k], f, cv);
+          dev_row_cost(m, lk, w, r, jar[k] + a * jv[k], f, cv);
           dphi -= f * jv[k]; ddphi += cv * jv[k] * jv[k];
         }
       }
       dphi = wave_sum(dphi) + gq + a * hh; ddphi = wave_sum(ddphi) + hh;
       alpha = a;
-      if (fabsf(dphi) < 1e-5f * fabsf(g0) + 1e-12f) break;
+      if (fabsf(dphi) < 1e-4f * fabsf(g0) + 1e-12f) break;
       if (dphi < 0.f) lo = a; else hi = a;
       float an = a - dphi / ddphi;
       if (hi >= 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
@@ -369,7 +395,7 @@ __device__ void dev_solve(const DevModel& m, Work& w, int maxit) {
     if (st < 1e-7f) { it++; break; }
   }
   // forces at the final acceleration
-  dev_eval_rows(m, w, w.qacc);
+  dev_eval_rows(m, lk, w, w.qacc);
   dev_jt_force(m, w, w.fcon);
   if (tid == 0) w.solver_iter = it;
   __syncthreads();

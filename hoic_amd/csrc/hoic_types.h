@@ -47,7 +47,7 @@ struct DevModel {
   int geom_type[NG], geom_bodyid[NG], geom_meshid[NG];
   float geom_size[NG][3], geom_pos[NG][3], geom_quat[NG][4], geom_rbound[NG];
   // static collision pair list with mixed parameters
-  int pair_geom1[NPAIR], pair_geom2[NPAIR], pair_condim[NPAIR];
+  int pair_geom1[NPAIR], pair_geom2[NPAIR], pair_condim[NPAIR], pair_b1[NPAIR], pair_b2[NPAIR];
   float pair_mu[NPAIR][3], pair_K[NPAIR], pair_B[NPAIR], pair_solimp[NPAIR][5], pair_margin[NPAIR], pair_gap[NPAIR];
   float pair_Rscale[NPAIR];  // R = max(MINVAL,(1-imp)/imp) * Rscale  (pyramidal: 2 mu^2 tran (1+mu^2); condim 1: tran)
   // mass-matrix sparsity: entries (i, j) with j an ancestor-or-self dof of i
@@ -86,28 +86,58 @@ struct DevState {
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
 };
 
+// lane-resident model constants: loaded from DevModel ONCE per launch, so the 15 fused substeps never chase
+// dependent global loads for them (lane = body / geom(lane-32) / dof / joint / collision pair)
+struct LaneK {
+  // lane = body
+  int b_parent, b_depth, b_jntadr, b_jntnum, b_dofadr, b_dofnum, b_subtree; unsigned b_mask;
+  float b_pos[3], b_quat[4], b_ipos[3], b_iquat[4], b_mass, b_inertia[3];
+  // lane - 32 = geom
+  int g_body; float g_pos[3], g_quat[4];
+  // lane = dof
+  int d_body, d_jnt, d_jtype, d_k, d_act; float d_arm, d_damp, d_floss, d_flR, d_flB;
+  // lane = joint
+  int j_type, j_qadr, j_dadr, j_limited; float j_lo, j_hi, j_margin, j_K, j_B, j_diag, j_solimp[5];
+  // lane = collision pair (pass 0: pairs 0..63, pass 1: pairs 64..127)
+  int p_g1[2], p_g2[2], p_t1[2], p_t2[2]; float p_s1[2][3], p_s2[2][3], p_bound[2], p_margin[2];
+  // mass-matrix entries handled by this lane
+  int m_i[4], m_j[4]; float m_arm[4];
+};
+
 // per-env LDS workspace
 struct Work {
+  // joint-indexed constants read by the body lanes during kinematics
+  float k_jaxis[NJ][3], k_jpos[NJ][3], k_jq0[NJ]; unsigned char k_jtype[NJ], k_jqadr[NJ];
+  unsigned k_bmask[NB];
   float qpos[NQP], qvel[NV], qacc[NV], warm[NV], qlag[NQP], vlag[NV], action[NV];
   float ctrl[NV], applied[NV], bias[NV], passive[NV], fsmooth[NV], asmooth[NV], fcon[NV];
   float grad[NV], search[NV], Ma[NV], Ms[NV], tv[NV], tv2[NV];
-  float xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3], I10[NB][10], Ic[NB][10];
-  float cvel[NB][6], cacc[NB][6], cfrc[NB][6];
+  float xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
+  // scratch shared by phases that never overlap: CRBA/RNE temporaries of the forward pass, and the 32x33
+  // transpose buffer of the matrix-core solves
+  union {
+    struct { float I10[NB][10], Ic[NB][10], cvel[NB][6], cacc[NB][6], cfrc[NB][6], fS[NV][6]; } dyn;
+    float T[NV * LD];
+  } sc;
   float xanchor[NJ][3], xaxis[NJ][3];
-  float S[NV][6], fS[NV][6];
+  float S[NV][6];
   float gxpos[NG][3], gxmat[NG][9], old_gxpos[NG][3], old_gxmat[NG][9];
   float old_objvel[6];
-  float M[NV * LD], H[NV * LD];
+  float M[NV * LD];
   // contacts of the current forward pass
   int ncon, nlim, nrow, pad0;
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON], c_mu[MAXCON][3], c_D[MAXCON], c_aref0[MAXCON], c_B[MAXCON];
-  int c_pair[MAXCON], c_nrow[MAXCON], c_row0[MAXCON];
-  float Jc[MAXCON * NBASIS * LD];
+  int c_pair[MAXCON], c_nrow[MAXCON], c_row0[MAXCON], c_b1[MAXCON], c_b2[MAXCON];
+  // Jacobian-free contacts: row (c,k) of the contact Jacobian is  sg(dof,c) * S[dof] . c_W[c][k]  with the
+  // wrench basis c_W[c][k] = [p x f_k ; f_k] (k = n,t1,t2) and [f_n ; 0] (spin) about the world origin
+  float c_W[MAXCON][NBASIS][6], c_G[MAXCON][6];
+  unsigned c_mpos[MAXCON], c_mneg[MAXCON];   // dofs moving body2 only (+1) / body1 only (-1)
   float u[MAXCON * NBASIS];
+  float bV[NB][6];                           // body spatial velocities for J.x products
   // limit rows
   int lim_dof[MAXLIM]; float lim_sign[MAXLIM], lim_D[MAXLIM];
   // all constraint rows: [0,nv) friction loss, [nv, nv+nlim) limits, then contact rows
-  float r_aref[NROW], r_jar[NROW], r_jv[NROW], r_force[NROW], r_curv[NROW];
+  float r_aref[NROW], r_jar[NROW], r_force[NROW], r_curv[NROW];
   unsigned char r_con[NROW], r_edge[NROW];
   // contact bookkeeping over the env step (record_contact / classify_contact)
   float rec_sum[NHG][12]; int rec_cnt[NHG];

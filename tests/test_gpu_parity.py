@@ -4,7 +4,7 @@ fixtures, plus size-independent properties at the full 4096-env configuration.
 Tolerances (float32 kernel vs float64 oracle, stated per quantity):
   kinematics / mass matrix / bias  : 2e-6 relative   (pure forward arithmetic)
   unconstrained / constrained qacc : 2e-3 relative   (32x32 Cholesky + Newton in float32)
-  state after one substep          : 1e-5 relative
+  state after one substep          : 3e-5 relative
   obs / reward after k env steps   : 2e-4 absolute over the first steps of an episode (contact dynamics amplify
                                      rounding; long open-loop trajectories are compared statistically instead)
 """
@@ -91,7 +91,7 @@ def test_forward_dynamics_parity(box_blob, box_model, oracle_lib, setup):
         worst["state"] = max(worst["state"], _rel(out["qpos_out"][i], e.get("qpos")[:33]), _rel(out["qvel_out"][i], e.get("qvel")))
     assert with_contacts > N // 3
     assert worst["kin"] < 2e-6 and worst["M"] < 2e-6 and worst["bias"] < 2e-6, worst
-    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < 1e-5, worst
+    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < 3e-5, worst
 
 
 def test_env_step_parity_short_horizon(box_blob, oracle_lib, setup):

@@ -20,7 +20,7 @@ seq = torch.randint(0, 16, (N,), generator=g, dtype=torch.int32); start = torch.
 sim.reset(seq, start)
 sim.enable_timing(True)
 names = ['other', 'pd_torque', 'applied+record', 'kinematics', 'mass_matrix', 'bias', 'collision', 'constraint', 'M^-1 solve',
-         'newton', 'euler', 'avg+classify', 'rfc_qp', 'diff+reward', 'obs+store', 'hs:assemble', 'hs:factor', 'hs:forward', 'hs:transpose+back', 'hs:store', 'pre-hsolve (newton pre-work etc.)']
+         'newton', 'euler', 'avg+classify', 'rfc_qp', 'diff+reward', 'obs+store', 'hs:assemble', 'hs:factor', 'hs:forward', 'hs:transpose+back', 'hs:store', 'pre-hsolve (newton pre-work etc.)', 'kin:levels', 'kin:inertia']
 tot = np.zeros(24); ms = []
 for t in range(8):
     a = torch.randn(N, 32, generator=g) * 0.1
