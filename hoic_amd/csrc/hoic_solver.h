@@ -33,17 +33,26 @@ template <int J> HD float hs_row_bcast(const f32x16& acc) {
   return __uint_as_float(half ? r.y : r.x);
 }
 
+HD float hs_rcp(float d) {
+  float inv = __builtin_amdgcn_rcpf(d);
+  return inv * (2.f - d * inv);                    // one Newton step: full f32 accuracy without the IEEE divide
+}
+// two pivots per MFMA (K = 2): pivot J on the low half of the wave, pivot J+1 on the high half; row J+1 is
+// brought up to date on the VALU while nothing else is in flight, so the serial chain per pivot pair is one MFMA.
 template <int J> struct HsFactor {
   static HD void run(f32x16& acc, float (&lcol)[32], float& dinv, int col, int hi) {
-    const float u = hs_row_bcast<J>(acc);           // u[lane&31] = A[J][lane&31] = L[.][J] * d_J
-    const float d = fmaxf(rl(u, J), 1e-30f);
-    float inv = __builtin_amdgcn_rcpf(d);
-    inv = inv * (2.f - d * inv);                   // one Newton step: full f32 accuracy without the IEEE divide
-    const float lj = u * inv;
-    if (col == J) dinv = inv;
-    lcol[J] = lj;
-    if (J < 31) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : -lj, hi ? 0.f : u, acc, 0, 0, 0);
-    HsFactor<J + 1>::run(acc, lcol, dinv, col, hi);
+    const float u0 = hs_row_bcast<J>(acc);           // u0[lane&31] = A[J][.] = L[.][J] * d_J
+    const float r1 = hs_row_bcast<J + 1>(acc);
+    const float inv0 = hs_rcp(fmaxf(rl(u0, J), 1e-30f));
+    const float l0 = u0 * inv0;
+    const float u1 = r1 - rl(l0, J + 1) * u0;        // row J+1 after eliminating pivot J
+    const float inv1 = hs_rcp(fmaxf(rl(u1, J + 1), 1e-30f));
+    const float l1 = u1 * inv1;
+    if (col == J) dinv = inv0;
+    if (col == J + 1) dinv = inv1;
+    lcol[J] = l0; lcol[J + 1] = l1;
+    if (J < 30) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? -l1 : -l0, hi ? u1 : u0, acc, 0, 0, 0);
+    HsFactor<J + 2>::run(acc, lcol, dinv, col, hi);
   }
 };
 template <> struct HsFactor<32> { static HD void run(f32x16&, float (&)[32], float&, int, int) {} };
@@ -320,18 +329,22 @@ __device__ void dev_jt_force(const DevModel& m, Work& w, float* out) {
 __device__ void dev_solve(const DevModel& m, const LaneK& lk, Work& w, int maxit) {
   const int tid = threadIdx.x;
   const float scale = 1.f / (m.meaninertia * (float)max(m.nv, 1));
-  // warm start choice: cost(warm) vs cost(asmooth)
+  // warm start choice: cost(warm) vs cost(asmooth); the row state of the LAST evaluation (warm) is reused by
+  // the first iteration when warm wins (the usual case)
   float gw = 0.f;
   if (tid < m.nv) { const float Ma = dev_Mrow(w, tid, w.warm); gw = 0.5f * (Ma - w.fsmooth[tid]) * (w.warm[tid] - w.asmooth[tid]); }
   gw = wave_sum(gw);
-  const float cw = gw + dev_eval_rows(m, lk, w, w.warm);
   const float cs = dev_eval_rows(m, lk, w, w.asmooth);
-  if (tid < NV) w.qacc[tid] = (tid < m.nv) ? ((cw < cs) ? w.warm[tid] : w.asmooth[tid]) : 0.f;
+  const float cw = gw + dev_eval_rows(m, lk, w, w.warm);
+  bool have_eval = cw < cs;
+  if (tid < NV) w.qacc[tid] = (tid < m.nv) ? (have_eval ? w.warm[tid] : w.asmooth[tid]) : 0.f;
   __syncthreads();
   int it = 0;
+  bool fresh = false;     // w.tv holds J'f of the current qacc
   for (; it < maxit; it++) {
     if (tid < m.nv) w.Ma[tid] = dev_Mrow(w, tid, w.qacc);
-    dev_eval_rows(m, lk, w, w.qacc);
+    if (!have_eval) dev_eval_rows(m, lk, w, w.qacc);
+    have_eval = false;
     dev_jt_force(m, w, w.tv);
     float g2 = 0.f;
     if (tid < NV) {
@@ -340,7 +353,7 @@ __device__ void dev_solve(const DevModel& m, const LaneK& lk, Work& w, int maxit
     }
     g2 = wave_sum(g2);
     __syncthreads();
-    if (sqrtf(g2) * scale < 1e-6f) break;
+    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; break; }
     if (tid < NV) {   // diagonal curvature of the friction-loss and limit rows
       float dg = 0.f;
       if (tid < m.nv) {
@@ -395,8 +408,8 @@ __device__ void dev_solve(const DevModel& m, const LaneK& lk, Work& w, int maxit
     if (st < 1e-7f) { it++; break; }
   }
   // forces at the final acceleration
-  dev_eval_rows(m, lk, w, w.qacc);
-  dev_jt_force(m, w, w.fcon);
+  if (fresh) { if (tid < NV) w.fcon[tid] = w.tv[tid]; }
+  else { dev_eval_rows(m, lk, w, w.qacc); dev_jt_force(m, w, w.fcon); }
   if (tid == 0) w.solver_iter = it;
   __syncthreads();
 }
