@@ -464,11 +464,16 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     const int t1 = m.geom_type[m.pair_geom1[p]], t2 = m.geom_type[m.pair_geom2[p]];
     if (t1 == HOIC_GEOM_MESH || t2 == HOIC_GEOM_MESH) { /* convex-mesh pairs: not in this round's kernel */ }
   }
-  std::vector<int> mva, mvn; std::vector<double> mv;
-  if (b.i32("mesh_vertadr", mva) && b.i32("mesh_vertnum", mvn) && b.f64("mesh_vert", mv)) {
-    for (size_t i = 0; i < mva.size() && i < HOIC_MAX_MESH; i++) { m.mesh_vertadr[i] = mva[i]; m.mesh_vertnum[i] = mvn[i]; }
-    for (size_t i = 0; i < mv.size() && i < (size_t)MAXMESHV * 3; i++) m.mesh_vert[i / 3][i % 3] = (float)mv[i];
-  }
+  std::vector<int> mva, mvn, mpa, mpn; std::vector<double> mv, mpl;
+  if (b.i32("mesh_vertadr", mva) && b.i32("mesh_vertnum", mvn) && b.f64("mesh_vert", mv) &&
+      b.i32("mesh_planeadr", mpa) && b.i32("mesh_planenum", mpn) && b.f64("mesh_plane", mpl)) {
+    if (mva.size() > HOIC_MAX_MESH || mv.size() > (size_t)MAXMESHV * 3 || mpl.size() > (size_t)MAXMESHP * 4) {
+      set_err("model blob: mesh tables exceed compiled capacities"); return false;
+    }
+    for (size_t i = 0; i < mva.size(); i++) { m.mesh_vertadr[i] = mva[i]; m.mesh_vertnum[i] = mvn[i]; m.mesh_planeadr[i] = mpa[i]; m.mesh_planenum[i] = mpn[i]; }
+    for (size_t i = 0; i < mv.size(); i++) m.mesh_vert[i / 3][i % 3] = (float)mv[i];
+    for (size_t i = 0; i < mpl.size(); i++) m.mesh_plane[i / 4][i % 4] = (float)mpl[i];
+  } else { set_err("model blob: mesh tables missing"); return false; }
   return true;
 }
 }  // namespace

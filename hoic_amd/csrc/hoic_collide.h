@@ -289,6 +289,147 @@ __device__ __noinline__ void col_box_box(const float* pa, const float* Ra, const
   o.n = ns;
 }
 
+// ---- convex mesh (hull vertices + face planes in the geom frame) vs plane / capsule / box.
+// Plain loops over the hull tables, one pair per lane; see oracle/ho_collide.c for the formulation.
+struct HullRef { const float (*v)[3]; int nv; const float (*pl)[4]; int np; };
+HD HullRef get_hull(const DevModel& m, int mesh) {
+  HullRef h;
+  h.v = &m.mesh_vert[m.mesh_vertadr[mesh]]; h.nv = m.mesh_vertnum[mesh];
+  h.pl = &m.mesh_plane[m.mesh_planeadr[mesh]]; h.np = m.mesh_planenum[mesh];
+  return h;
+}
+HD float hull_line_max(const HullRef& h, const float* a, const float* d, float t, int& face) {
+  const float x = a[0] + t * d[0], y = a[1] + t * d[1], z = a[2] + t * d[2];
+  float best = -1e30f; int bf = 0;
+  for (int f = 0; f < h.np; f++) {
+    const float v = h.pl[f][0] * x + h.pl[f][1] * y + h.pl[f][2] * z - h.pl[f][3];
+    if (v > best) { best = v; bf = f; }
+  }
+  face = bf;
+  return best;
+}
+HD void lc_keep_deepest(LaneContacts& o, float dist, const float* pos, const float* n) {
+  int slot = -1;
+  if (o.n < 4) slot = o.n++;
+  else {
+    int wst = 0;
+    for (int q = 1; q < 4; q++) if (o.dist[q] > o.dist[wst]) wst = q;
+    if (dist < o.dist[wst]) slot = wst;
+  }
+  if (slot >= 0) {
+    // slot is data dependent: write through selects so the arrays stay in registers
+    for (int q = 0; q < 4; q++)
+      if (q == slot) { o.dist[q] = dist; for (int i = 0; i < 3; i++) { o.pos[q][i] = pos[i]; o.nrm[q][i] = n[i]; } }
+  }
+}
+__device__ __noinline__ void col_plane_mesh(const DevModel& m, const float* pp, const float* pR, const float* mp,
+                                            const float* mR, int mesh, LaneContacts& o) {
+  const HullRef h = get_hull(m, mesh);
+  float n[3];
+  matcol(pR, 2, n);
+  float best[3] = {0.f, 0.f, 0.f}; int bi[3] = {-1, -1, -1};
+  for (int v = 0; v < h.nv; v++) {
+    float wv[3];
+    matvec(mR, h.v[v], wv);
+    const float dist = (wv[0] + mp[0] - pp[0]) * n[0] + (wv[1] + mp[1] - pp[1]) * n[1] + (wv[2] + mp[2] - pp[2]) * n[2];
+    if (dist >= 0.f) continue;
+    if (bi[0] < 0 || dist < best[0]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = best[0]; bi[1] = bi[0]; best[0] = dist; bi[0] = v; }
+    else if (bi[1] < 0 || dist < best[1]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = dist; bi[1] = v; }
+    else if (bi[2] < 0 || dist < best[2]) { best[2] = dist; bi[2] = v; }
+  }
+  for (int s = 0; s < 3; s++) {
+    if (bi[s] < 0) continue;
+    float wv[3], pos[3];
+    matvec(mR, h.v[bi[s]], wv);
+    for (int i = 0; i < 3; i++) pos[i] = wv[i] + mp[i] - 0.5f * best[s] * n[i];
+    lc_set(o, o.n, best[s], pos, n);
+    o.n++;
+  }
+}
+__device__ __noinline__ void col_capsule_mesh(const DevModel& m, const float* cp, const float* cR, const float* cs,
+                                              const float* mp, const float* mR, int mesh, LaneContacts& o) {
+  const HullRef h = get_hull(m, mesh);
+  float ax[3], rel[3], pc[3], al[3], a[3], d[3];
+  matcol(cR, 2, ax);
+  for (int i = 0; i < 3; i++) rel[i] = cp[i] - mp[i];
+  mattvec(mR, rel, pc); mattvec(mR, ax, al);
+  for (int i = 0; i < 3; i++) { a[i] = pc[i] - cs[1] * al[i]; d[i] = 2.f * cs[1] * al[i]; }
+  const float r = cs[0];
+  int f0, f1, fm;
+  const float v0 = hull_line_max(h, a, d, 0.f, f0), v1 = hull_line_max(h, a, d, 1.f, f1);
+  const float s0 = h.pl[f0][0] * d[0] + h.pl[f0][1] * d[1] + h.pl[f0][2] * d[2];
+  const float s1 = h.pl[f1][0] * d[0] + h.pl[f1][1] * d[1] + h.pl[f1][2] * d[2];
+  float ts, vs, nmin[3];
+  if (s0 >= 0.f) { ts = 0.f; vs = v0; for (int i = 0; i < 3; i++) nmin[i] = h.pl[f0][i]; }
+  else if (s1 <= 0.f) { ts = 1.f; vs = v1; for (int i = 0; i < 3; i++) nmin[i] = h.pl[f1][i]; }
+  else {
+    float tl = 0.f, vl = v0, sl = s0, tr = 1.f, vr = v1, sr = s1; int fl = f0, fr = f1;
+    ts = 0.f; vs = v0;
+    for (int it = 0; it < 8; it++) {
+      float t = ((vr - sr * tr) - (vl - sl * tl)) / (sl - sr);
+      t = fminf(fmaxf(t, tl), tr);
+      const float v = hull_line_max(h, a, d, t, fm);
+      const float lineval = vl + sl * (t - tl);
+      ts = t; vs = v;
+      if (v <= lineval + 1e-7f) break;
+      const float sm = h.pl[fm][0] * d[0] + h.pl[fm][1] * d[1] + h.pl[fm][2] * d[2];
+      if (sm < 0.f) { tl = t; vl = v; sl = sm; fl = fm; } else { tr = t; vr = v; sr = sm; fr = fm; }
+    }
+    const float lam = sr / (sr - sl);   // zero sub-gradient combination of the two tied faces
+    for (int i = 0; i < 3; i++) nmin[i] = lam * h.pl[fl][i] + (1.f - lam) * h.pl[fr][i];
+    normalize3(nmin);
+  }
+  float tc[3], vc[3], nc3[3][3]; int nc = 0;
+  if (v0 < r) { tc[nc] = 0.f; vc[nc] = v0; for (int i = 0; i < 3; i++) nc3[nc][i] = h.pl[f0][i]; nc++; }
+  if (v1 < r) { tc[nc] = 1.f; vc[nc] = v1; for (int i = 0; i < 3; i++) nc3[nc][i] = h.pl[f1][i]; nc++; }
+  if (nc < 2 && vs < r) {
+    bool dup = false;
+    for (int q = 0; q < nc; q++) if (fabsf(ts - tc[q]) < 1e-4f) dup = true;
+    if (!dup) { tc[nc] = ts; vc[nc] = vs; for (int i = 0; i < 3; i++) nc3[nc][i] = nmin[i]; nc++; }
+  }
+  for (int q = 0; q < nc && q < 2; q++) {
+    const float* pl = nc3[q];
+    float pos[3], nrm[3], pw[3], nw[3];
+    for (int i = 0; i < 3; i++) { const float c = a[i] + tc[q] * d[i]; nrm[i] = -pl[i]; pos[i] = c - pl[i] * 0.5f * (r + vc[q]); }
+    matvec(mR, pos, pw); matvec(mR, nrm, nw);
+    for (int i = 0; i < 3; i++) pw[i] += mp[i];
+    lc_set(o, o.n, vc[q] - r, pw, nw);
+    o.n++;
+  }
+}
+__device__ __noinline__ void col_box_mesh(const DevModel& m, const float* bp, const float* bR, const float* bh,
+                                          const float* mp, const float* mR, int mesh, LaneContacts& o) {
+  const HullRef h = get_hull(m, mesh);
+  for (int v = 0; v < h.nv; v++) {
+    float wv[3], rel[3], p[3];
+    matvec(mR, h.v[v], wv);
+    for (int i = 0; i < 3; i++) { wv[i] += mp[i]; rel[i] = wv[i] - bp[i]; }
+    mattvec(bR, rel, p);
+    float depth = 1e30f; int k = 0;
+    for (int i = 0; i < 3; i++) { const float dd = bh[i] - fabsf(p[i]); if (dd < depth) { depth = dd; k = i; } }
+    if (depth <= 0.f) continue;
+    float nl[3] = {0.f, 0.f, 0.f}, nw[3], pos[3];
+    const float sg = p[k] >= 0.f ? 1.f : -1.f;
+    nl[0] = k == 0 ? sg : 0.f; nl[1] = k == 1 ? sg : 0.f; nl[2] = k == 2 ? sg : 0.f;
+    matvec(bR, nl, nw);
+    for (int i = 0; i < 3; i++) pos[i] = wv[i] + nw[i] * 0.5f * depth;
+    lc_keep_deepest(o, -depth, pos, nw);
+  }
+  for (int c = 0; c < 8; c++) {
+    float loc[3] = {(c & 1 ? bh[0] : -bh[0]), (c & 2 ? bh[1] : -bh[1]), (c & 4 ? bh[2] : -bh[2])}, wc[3], rel[3], p[3];
+    matvec(bR, loc, wc);
+    for (int i = 0; i < 3; i++) { wc[i] += bp[i]; rel[i] = wc[i] - mp[i]; }
+    mattvec(mR, rel, p);
+    const float zero[3] = {0.f, 0.f, 0.f}; int f;
+    const float s = hull_line_max(h, p, zero, 0.f, f);
+    if (s >= 0.f) continue;
+    float nl[3] = {-h.pl[f][0], -h.pl[f][1], -h.pl[f][2]}, nw[3], pos[3];
+    matvec(mR, nl, nw);
+    for (int i = 0; i < 3; i++) pos[i] = wc[i] + nw[i] * 0.5f * s;
+    lc_keep_deepest(o, s, pos, nw);
+  }
+}
+
 // tangents from the normal (same rule as the oracle's ho_make_frame)
 HD void make_frame(float* f) {
   float* x = f; float* y = f + 3; float* z = f + 6;
@@ -327,6 +468,11 @@ __device__ void dev_collision(const DevModel& m, const LaneK& lk, Work& w, int* 
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_CAPSULE) col_capsule_capsule(p1, R1, s1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_BOX) col_capsule_box(p1, R1, s1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX) col_box_box(p1, R1, s1, p2, R2, s2, lc);
+        else if (t2 == HOIC_GEOM_MESH) {
+          if (t1 == HOIC_GEOM_CAPSULE) col_capsule_mesh(m, p1, R1, s1, p2, R2, lk.p_mesh[ps], lc);
+          else if (t1 == HOIC_GEOM_BOX) col_box_mesh(m, p1, R1, s1, p2, R2, lk.p_mesh[ps], lc);
+          else if (t1 == HOIC_GEOM_PLANE) col_plane_mesh(m, p1, R1, p2, R2, lk.p_mesh[ps], lc);
+        }
       }
       // margin filter
       int k2 = 0;

@@ -40,6 +40,7 @@ __device__ void dev_load_constants(const DevModel& m, Work& w, LaneK& lk) {
     const int g1 = m.pair_geom1[pp], g2 = m.pair_geom2[pp];
     lk.p_g1[ps] = g1; lk.p_g2[ps] = g2; lk.p_t1[ps] = p < m.npair ? m.geom_type[g1] : -1; lk.p_t2[ps] = m.geom_type[g2];
     for (int i = 0; i < 3; i++) { lk.p_s1[ps][i] = m.geom_size[g1][i]; lk.p_s2[ps][i] = m.geom_size[g2][i]; }
+    lk.p_mesh[ps] = m.geom_meshid[g2];
     lk.p_margin[ps] = m.pair_margin[pp];
     lk.p_bound[ps] = m.geom_rbound[g1] + m.geom_rbound[g2] + m.pair_margin[pp];
   }

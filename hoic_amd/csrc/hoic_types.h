@@ -24,6 +24,7 @@
 #define NHB HOIC_NHANDBODY
 #define NHG 19
 #define MAXMESHV 256
+#define MAXMESHP HOIC_MAX_MESHPLANE
 
 struct DevModel {
   int nbody, njnt, nq, nv, nu, ngeom, npair, nlevel, nM;
@@ -53,8 +54,9 @@ struct DevModel {
   // mass-matrix sparsity: entries (i, j) with j an ancestor-or-self dof of i
   unsigned char mi[256], mj[256];
   // convex meshes (hull vertices in the geom frame)
-  int mesh_vertadr[HOIC_MAX_MESH], mesh_vertnum[HOIC_MAX_MESH];
+  int mesh_vertadr[HOIC_MAX_MESH], mesh_vertnum[HOIC_MAX_MESH], mesh_planeadr[HOIC_MAX_MESH], mesh_planenum[HOIC_MAX_MESH];
   float mesh_vert[MAXMESHV][3];
+  float mesh_plane[MAXMESHP][4];   // hull faces n.x <= d in the geom frame
 };
 
 struct DevConfig {
@@ -99,7 +101,7 @@ struct LaneK {
   // lane = joint
   int j_type, j_qadr, j_dadr, j_limited; float j_lo, j_hi, j_margin, j_K, j_B, j_diag, j_solimp[5];
   // lane = collision pair (pass 0: pairs 0..63, pass 1: pairs 64..127)
-  int p_g1[2], p_g2[2], p_t1[2], p_t2[2]; float p_s1[2][3], p_s2[2][3], p_bound[2], p_margin[2];
+  int p_g1[2], p_g2[2], p_t1[2], p_t2[2], p_mesh[2]; float p_s1[2][3], p_s2[2][3], p_bound[2], p_margin[2];
   // mass-matrix entries handled by this lane
   int m_i[4], m_j[4]; float m_arm[4];
 };

@@ -412,7 +412,7 @@ def compile_model(hand_xml: str, obj_xml: str | None, max_mesh_verts: int = 64) 
         # MuJoCo re-expresses a mesh in its own inertial frame (centre of mass + principal
         # axes) and folds that offset into the geom pose [MJ-doc].
         pm, R = eig3_desc(inertia)
-        entry = {"vol": vol, "com": com, "R": R, "pm": pm, "hull": np.zeros((0, 3))}
+        entry = {"vol": vol, "com": com, "R": R, "pm": pm, "hull": np.zeros((0, 3)), "planes": np.zeros((0, 4))}
         if need_hull:
             from scipy.spatial import ConvexHull
             pts = np.unique(tris.reshape(-1, 3), axis=0)
@@ -420,7 +420,21 @@ def compile_model(hand_xml: str, obj_xml: str | None, max_mesh_verts: int = 64) 
             hv = pts[hull.vertices]
             if hv.shape[0] > max_mesh_verts:
                 hv = _decimate_hull(hv, max_mesh_verts)
-            entry["hull"] = (hv - com) @ R  # in mesh frame
+            hv = (hv - com) @ R  # in mesh frame
+            # the collision shape is the hull of the (possibly decimated) vertex set: keep its vertices AND its
+            # face planes n.x <= d (merged when coplanar), so narrow-phase queries are plain loops over both
+            h2 = ConvexHull(hv)
+            hv = hv[h2.vertices]
+            h2 = ConvexHull(hv)
+            eq = h2.equations.copy()                       # n.x + off <= 0 inside
+            pl = np.concatenate([eq[:, :3], -eq[:, 3:4]], 1)
+            pl = pl[np.lexsort(np.round(pl, 9).T[::-1])]
+            keep = [0]
+            for i in range(1, pl.shape[0]):
+                if np.abs(pl[i] - pl[keep[-1]]).max() > 1e-9:
+                    keep.append(i)
+            entry["hull"] = hv
+            entry["planes"] = pl[keep]
         mesh_index[key] = len(meshes)
         meshes.append(entry)
         return mesh_index[key]
@@ -586,6 +600,12 @@ def compile_model(hand_xml: str, obj_xml: str | None, max_mesh_verts: int = 64) 
     A["mesh_vertadr"] = np.array(vadr if vadr else [0], np.int32)
     A["mesh_vertnum"] = np.array(vnum if vnum else [0], np.int32)
     A["mesh_vert"] = np.concatenate(verts, 0) if verts and sum(vnum) else np.zeros((1, 3))
+    padr, pnum, planes = [], [], []
+    for me in meshes:
+        padr.append(sum(pnum)); pnum.append(me["planes"].shape[0]); planes.append(me["planes"])
+    A["mesh_planeadr"] = np.array(padr if padr else [0], np.int32)
+    A["mesh_planenum"] = np.array(pnum if pnum else [0], np.int32)
+    A["mesh_plane"] = np.concatenate(planes, 0) if planes and sum(pnum) else np.zeros((1, 4))
     A["nmesh"] = np.array([len(meshes)], np.int32)
     A["names_body"] = _enc_names([B.name for B in bodies]); A["names_joint"] = _enc_names(jnt_names)
     A["names_geom"] = _enc_names(g_names); A["names_actuator"] = _enc_names(act_names)

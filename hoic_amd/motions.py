@@ -156,7 +156,29 @@ def _slerp(q0, q1, t):
     return q / np.linalg.norm(q, axis=-1, keepdims=True)
 
 
-def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_half_height: float = 0.0165) -> dict:
+def object_rest_height(model: mjcf.CompiledModel, quat) -> float:
+    """Height of the object's body origin above a horizontal support when it rests with orientation `quat`
+    (lowest point of its collision geoms: box corners / hull vertices)."""
+    A = model.arrays
+    ob = model.scalar("obj_body")
+    pts = []
+    for g in range(model.scalar("obj_geom0"), model.scalar("obj_geom1") + 1):
+        if A["geom_bodyid"][g] != ob:
+            continue
+        if A["geom_type"][g] == mjcf.GEOM_BOX:
+            h = A["geom_size"][g]
+            loc = np.array([[sx * h[0], sy * h[1], sz * h[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+        elif A["geom_type"][g] == mjcf.GEOM_MESH:
+            me = A["geom_meshid"][g]
+            loc = A["mesh_vert"][A["mesh_vertadr"][me]:A["mesh_vertadr"][me] + A["mesh_vertnum"][me]]
+        else:
+            continue
+        pts.append(qrot(np.broadcast_to(A["geom_quat"][g], (loc.shape[0], 4)), loc) + A["geom_pos"][g])
+    pts = np.concatenate(pts, 0)
+    return float(-qrot(np.broadcast_to(np.asarray(quat, dtype=np.float64), (pts.shape[0], 4)), pts)[:, 2].min())
+
+
+def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_half_height: float | None = None) -> dict:
     rng = np.random.default_rng(seed)
     A = model.arrays
     nh = model.scalar("hand_nq")
@@ -180,6 +202,8 @@ def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_h
     palm_q = _euler_xyz_quat(hand[:, 3:6])
     off = np.array([0.0, 0.045, -0.06])
     rel_q = np.array([np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0])       # long axis of the object along palm x
+    if obj_half_height is None:
+        obj_half_height = object_rest_height(model, rel_q)
     grasp_p = hand[:, :3] + qrot(palm_q, np.broadcast_to(off, (T, 3)))
     grasp_q = qmul(palm_q, np.broadcast_to(rel_q, (T, 4)))
     rest_p = np.array([hand[0, 0] + rng.uniform(-0.03, 0.03), hand[0, 1] + 0.04 + rng.uniform(-0.02, 0.02), 0.5 + obj_half_height + 0.0005])

@@ -358,148 +358,139 @@ static int box_box(const double pa[3], const double Ra[9], const double ha[3], c
   return ns;
 }
 
-/* ---------------------------------------------------------------- convex mesh vs primitive: GJK distance with
- * the primitive shrunk to its core (point set / segment) and EPA-free penetration via core inflation.
- * capsule core = segment (radius r), box handled through its 8 corners as a polytope. */
-typedef struct { const double* pos; const double* R; int type; const double* size; const double (*verts)[3]; int nvert; } shape;
-static void support(const shape* s, const double dir[3], double out[3]) {
-  double dl[3], loc[3] = {0, 0, 0};
-  mtv(s->R, dir, dl);
-  if (s->type == HOIC_GEOM_MESH) {
-    double best = -1e300; int bi = 0;
-    for (int v = 0; v < s->nvert; v++) { double dd = ho_dot3(s->verts[v], dl); if (dd > best) { best = dd; bi = v; } }
-    memcpy(loc, s->verts[bi], sizeof(loc));
-  } else if (s->type == HOIC_GEOM_BOX) {
-    for (int i = 0; i < 3; i++) loc[i] = dl[i] >= 0 ? s->size[i] : -s->size[i];
-  } else if (s->type == HOIC_GEOM_CAPSULE) { /* core segment */
-    loc[2] = dl[2] >= 0 ? s->size[1] : -s->size[1];
-  }
-  mv(s->R, loc, out);
-  for (int i = 0; i < 3; i++) out[i] += s->pos[i];
+/* ---------------------------------------------------------------- convex mesh vs primitive.
+ * The collision shape of a mesh geom is its convex hull, stored as vertices AND face planes n.x <= d (mesh
+ * frame, hoic_amd/mjcf.py).  Queries are plain loops over those tables (no GJK/EPA iteration, no degenerate
+ * simplices; the same loops run one pair per lane on the GPU):
+ *   signed distance of a point  ~  max_f (n_f.x - d_f)   (exact inside the hull and in front of a face; a lower
+ *   bound next to edges/vertices, off by less than the facet size times the angle defect),
+ *   capsule: minimise that convex piecewise-linear function along the axis, end spheres + minimiser (<= 2 points),
+ *   box: hull vertices inside the box and box corners inside the hull (<= 4 deepest),
+ *   plane: deepest hull vertices (<= 3).
+ * MuJoCo uses libccd (MPR) with one point per pair here; this is a from-scratch substitute (PARITY UNPINNED). */
+typedef struct { const double (*v)[3]; int nv; const double (*pl)[4]; int np; } hull_t;
+static hull_t get_hull(const ho_model* m, int mesh) {
+  hull_t h = {(const double(*)[3])m->mesh_vert[m->mesh_vertadr[mesh]], m->mesh_vertnum[mesh],
+              (const double(*)[4])m->mesh_plane[m->mesh_planeadr[mesh]], m->mesh_planenum[mesh]};
+  return h;
 }
-/* closest point to the origin on a simplex (1..4 points), reduces the simplex; returns squared distance */
-static double closest_simplex(double W[4][3], double A[4][3], double Bp[4][3], int* n, double v[3]) {
-  /* brute force over sub-simplices with barycentric solve (small, robust enough for an oracle) */
-  int bestmask = 1; double bestd = 1e300, bestw[4] = {1, 0, 0, 0};
-  for (int mask = 1; mask < (1 << *n); mask++) {
-    int idx[4], k = 0;
-    for (int i = 0; i < *n; i++) if (mask & (1 << i)) idx[k++] = i;
-    double w[4] = {0, 0, 0, 0};
-    if (k == 1) w[0] = 1;
-    else {
-      /* minimise |sum w_i p_i|^2, sum w = 1: solve (k-1)x(k-1) normal equations on edges from p0 */
-      double E[3][3], G[3][3], rhs[3];
-      for (int a = 1; a < k; a++) for (int c = 0; c < 3; c++) E[a - 1][c] = W[idx[a]][c] - W[idx[0]][c];
-      for (int a = 0; a < k - 1; a++) { rhs[a] = -ho_dot3(E[a], W[idx[0]]); for (int b = 0; b < k - 1; b++) G[a][b] = ho_dot3(E[a], E[b]); }
-      double x[3] = {0, 0, 0};
-      int kk = k - 1, ok = 1;
-      /* gaussian elimination */
-      double M[3][4];
-      for (int a = 0; a < kk; a++) { for (int b = 0; b < kk; b++) M[a][b] = G[a][b]; M[a][kk] = rhs[a]; }
-      for (int a = 0; a < kk && ok; a++) {
-        int p = a; for (int b = a + 1; b < kk; b++) if (fabs(M[b][a]) > fabs(M[p][a])) p = b;
-        if (fabs(M[p][a]) < 1e-30) { ok = 0; break; }
-        for (int c = 0; c <= kk; c++) { double tt = M[a][c]; M[a][c] = M[p][c]; M[p][c] = tt; }
-        for (int b = a + 1; b < kk; b++) { double f = M[b][a] / M[a][a]; for (int c = a; c <= kk; c++) M[b][c] -= f * M[a][c]; }
-      }
-      if (!ok) continue;
-      for (int a = kk - 1; a >= 0; a--) { double s = M[a][kk]; for (int b = a + 1; b < kk; b++) s -= M[a][b] * x[b]; x[a] = s / M[a][a]; }
-      double s0 = 1; int neg = 0;
-      for (int a = 0; a < kk; a++) { w[a + 1] = x[a]; s0 -= x[a]; if (x[a] < -1e-14) neg = 1; }
-      w[0] = s0; if (s0 < -1e-14) neg = 1;
-      if (neg) continue;
+/* max over faces of alpha_f + t beta_f; returns the value and the arg-max face */
+static double hull_line_max(const hull_t* h, const double a[3], const double d[3], double t, int* face) {
+  double best = -1e300; int bf = 0;
+  for (int f = 0; f < h->np; f++) {
+    const double* p = h->pl[f];
+    double v = p[0] * (a[0] + t * d[0]) + p[1] * (a[1] + t * d[1]) + p[2] * (a[2] + t * d[2]) - p[3];
+    if (v > best) { best = v; bf = f; }
+  }
+  *face = bf;
+  return best;
+}
+static int capsule_mesh(const ho_model* m, const double cp[3], const double cR[9], const double cs[3],
+                        const double mp[3], const double mR[9], int mesh, ho_contact* out) {
+  hull_t h = get_hull(m, mesh);
+  double ax[3], rel[3], pc[3], al[3], a[3], d[3];
+  col(cR, 2, ax);
+  for (int i = 0; i < 3; i++) rel[i] = cp[i] - mp[i];
+  mtv(mR, rel, pc); mtv(mR, ax, al);
+  for (int i = 0; i < 3; i++) { a[i] = pc[i] - cs[1] * al[i]; d[i] = 2 * cs[1] * al[i]; }
+  const double r = cs[0];
+  /* minimise phi(t) = max_f (alpha_f + t beta_f) on [0,1]: bracket by the active faces at the ends, then
+     intersect the two bracketing lines until the intersection is on the envelope */
+  int f0, f1, fm;
+  double v0 = hull_line_max(&h, a, d, 0, &f0), v1 = hull_line_max(&h, a, d, 1, &f1);
+  double s0 = h.pl[f0][0] * d[0] + h.pl[f0][1] * d[1] + h.pl[f0][2] * d[2];
+  double s1 = h.pl[f1][0] * d[0] + h.pl[f1][1] * d[1] + h.pl[f1][2] * d[2];
+  double ts, vs; int fs;
+  double nmin[3];     /* outward hull normal used at the minimiser */
+  if (s0 >= 0) { ts = 0; vs = v0; fs = f0; for (int i = 0; i < 3; i++) nmin[i] = h.pl[f0][i]; }
+  else if (s1 <= 0) { ts = 1; vs = v1; fs = f1; for (int i = 0; i < 3; i++) nmin[i] = h.pl[f1][i]; }
+  else {
+    double tl = 0, vl = v0, sl = s0, tr = 1, vr = v1, sr = s1; int fl = f0, fr = f1;
+    ts = 0; vs = v0; fs = f0;
+    for (int it = 0; it < 16; it++) {
+      double t = ((vr - sr * tr) - (vl - sl * tl)) / (sl - sr);
+      t = fmin(fmax(t, tl), tr);
+      double v = hull_line_max(&h, a, d, t, &fm);
+      double lineval = vl + sl * (t - tl);
+      ts = t; vs = v; fs = fm;
+      if (v <= lineval + 1e-12) break;
+      double sm = h.pl[fm][0] * d[0] + h.pl[fm][1] * d[1] + h.pl[fm][2] * d[2];
+      if (sm < 0) { tl = t; vl = v; sl = sm; fl = fm; } else { tr = t; vr = v; sr = sm; fr = fm; }
     }
-    double p[3] = {0, 0, 0};
-    for (int a = 0; a < k; a++) for (int c = 0; c < 3; c++) p[c] += w[a] * W[idx[a]][c];
-    double dd = ho_dot3(p, p);
-    if (dd < bestd - 1e-30) { bestd = dd; bestmask = mask; for (int a = 0; a < 4; a++) bestw[a] = 0; for (int a = 0; a < k; a++) bestw[a] = w[a]; memcpy(v, p, sizeof(p)); }
+    /* the minimiser sits where the two bracketing faces tie: use the combination of their normals that is
+       perpendicular to the axis (zero sub-gradient), which is continuous in the pose */
+    double lam = sr / (sr - sl);
+    for (int i = 0; i < 3; i++) nmin[i] = lam * h.pl[fl][i] + (1 - lam) * h.pl[fr][i];
+    ho_normalize3(nmin);
   }
-  /* compact */
-  int k = 0; double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
-  for (int i = 0; i < *n; i++)
-    if (bestmask & (1 << i)) {
-      for (int c = 0; c < 3; c++) { ca[c] += bestw[k] * A[i][c]; cb[c] += bestw[k] * Bp[i][c]; }
-      if (k != i) { memcpy(W[k], W[i], 24); memcpy(A[k], A[i], 24); memcpy(Bp[k], Bp[i], 24); }
-      k++;
+  double tc[3], vc[3], nc3[3][3]; int nc = 0;
+  if (v0 < r) { tc[nc] = 0; vc[nc] = v0; for (int i = 0; i < 3; i++) nc3[nc][i] = h.pl[f0][i]; nc++; }
+  if (v1 < r) { tc[nc] = 1; vc[nc] = v1; for (int i = 0; i < 3; i++) nc3[nc][i] = h.pl[f1][i]; nc++; }
+  if (nc < 2 && vs < r) {
+    int dup = 0;
+    for (int k = 0; k < nc; k++) if (fabs(ts - tc[k]) < 1e-6) dup = 1;
+    if (!dup) { tc[nc] = ts; vc[nc] = vs; for (int i = 0; i < 3; i++) nc3[nc][i] = nmin[i]; nc++; }
+  }
+  (void)fs;
+  int cnt = 0;
+  for (int k = 0; k < nc && cnt < 2; k++) {
+    const double* pl = nc3[k];
+    double c[3], pos[3], nrm[3], pw[3], nw[3];
+    for (int i = 0; i < 3; i++) { c[i] = a[i] + tc[k] * d[i]; nrm[i] = -pl[i]; pos[i] = c[i] - pl[i] * 0.5 * (r + vc[k]); }
+    mv(mR, pos, pw); mv(mR, nrm, nw);
+    for (int i = 0; i < 3; i++) pw[i] += mp[i];
+    set_contact(out + cnt, vc[k] - r, pw, nw);
+    cnt++;
+  }
+  return cnt;
+}
+static void keep_deepest(ho_contact* out, int* n, int cap, double dist, const double pos[3], const double nrm[3]) {
+  int slot = -1;
+  if (*n < cap) slot = (*n)++;
+  else {
+    int w = 0;
+    for (int k = 1; k < cap; k++) if (out[k].dist > out[w].dist) w = k;
+    if (dist < out[w].dist) slot = w;
+  }
+  if (slot >= 0) set_contact(out + slot, dist, pos, nrm);
+}
+static int box_mesh(const ho_model* m, const double bp[3], const double bR[9], const double bh[3],
+                    const double mp[3], const double mR[9], int mesh, ho_contact* out) {
+  hull_t h = get_hull(m, mesh);
+  int n = 0;
+  /* hull vertices inside the box */
+  for (int v = 0; v < h.nv; v++) {
+    double wv[3], rel[3], p[3];
+    mv(mR, h.v[v], wv);
+    for (int i = 0; i < 3; i++) { wv[i] += mp[i]; rel[i] = wv[i] - bp[i]; }
+    mtv(bR, rel, p);
+    double depth = 1e300; int k = -1;
+    for (int i = 0; i < 3; i++) {
+      double dd = bh[i] - fabs(p[i]);
+      if (dd < depth) { depth = dd; k = i; }
     }
-  *n = k;
-  memcpy(A[3], ca, sizeof(ca)); memcpy(Bp[3], cb, sizeof(cb)); /* witness points parked in slot 3 when n<4 */
-  return bestd;
-}
-/* GJK distance between two convex shapes; returns distance (0 if intersecting), witness points pa, pb */
-static double gjk_distance(const shape* sa, const shape* sb, double pa[3], double pb[3]) {
-  double W[4][3], A[4][3], Bp[4][3], v[3], nd[3];
-  for (int i = 0; i < 3; i++) v[i] = sa->pos[i] - sb->pos[i];
-  if (ho_dot3(v, v) < 1e-20) { v[0] = 1; v[1] = v[2] = 0; }
-  int n = 0; double d2 = 1e300;
-  for (int it = 0; it < 64; it++) {
-    double a[3], b[3], w[3];
-    for (int i = 0; i < 3; i++) nd[i] = -v[i];
-    support(sa, nd, a); support(sb, v, b);
-    for (int i = 0; i < 3; i++) w[i] = a[i] - b[i];
-    double vv = ho_dot3(v, v), vw = ho_dot3(v, w);
-    if (n > 0 && vv - vw <= 1e-12 * vv + 1e-24) break; /* no progress possible */
-    if (n == 4) break;
-    memcpy(W[n], w, 24); memcpy(A[n], a, 24); memcpy(Bp[n], b, 24); n++;
-    double wa[3], wb[3];
-    d2 = closest_simplex(W, A, Bp, &n, v);
-    memcpy(wa, A[3], 24); memcpy(wb, Bp[3], 24);
-    if (n < 4) { memcpy(pa, wa, 24); memcpy(pb, wb, 24); }
-    if (d2 < 1e-24 || n == 4) { d2 = 0; memcpy(pa, wa, 24); memcpy(pb, wb, 24); break; }
+    if (depth <= 0) continue;
+    double nl[3] = {0, 0, 0}, nw[3], pos[3];
+    nl[k] = p[k] >= 0 ? 1 : -1;
+    mv(bR, nl, nw);
+    for (int i = 0; i < 3; i++) pos[i] = wv[i] + nw[i] * 0.5 * depth;
+    keep_deepest(out, &n, 4, -depth, pos, nw);
   }
-  return sqrt(d2 > 1e299 ? 0 : d2);
-}
-/* mesh vs capsule: GJK on (hull, core segment); contact if distance < radius. Deep case (core touches the hull)
- * falls back to pushing along the centre line of the two geoms. */
-static int convex_capsule(const shape* cap, const shape* mesh, ho_contact* out) {
-  double pa[3], pb[3];
-  double dist = gjk_distance(cap, mesh, pa, pb), r = cap->size[0];
-  double n[3];
-  if (dist > 1e-9) {
-    if (dist - r >= 0) return 0;
-    for (int i = 0; i < 3; i++) n[i] = (pb[i] - pa[i]) / dist;   /* capsule -> mesh */
-    double pos[3];
-    for (int i = 0; i < 3; i++) pos[i] = pa[i] + n[i] * (r + 0.5 * (dist - r));
-    set_contact(out, dist - r, pos, n);
-    return 1;
+  /* box corners inside the hull */
+  for (int c = 0; c < 8; c++) {
+    double loc[3] = {(c & 1 ? bh[0] : -bh[0]), (c & 2 ? bh[1] : -bh[1]), (c & 4 ? bh[2] : -bh[2])}, wc[3], rel[3], p[3];
+    mv(bR, loc, wc);
+    for (int i = 0; i < 3; i++) { wc[i] += bp[i]; rel[i] = wc[i] - mp[i]; }
+    mtv(mR, rel, p);
+    double zero[3] = {0, 0, 0}; int f;
+    double s = hull_line_max(&h, p, zero, 0, &f);
+    if (s >= 0) continue;
+    double nl[3] = {-h.pl[f][0], -h.pl[f][1], -h.pl[f][2]}, nw[3], pos[3];
+    mv(mR, nl, nw);
+    for (int i = 0; i < 3; i++) pos[i] = wc[i] - nw[i] * 0.5 * (-s);
+    keep_deepest(out, &n, 4, s, pos, nw);
   }
-  for (int i = 0; i < 3; i++) n[i] = mesh->pos[i] - cap->pos[i];
-  ho_normalize3(n);
-  double sm[3], nn[3] = {-n[0], -n[1], -n[2]};
-  support(mesh, nn, sm);
-  double dep = 0;
-  for (int i = 0; i < 3; i++) dep += (cap->pos[i] - sm[i]) * nn[i];
-  double pos[3];
-  for (int i = 0; i < 3; i++) pos[i] = 0.5 * (cap->pos[i] + sm[i]);
-  set_contact(out, -(fabs(dep) + r), pos, n);
-  return 1;
-}
-/* box vs mesh: treat both as polytopes; shrink nothing, so GJK only reports separation. Penetration is
- * estimated by the minimum over the box face normals and the centre direction of the support overlap. */
-static int convex_box(const shape* box, const shape* mesh, ho_contact* out) {
-  double pa[3], pb[3];
-  double dist = gjk_distance(box, mesh, pa, pb);
-  if (dist > 1e-9) return 0;
-  double best = 1e300, bn[3] = {0, 0, 1};
-  double cand[7][3];
-  for (int k = 0; k < 3; k++) col(box->R, k, cand[k]);
-  for (int k = 0; k < 3; k++) for (int i = 0; i < 3; i++) cand[3 + k][i] = -cand[k][i];
-  for (int i = 0; i < 3; i++) cand[6][i] = mesh->pos[i] - box->pos[i];
-  ho_normalize3(cand[6]);
-  double sbest[3] = {0, 0, 0}, mbest[3] = {0, 0, 0};
-  for (int k = 0; k < 7; k++) {
-    double nn[3] = {-cand[k][0], -cand[k][1], -cand[k][2]}, sb[3], smh[3];
-    support(box, cand[k], sb); support(mesh, nn, smh);
-    double pen = 0;
-    for (int i = 0; i < 3; i++) pen += (sb[i] - smh[i]) * cand[k][i];
-    if (pen < best) { best = pen; memcpy(bn, cand[k], 24); memcpy(sbest, sb, 24); memcpy(mbest, smh, 24); }
-  }
-  if (best <= 0) return 0;
-  double pos[3];
-  for (int i = 0; i < 3; i++) pos[i] = mbest[i] + 0.5 * best * bn[i];
-  (void)sbest;
-  set_contact(out, -best, pos, bn);
-  return 1;
+  return n;
 }
 
 /* ---------------------------------------------------------------- dispatcher */
@@ -514,11 +505,7 @@ int ho_collide_pair(const ho_model* m, const ho_data* d, int pair, ho_contact* o
   if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_CAPSULE) return capsule_capsule(p1, R1, s1, p2, R2, s2, out);
   if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_BOX) return capsule_box(p1, R1, s1, p2, R2, s2, out);
   if (t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX) return box_box(p1, R1, s1, p2, R2, s2, out, maxout);
-  if (t2 == HOIC_GEOM_MESH && (t1 == HOIC_GEOM_CAPSULE || t1 == HOIC_GEOM_BOX)) {
-    int me = m->geom_meshid[g2];
-    shape a = {p1, R1, t1, s1, NULL, 0};
-    shape b = {p2, R2, HOIC_GEOM_MESH, s2, (const double(*)[3])m->mesh_vert[m->mesh_vertadr[me]], m->mesh_vertnum[me]};
-    return t1 == HOIC_GEOM_CAPSULE ? convex_capsule(&a, &b, out) : convex_box(&a, &b, out);
-  }
+  if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_MESH) return capsule_mesh(m, p1, R1, s1, p2, R2, m->geom_meshid[g2], out);
+  if (t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_MESH) return box_mesh(m, p1, R1, s1, p2, R2, m->geom_meshid[g2], out);
   return 0;
 }

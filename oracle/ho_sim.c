@@ -152,6 +152,7 @@ int ho_model_load(ho_model* m, const void* blob, size_t nbytes) {
   LF("pair_friction", m->pair_friction); LF("pair_solref", m->pair_solref); LF("pair_solimp", m->pair_solimp);
   LF("pair_margin", m->pair_margin); LF("pair_gap", m->pair_gap);
   LI("mesh_vertadr", m->mesh_vertadr); LI("mesh_vertnum", m->mesh_vertnum); LF("mesh_vert", m->mesh_vert);
+  LI("mesh_planeadr", m->mesh_planeadr); LI("mesh_planenum", m->mesh_planenum); LF("mesh_plane", m->mesh_plane);
   LI1("hand_body0", m->hand_body0); LI1("hand_nbody", m->hand_nbody); LI1("obj_body", m->obj_body);
   LI1("hand_geom0", m->hand_geom0); LI1("hand_geom1", m->hand_geom1);
   LI1("obj_geom0", m->obj_geom0); LI1("obj_geom1", m->obj_geom1);

@@ -207,3 +207,63 @@ def test_narrow_phase_geometry(oracle_lib, box_blob, box_model, case):
         assert np.linalg.norm(g[8] - g[20]) > 0.02
         con = e.contacts()
         assert not len(con[(con[:, 13] == 8) & (con[:, 14] == 20)])
+
+
+@pytest.mark.parametrize("obj", ["bottle", "banana"])
+def test_convex_mesh_models(oracle_lib, obj):
+    """Bottle / banana (BASELINE.json configs 2-3): hull tables are consistent, the object comes to rest on the
+    table through the box-mesh routine, and capsule-mesh contacts agree with a brute-force hull distance."""
+    blob = open(mjcf.packaged_model_path(obj), "rb").read()
+    model = mjcf.CompiledModel.from_blob(blob)
+    A = model.arrays
+    nm = model.scalar("nmesh")
+    for me in range(nm):
+        nvt, npl = A["mesh_vertnum"][me], A["mesh_planenum"][me]
+        if nvt == 0:
+            continue                                   # visual mesh: no collision hull
+        V = A["mesh_vert"][A["mesh_vertadr"][me]:A["mesh_vertadr"][me] + nvt]
+        P = A["mesh_plane"][A["mesh_planeadr"][me]:A["mesh_planeadr"][me] + npl]
+        sd = V @ P[:, :3].T - P[:, 3]
+        assert sd.max() < 1e-9                          # every vertex inside every face plane
+        assert np.all((np.abs(sd) < 1e-9).sum(0) >= 3)  # every face touches >= 3 vertices
+        np.testing.assert_allclose(np.linalg.norm(P[:, :3], axis=1), 1, atol=1e-12)
+    e = oracle_lib.OracleEnv(blob)
+    q = np.zeros(model.scalar("nq")); q[:26] = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1]); q[2] = 0.9
+    q[26:29] = [0.3, 0.0, 0.58]; q[29] = 1
+    e.set("qpos", q); e.set("qvel", np.zeros(32))
+    for _ in range(1500):
+        e.sim_step()
+    assert 0.5 < e.get("qpos")[28] < 0.6 and np.isfinite(e.get("qvel")).all()
+    if obj == "bottle":                               # the banana keeps rocking for seconds; the bottle settles
+        assert np.abs(e.get("qvel")[26:]).max() < 5e-3
+    con = e.contacts()
+    tab = con[(con[:, 13] == 1) & (con[:, 14] >= model.scalar("obj_geom0"))]
+    assert len(tab) >= 1 and np.all(tab[:, 0] < 0) and np.all(tab[:, 0] > -1e-3)
+    np.testing.assert_allclose(tab[:, 4:7], [[0, 0, 1]] * len(tab), atol=1e-9)   # table pushes the object up
+    # capsule vs hull: put the object right under the index fingertip capsule and compare with brute force
+    e2 = oracle_lib.OracleEnv(blob)
+    q[26:29] = [0.5, 0.5, 1.5]
+    e2.set("qpos", q); e2.forward()
+    g = 8
+    gp = e2.get("geom_xpos")[g]; R = e2.get("geom_xmat")[g].reshape(3, 3); r, hl = A["geom_size"][g][:2]
+    og = model.scalar("obj_geom0")
+    me = A["geom_meshid"][og]
+    V = A["mesh_vert"][A["mesh_vertadr"][me]:A["mesh_vertadr"][me] + A["mesh_vertnum"][me]]
+    P = A["mesh_plane"][A["mesh_planeadr"][me]:A["mesh_planeadr"][me] + A["mesh_planenum"][me]]
+    # raise the object from below the fingertip until the first contact with its first hull appears
+    cm = np.zeros((0, 16))
+    goff = e2.get("geom_xpos")[og] - q[26:29]     # hull centre relative to the body origin (identity rotation)
+    for dz in np.arange(-0.15, 0.05, 0.0005):
+        q[26:29] = [gp[0] - goff[0], gp[1] - goff[1], gp[2] - goff[2] + dz]
+        e2.set("qpos", q); e2.forward()
+        con = e2.contacts(); cm = con[(con[:, 13] == g) & (con[:, 14] == og)]
+        if len(cm):
+            break
+    assert 1 <= len(cm) <= 2 and np.all(cm[:, 0] < 0) and cm[:, 0].min() > -0.002
+    # brute force: min over the capsule axis of max_f plane distance, in the mesh frame
+    mp_, mR = e2.get("geom_xpos")[og], e2.get("geom_xmat")[og].reshape(3, 3)
+    ts = np.linspace(0, 1, 2001)
+    pts = (gp - hl * R[:, 2])[None] + ts[:, None] * (2 * hl * R[:, 2])[None]
+    loc = (pts - mp_) @ mR
+    phi = (loc @ P[:, :3].T - P[:, 3]).max(1)
+    assert abs((phi.min() - r) - cm[:, 0].min()) < 1e-6
