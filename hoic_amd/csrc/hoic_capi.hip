@@ -28,9 +28,8 @@ __device__ void load_state(const DevModel& m, const DevState& st, Work& w, int e
     w.warm[tid] = st.warm[(size_t)env * NV + tid];
     w.ctrl[tid] = 0.f; w.applied[tid] = 0.f; w.qacc[tid] = 0.f;
   }
-  for (int k = tid; k < NV * LD; k += NT) w.M[k] = 0.f;
   if (tid < NHG) { for (int i = 0; i < 12; i++) w.rec_sum[tid][i] = 0.f; w.rec_cnt[tid] = 0; }
-  if (tid == 0) { w.ncon = 0; w.nlim = 0; w.nrow = 0; w.n_avg = 0; w.solver_iter = 0; w.fail = 0; }
+  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; }
   __syncthreads();
 }
 __device__ void store_state(const DevState& st, const Work& w, int env) {
@@ -43,52 +42,48 @@ __device__ void store_state(const DevState& st, const Work& w, int env) {
 }
 
 // mj_forward dynamics on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
-__device__ bool dev_forward_dyn(const DevModel& m, const LaneK& lk, const DevConfig& cfg, Work& w, int* overflow) {
-  const int tid = threadIdx.x;
-  dev_forward_kin(m, lk, w, w.qpos, w.qvel, overflow);
-  dev_make_constraint(m, lk, w, w.qpos, w.qvel); PT(7);
-  if (tid < NV) {
-    float fs = 0.f;
-    if (tid < m.nv) {
-      const float act = lk.d_act >= 0 ? w.ctrl[lk.d_act] : 0.f;
-      fs = w.passive[tid] - w.bias[tid] + w.applied[tid] + act;
-    }
-    w.fsmooth[tid] = fs; w.asmooth[tid] = fs; w.tv2[tid] = 0.f;
+__device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const DofK& dk, MReg& M, int* overflow) {
+  const int tid = threadIdx.x, d = tid & 31;
+  dev_forward_kin(m, w, dk, M, w.qpos, w.qvel, overflow);
+  RowK rk;
+  dev_make_constraint(m, w, dk, rk, w.qpos, w.qvel); PT(7);
+  float fs = 0.f;
+  if (d < m.nv) {
+    const float act = dk.act >= 0 ? w.ctrl[dk.act] : 0.f;
+    fs = -dk.damp * w.qvel[d] - w.bias[d] + w.applied[d] + act;   // passive (joint damping) - bias + applied + actuation
   }
-  __syncthreads();
+  if (tid < NV) w.fsmooth[tid] = fs;
   PT(20);
-  dev_hsolve(m, w, w.tv2, m.nv, false, w.asmooth); PT(8);
-  dev_solve(m, lk, w, cfg.c.solver_iterations); PT(9);
+  const float a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs); PT(8);
+  if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
+  __syncthreads();
+  dev_solve(m, w, M, dk, rk, cfg.c.solver_iterations); PT(9);
   float bad = 0.f;
   if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
   return !(wave_max(bad) > 0.f);
 }
 
 // semi-implicit Euler with implicit joint damping; also records the pre-integration state (lag) and warm start
-__device__ void dev_euler(const DevModel& m, const LaneK& lk, Work& w) {
-  const int tid = threadIdx.x;
-  if (tid < NV) {
-    w.tv2[tid] = (tid < m.nv) ? m.timestep * lk.d_damp : 0.f;
-    w.tv[tid] = (tid < m.nv) ? (w.fsmooth[tid] + w.fcon[tid]) : 0.f;
-  }
-  __syncthreads();
-  PT(20);
-  dev_hsolve(m, w, w.tv2, m.nv, false, w.tv);
+__device__ void dev_euler(const DevModel& m, Work& w, const DofK& dk, const MReg& M) {
+  const int tid = threadIdx.x, d = tid & 31;
   const float h = m.timestep;
+  const float rhs = (d < m.nv) ? (w.fsmooth[d] + w.fcon[d]) : 0.f;
+  PT(20);
+  const float acc = dev_hsolve(m, w, M, h * dk.damp, m.nv, false, rhs);
   if (tid < NQP) w.qlag[tid] = w.qpos[tid];
   if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
   __syncthreads();
-  if (tid < m.nv) w.qvel[tid] += h * w.tv[tid];
+  if (tid < m.nv) w.qvel[tid] += h * acc;
   __syncthreads();
   if (tid < m.njnt) {
-    const int qa = lk.j_qadr, da = lk.j_dadr;
-    if (lk.j_type == HOIC_JNT_FREE) {
+    const int qa = m.jnt_qposadr[tid], da = m.jnt_dofadr[tid];
+    if (m.jnt_type[tid] == HOIC_JNT_FREE) {
       for (int i = 0; i < 3; i++) w.qpos[qa + i] += h * w.qvel[da + i];
       float wv[3] = {w.qvel[da + 3], w.qvel[da + 4], w.qvel[da + 5]};
       const float ang = normalize3(wv) * h;
       if (ang != 0.f) {
         float s, c;
-        sincosf(0.5f * ang, &s, &c);
+        sincos_pi(0.5f * ang, &s, &c);
         float dq[4] = {c, s * wv[0], s * wv[1], s * wv[2]}, qo[4] = {w.qpos[qa + 3], w.qpos[qa + 4], w.qpos[qa + 5], w.qpos[qa + 6]}, qn[4];
         mulquat(qo, dq, qn);
         normquat(qn);
@@ -99,18 +94,18 @@ __device__ void dev_euler(const DevModel& m, const LaneK& lk, Work& w) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
-                                                       DevExpert ex, DevState st, const float* __restrict__ action,
-                                                       float* __restrict__ obs, float* __restrict__ reward,
-                                                       float* __restrict__ reward_info, int* __restrict__ flags,
-                                                       float* __restrict__ percent, const int* __restrict__ next_seq,
-                                                       const int* __restrict__ next_start) {
+// ---- kernel 1 of a step: the 15 substeps (control glue + dynamics + contact solve + integration), f32.
+// Leaves the new state in HBM and a hand-over record (lagged body / geom poses, contact sums, 15-substep finite
+// differences) for the post-step kernel.
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+                                                          DevExpert ex, DevState st, const float* __restrict__ action) {
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
   const int env = blockIdx.x, tid = threadIdx.x;
   load_state(m, st, w, env);
-  LaneK lk;
-  dev_load_constants(m, w, lk);
+  DofK dk;
+  dev_load_constants(m, dk);
+  MReg M;
 #ifdef HOIC_PHASE_TIMING
   if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
   __syncthreads();
@@ -125,53 +120,101 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
     vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
   }
   int* ovf = &st.overflow[env];
+  float* post = st.post + (size_t)env * PB_SIZE;
+  float* oldg = st.oldg + (size_t)env * OG_SIZE;
   // quantities of the previous forward pass (one-substep lag): recompute them from the lagged state
-  dev_forward_kin(m, lk, w, w.qlag, w.vlag, tid == 0 ? ovf : nullptr);
+  dev_forward_kin(m, w, dk, M, w.qlag, w.vlag, tid == 0 ? ovf : nullptr);
   for (int g = tid; g < m.ngeom; g += NT) {
-    for (int i = 0; i < 3; i++) w.old_gxpos[g][i] = w.gxpos[g][i];
-    for (int i = 0; i < 9; i++) w.old_gxmat[g][i] = w.gxmat[g][i];
+    for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
+    for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
   }
-  if (tid < 6) w.old_objvel[tid] = w.qvel[m.nv - 6 + tid];
-  __syncthreads();
+  const float old_objvel = (tid < 6) ? w.qvel[m.nv - 6 + tid] : 0.f;
   bool ok = true;
   const int nsub = cfg.c.sim_step;
   for (int i = 0; i < nsub; i++) {
     PT(0);
-    dev_pd_torque(m, cfg, w, ev); PT(1);       // :518-523
-    dev_applied(m, cfg, w, vf, vt);      // :526-540
-    dev_record_contact(m, w); PT(2);           // :543
-    ok = dev_forward_dyn(m, lk, cfg, w, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
+    dev_record_contact(m, w); PT(2);           // :543 (contacts of the previous forward pass)
+    dev_pd_torque(m, cfg, w, M, ev); PT(1);    // :518-523
+    dev_applied(m, cfg, w, vf, vt);            // :526-540
+    ok = dev_forward_dyn(m, cfg, w, dk, M, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
     if (!ok) break;
-    dev_euler(m, lk, w); PT(10);                    //              ... + Euler
+    dev_euler(m, w, dk, M); PT(10);            //              ... + Euler
   }
   PT(0);
-  float rfc_score = 0.f;
   if (ok) {
     const float dt = (float)nsub * m.timestep, idt = 1.f / dt;
-    if (tid < 6) w.obj_avg_acc[tid] = (w.qvel[m.nv - 6 + tid] - w.old_objvel[tid]) * idt;        // :554
+    if (tid < 6) post[PB_OBJACC + tid] = (w.qvel[m.nv - 6 + tid] - old_objvel) * idt;                 // :554
     for (int g = tid; g < m.ngeom; g += NT) {
-      for (int i = 0; i < 3; i++) w.gvel[g][i] = (w.gxpos[g][i] - w.old_gxpos[g][i]) * idt;       // :555
-      float Rd[9], aa[3];
+      for (int i = 0; i < 3; i++) post[PB_GVEL + g * 3 + i] = (w.gxpos[g][i] - oldg[g * 12 + i]) * idt;   // :555
+      float Rd[9], aa[3], Ro[9];
+      for (int i = 0; i < 9; i++) Ro[i] = oldg[g * 12 + 3 + i];
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
           float s = 0.f;
-          for (int k = 0; k < 3; k++) s += w.gxmat[g][3 * i + k] * w.old_gxmat[g][3 * j + k];
+          for (int k = 0; k < 3; k++) s += w.gxmat[g][3 * i + k] * Ro[3 * j + k];
           Rd[3 * i + j] = s;
         }
       dev_matrix_to_axis_angle(Rd, aa);                                                         // :556-559
-      for (int i = 0; i < 3; i++) w.gangvel[g][i] = aa[i] * idt;
+      for (int i = 0; i < 3; i++) post[PB_GANGVEL + g * 3 + i] = aa[i] * idt;
     }
-    __syncthreads();
-    dev_classify_contact(m, w); PT(11);                                                        // :562
-    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt);                     // :631
-    PT(12);
-    if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
-  }
-  if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
+  } else {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
     if (tid < NQP) w.qpos[tid] = w.qlag[tid];
     if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
     __syncthreads();
-    dev_kinematics(m, lk, w, w.qpos);
+    dev_kinematics(m, w, w.qpos);
+  }
+  if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
+  for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
+  for (int k = tid; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
+  for (int k = tid; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
+  for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
+  if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
+  store_state(st, w, env);
+  PT(13);
+#ifdef HOIC_PHASE_TIMING
+  if (tid < 24) st.phase[(size_t)env * 24 + tid] = w.pt[tid];
+#endif
+}
+
+// ---- kernel 2 of a step: contact averaging, the residual-force QP (float64), termination, reward, the optional
+// in-launch reset and the 617-float observation (HandObjMimic4.step after do_simulation, ho_im4.py:631-662)
+__global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+                                                           DevExpert ex, DevState st, const float* __restrict__ action,
+                                                           float* __restrict__ obs, float* __restrict__ reward,
+                                                           float* __restrict__ reward_info, int* __restrict__ flags,
+                                                           float* __restrict__ percent, const int* __restrict__ next_seq,
+                                                           const int* __restrict__ next_start) {
+  __shared__ Work w;
+  const DevModel& m = *mp; const DevConfig& cfg = *cp;
+  const int env = blockIdx.x, tid = threadIdx.x;
+  const float* post = st.post + (size_t)env * PB_SIZE;
+  if (tid < NQP) w.qpos[tid] = st.qpos[(size_t)env * NQP + tid];
+  if (tid < NV) {
+    w.qvel[tid] = st.qvel[(size_t)env * NV + tid];
+    w.action[tid] = fminf(fmaxf(action[(size_t)env * HOIC_ACT_DIM + tid], -1.f), 1.f);
+  }
+  for (int k = tid; k < m.nbody * 3; k += NT) w.xpos[k / 3][k % 3] = post[PB_XPOS + k];
+  for (int k = tid; k < m.nbody * 4; k += NT) w.xquat[k / 4][k % 4] = post[PB_XQUAT + k];
+  for (int k = tid; k < m.ngeom * 3; k += NT) w.gxpos[k / 3][k % 3] = post[PB_GXPOS + k];
+  for (int k = tid; k < NHG * 12; k += NT) w.rec_sum[k / 12][k % 12] = post[PB_REC + k];
+  if (tid < NHG) w.rec_cnt[tid] = (int)post[PB_RECCNT + tid];
+  for (int k = tid; k < m.ngeom * 3; k += NT) { w.sc.post.gvel[k / 3][k % 3] = post[PB_GVEL + k]; w.sc.post.gangvel[k / 3][k % 3] = post[PB_GANGVEL + k]; }
+  if (tid < 6) w.sc.post.obj_avg_acc[tid] = post[PB_OBJACC + tid];
+  bool ok = post[PB_OK] != 0.f;
+  const int solver_iter = (int)post[PB_ITER];
+  __syncthreads();
+  const int seq = st.seq[env];
+  ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], st.start[env], st.cur_t[env]};
+  float vf[3], vt[3];
+  for (int i = 0; i < 3; i++) {
+    vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
+    vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
+  }
+  float rfc_score = 0.f;
+  if (ok) {
+    dev_classify_contact(m, w);                                                                // :562
+    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt);                     // :631
+    if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
   }
   ev.cur_t += 1;                                                                                // :641
   float df[5];
@@ -189,26 +232,22 @@ __global__ __launch_bounds__(NT) void hoic_step_kernel(const DevModel* __restric
   if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                     // agent_handmimic.py:479-480
   if (tid == 0) {
     reward[env] = r;
-    flags[4 * env] = fail; flags[4 * env + 1] = end; flags[4 * env + 2] = done; flags[4 * env + 3] = w.solver_iter;
+    flags[4 * env] = fail; flags[4 * env + 1] = end; flags[4 * env + 2] = done; flags[4 * env + 3] = solver_iter;
     percent[env] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
     st.rfc_score[env] = rfc_score;
   }
   if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)env * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
   if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
     const int ns = next_seq[env], nst = next_start[env];
+    __syncthreads();
     dev_reset_state(m, w, ex, ns, nst);
-    dev_kinematics(m, lk, w, w.qpos);
+    dev_kinematics(m, w, w.qpos);
     ev.off = ex.seq_off[ns]; ev.len = ex.seq_len[ns]; ev.start = nst; ev.cur_t = 0;
     if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
+    store_state(st, w, env);
   }
-  PT(13);
   dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
-  store_state(st, w, env);
   if (tid == 0) st.cur_t[env] = ev.cur_t;
-  PT(14);
-#ifdef HOIC_PHASE_TIMING
-  if (tid < 24) st.phase[(size_t)env * 24 + tid] = w.pt[tid];
-#endif
 }
 
 __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restrict__ mp, DevExpert ex, DevState st,
@@ -221,10 +260,8 @@ __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restri
   const int seq = seqs[k], start = starts[k];
   if (tid < NQP) w.qpos[tid] = 0.f;
   __syncthreads();
-  LaneK lk;
-  dev_load_constants(m, w, lk);
   dev_reset_state(m, w, ex, seq, start);
-  dev_kinematics(m, lk, w, w.qpos);
+  dev_kinematics(m, w, w.qpos);
   ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], start, 0};
   if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
   store_state(st, w, env);
@@ -258,7 +295,6 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
   const int env = blockIdx.x, tid = threadIdx.x;
-  for (int k = tid; k < NV * LD; k += NT) w.M[k] = 0.f;
   if (tid < NQP) w.qpos[tid] = tid < m.nq ? a.qpos[(size_t)env * m.nq + tid] : 0.f;
   if (tid < NV) {
     w.qvel[tid] = tid < m.nv ? a.qvel[(size_t)env * m.nv + tid] : 0.f;
@@ -266,16 +302,20 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
     w.applied[tid] = (a.applied && tid < m.nv) ? a.applied[(size_t)env * m.nv + tid] : 0.f;
     w.warm[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;
   }
-  if (tid == 0) { w.ncon = 0; w.nlim = 0; w.nrow = 0; w.solver_iter = 0; }
+  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; }
   __syncthreads();
-  LaneK lk;
-  dev_load_constants(m, w, lk);
-  const bool ok = dev_forward_dyn(m, lk, cfg, w, nullptr);
+  DofK dk;
+  dev_load_constants(m, dk);
+  MReg M;
+  const bool ok = dev_forward_dyn(m, cfg, w, dk, M, nullptr);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
   if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
   if (a.gxmat) for (int k = tid; k < m.ngeom * 9; k += NT) a.gxmat[(size_t)env * m.ngeom * 9 + k] = w.gxmat[k / 9][k % 9];
-  if (a.qM) for (int k = tid; k < m.nv * m.nv; k += NT) a.qM[(size_t)env * m.nv * m.nv + k] = w.M[(k / m.nv) * LD + k % m.nv];
+  if (a.qM && tid < m.nv) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) if (k < m.nv) a.qM[((size_t)env * m.nv + tid) * m.nv + k] = M.r[k];
+  }
   if (a.bias && tid < m.nv) a.bias[(size_t)env * m.nv + tid] = w.bias[tid];
   if (a.asmooth && tid < m.nv) a.asmooth[(size_t)env * m.nv + tid] = w.asmooth[tid];
   if (a.qacc && tid < m.nv) a.qacc[(size_t)env * m.nv + tid] = w.qacc[tid];
@@ -293,7 +333,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
       } else for (int i = 0; i < 16; i++) r[i] = 0.f;
     }
   }
-  if (a.do_step && ok) dev_euler(m, lk, w);
+  if (a.do_step && ok) dev_euler(m, w, dk, M);
   if (a.qpos_out && tid < m.nq) a.qpos_out[(size_t)env * m.nq + tid] = w.qpos[tid];
   if (a.qvel_out && tid < m.nv) a.qvel_out[(size_t)env * m.nv + tid] = w.qvel[tid];
 }
@@ -310,8 +350,7 @@ struct hoic_sim {
   DevState st{};
   int *d_iota_seq = nullptr, *d_iota_start = nullptr;
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_ms = -1.f;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   bool has_expert = false;
 };
 
@@ -428,12 +467,36 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     for (int d = lastdof[i]; d >= 0; d = dparent[d]) mask |= 1u << d;
     m.body_dofmask[i] = mask;
   }
-  m.nM = 0;
-  for (int i = 0; i < m.nv; i++)
-    for (int j = i; j >= 0; j = dparent[j]) {
-      if (m.nM >= 256) { set_err("model blob: too many mass-matrix entries"); return false; }
-      m.mi[m.nM] = (unsigned char)i; m.mj[m.nM] = (unsigned char)j; m.nM++;
+  // pointer-jumping schedule of the kinematics: round r composes a body with its ancestor 2^r levels up
+  {
+    int anc[NB];
+    for (int i = 0; i < m.nbody; i++) anc[i] = m.body_parent[i];
+    m.nround = 0;
+    for (int r = 0; r < MAXROUND; r++) {
+      bool any = false;
+      int nxt[NB];
+      for (int i = 0; i < m.nbody; i++) {
+        m.body_jump[r][i] = (i > 0 && anc[i] != 0) ? anc[i] : -1;
+        nxt[i] = (i > 0 && anc[i] != 0) ? anc[anc[i]] : 0;
+        any = any || m.body_jump[r][i] >= 0;
+      }
+      for (int i = 0; i < m.nbody; i++) anc[i] = nxt[i];
+      if (any) m.nround = r + 1;
     }
+    for (int i = 0; i < m.nbody; i++) if (anc[i] != 0) { set_err("model blob: kinematic tree deeper than 8 levels"); return false; }
+  }
+  for (int d = 0; d < m.nv; d++) {
+    unsigned am = 0;
+    for (int e = dparent[d]; e >= 0; e = dparent[e]) am |= 1u << e;
+    m.dof_amask[d] = am;
+    m.dof_actid[d] = -1;
+    for (int u = 0; u < m.nu; u++) if (m.act_dofid[u] == d) m.dof_actid[d] = u;
+  }
+  for (int d = 0; d < m.nv; d++) {
+    unsigned dm = 0;
+    for (int e = 0; e < m.nv; e++) if (e != d && ((m.dof_amask[e] >> d) & 1u)) dm |= 1u << e;
+    m.dof_dmask[d] = dm;
+  }
   // constraint constants
   for (int i = 0; i < m.nv; i++) {
     float K;
@@ -461,8 +524,10 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
       m.pair_Rscale[p] = (float)(2 * mu * mu * (tran + f[0] * f[0] * tran));
     }
     m.pair_b1[p] = b1; m.pair_b2[p] = b2;
-    const int t1 = m.geom_type[m.pair_geom1[p]], t2 = m.geom_type[m.pair_geom2[p]];
-    if (t1 == HOIC_GEOM_MESH || t2 == HOIC_GEOM_MESH) { /* convex-mesh pairs: not in this round's kernel */ }
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    m.pair_type1[p] = m.geom_type[g1]; m.pair_type2[p] = m.geom_type[g2]; m.pair_mesh[p] = m.geom_meshid[g2];
+    m.pair_bound[p] = m.geom_rbound[g1] + m.geom_rbound[g2] + m.pair_margin[p];
+    if (m.pair_type1[p] == HOIC_GEOM_MESH) { set_err("model blob: a mesh must be the second geom of a pair"); return false; }
   }
   std::vector<int> mva, mvn, mpa, mpn; std::vector<double> mv, mpl;
   if (b.i32("mesh_vertadr", mva) && b.i32("mesh_vertnum", mvn) && b.f64("mesh_vert", mv) &&
@@ -507,7 +572,8 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.warm, n * NV * 4) == hipSuccess && hipMalloc(&s->st.cur_t, n * 4) == hipSuccess &&
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
        hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess &&
-       hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess;
+       hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
+       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
   hipMemcpy(s->d_model, &s->hm, sizeof(DevModel), hipMemcpyHostToDevice);
   hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice);
@@ -515,6 +581,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.vlag, 0, n * NV * 4); hipMemset(s->st.warm, 0, n * NV * 4); hipMemset(s->st.cur_t, 0, n * 4);
   hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
   hipMemset(s->st.overflow, 0, n * 4); hipMemset(s->st.phase, 0, n * 24 * 8);
+  hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4);
   hipDeviceSynchronize();
   return s;
 }
@@ -524,10 +591,11 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->d_iota_seq, s->d_iota_start};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->d_iota_seq, s->d_iota_start};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->ev2) hipEventDestroy(s->ev2);
   delete s;
 }
 
@@ -607,9 +675,11 @@ extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, f
   if (!s->has_expert) { set_err("hoic_step: set_expert has not been called"); return HOIC_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
   if (s->timing) hipEventRecord(s->ev0, st);
-  hipLaunchKernelGGL(hoic_step_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start);
+  hipLaunchKernelGGL(hoic_substep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action);
   if (s->timing) hipEventRecord(s->ev1, st);
+  hipLaunchKernelGGL(hoic_poststep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start);
+  if (s->timing) hipEventRecord(s->ev2, st);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -640,14 +710,15 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
   if (!s || n <= 0 || !d_qpos || !d_qvel) { set_err("hoic_probe_forward: bad arguments"); return HOIC_ERR_ARG; }
   ProbeArgs a{d_qpos, d_qvel, d_ctrl, d_applied, d_warm, do_step, d_xpos, d_xquat, d_geom_xpos, d_geom_xmat, d_qM, d_bias,
               d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_ncon, d_solver_iter};
-  hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->d_cfg, a);
+  static const int lds_pad = getenv("HOIC_DBG_LDS_PAD") ? atoi(getenv("HOIC_DBG_LDS_PAD")) : 0;   // occupancy experiments
+  hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), lds_pad, (hipStream_t)stream, s->d_model, s->d_cfg, a);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
 
 extern "C" int32_t hoic_enable_timing(hoic_sim* s, int32_t enable) {
   if (!s) return HOIC_ERR_ARG;
-  if (enable && !s->ev0) { HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); }
+  if (enable && !s->ev0) { HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); HIPCHK(hipEventCreate(&s->ev2)); }
   s->timing = enable != 0;
   return HOIC_OK;
 }
@@ -656,6 +727,13 @@ extern "C" float hoic_last_step_ms(hoic_sim* s) {
   if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.f;
   float ms = -1.f;
   if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.f;
+  return ms;
+}
+extern "C" float hoic_last_poststep_ms(hoic_sim* s) {
+  if (!s || !s->timing || !s->ev2) return -1.f;
+  if (hipEventSynchronize(s->ev2) != hipSuccess) return -1.f;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, s->ev1, s->ev2) != hipSuccess) return -1.f;
   return ms;
 }
 

@@ -442,42 +442,45 @@ HD void make_frame(float* f) {
 }
 
 // ---- collision driver: lane = pair (two passes when npair > 64); contacts compacted into the workspace
-__device__ void dev_collision(const DevModel& m, const LaneK& lk, Work& w, int* overflow) {
+__device__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
   const int tid = threadIdx.x;
   if (tid == 0) w.ncon = 0;
   __syncthreads();
-#pragma unroll
-  for (int ps = 0; ps < 2; ps++) {
-    const int base = ps * NT;
-    if (base >= m.npair) break;
-    const int p = base + tid;
+  for (int ps = 0; ps * NT < m.npair; ps++) {
+    const int p = ps * NT + tid;
     LaneContacts lc;
     lc.n = 0;
-    if (lk.p_t1[ps] >= 0) {
-      const int g1 = lk.p_g1[ps], g2 = lk.p_g2[ps], t1 = lk.p_t1[ps], t2 = lk.p_t2[ps];
-      const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1]; const float* s1 = lk.p_s1[ps];
-      const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2]; const float* s2 = lk.p_s2[ps];
+    int g1 = 0, g2 = 0;
+    if (p < m.npair) {
+      g1 = m.pair_geom1[p]; g2 = m.pair_geom2[p];
+      const int t1 = m.pair_type1[p], t2 = m.pair_type2[p];
+      const float bound = m.pair_bound[p], margin = m.pair_margin[p];
+      const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1];
+      const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2];
       bool test = true;
       if (t1 != HOIC_GEOM_PLANE) {
         float dv[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-        test = dot3(dv, dv) <= lk.p_bound[ps] * lk.p_bound[ps];
+        test = dot3(dv, dv) <= bound * bound;
       }
       if (test) {
+        const float s1[3] = {m.geom_size[g1][0], m.geom_size[g1][1], m.geom_size[g1][2]};
+        const float s2[3] = {m.geom_size[g2][0], m.geom_size[g2][1], m.geom_size[g2][2]};
         if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_CAPSULE) col_plane_capsule(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_BOX) col_plane_box(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_CAPSULE) col_capsule_capsule(p1, R1, s1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_BOX) col_capsule_box(p1, R1, s1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX) col_box_box(p1, R1, s1, p2, R2, s2, lc);
         else if (t2 == HOIC_GEOM_MESH) {
-          if (t1 == HOIC_GEOM_CAPSULE) col_capsule_mesh(m, p1, R1, s1, p2, R2, lk.p_mesh[ps], lc);
-          else if (t1 == HOIC_GEOM_BOX) col_box_mesh(m, p1, R1, s1, p2, R2, lk.p_mesh[ps], lc);
-          else if (t1 == HOIC_GEOM_PLANE) col_plane_mesh(m, p1, R1, p2, R2, lk.p_mesh[ps], lc);
+          const int mesh = m.pair_mesh[p];
+          if (t1 == HOIC_GEOM_CAPSULE) col_capsule_mesh(m, p1, R1, s1, p2, R2, mesh, lc);
+          else if (t1 == HOIC_GEOM_BOX) col_box_mesh(m, p1, R1, s1, p2, R2, mesh, lc);
+          else if (t1 == HOIC_GEOM_PLANE) col_plane_mesh(m, p1, R1, p2, R2, mesh, lc);
         }
       }
       // margin filter
       int k2 = 0;
       for (int q = 0; q < lc.n; q++)
-        if (lc.dist[q] < lk.p_margin[ps]) {
+        if (lc.dist[q] < margin) {
           if (k2 != q) { lc.dist[k2] = lc.dist[q]; for (int i = 0; i < 3; i++) { lc.pos[k2][i] = lc.pos[q][i]; lc.nrm[k2][i] = lc.nrm[q][i]; } }
           k2++;
         }
@@ -490,7 +493,7 @@ __device__ void dev_collision(const DevModel& m, const LaneK& lk, Work& w, int* 
     for (int q = 0; q < lc.n; q++) {
       const int c = start + q;
       if (c < MAXCON) {
-        w.c_dist[c] = lc.dist[q]; w.c_pair[c] = p;
+        w.c_dist[c] = lc.dist[q]; w.c_pair[c] = (unsigned char)p; w.c_g1[c] = (unsigned char)g1; w.c_g2[c] = (unsigned char)g2;
         for (int i = 0; i < 3; i++) { w.c_pos[c][i] = lc.pos[q][i]; w.c_frame[c][i] = lc.nrm[q][i]; }
         make_frame(w.c_frame[c]);
       }

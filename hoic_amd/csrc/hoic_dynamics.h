@@ -3,127 +3,105 @@
 // Replaces the position/velocity stages of mj_forward that the reference runs through
 // self.sim.step() / self.sim.forward() (uhc/envs/ho_im4.py:545, mujoco_env.py:114): kinematics,
 // mass matrix (data.qM, read back by ho_im4.py:398) and qfrc_bias (ho_im4.py:401).
-// Design: lanes = bodies walked level by level down the kinematic tree; subtree sums use the
-// depth-first body order (a subtree is an index range), so no atomics and no recursion.
+//
+// Design (no level-by-level tree walks: every stage is a fixed number of wave-wide steps):
+//   * kinematics: every body lane builds its transform relative to its parent, three pointer-jumping rounds
+//     compose them into world poses;
+//   * velocities / velocity-product accelerations are masked sums over the dofs on a body's path (motion axes
+//     are expressed about the world origin, so spatial vectors of different bodies simply add);
+//   * subtree sums use the depth-first body order (a subtree is an index range): no atomics, no recursion;
+//   * the joint-space inertia matrix is produced one row per lane, in registers (MReg).
 // Spatial vectors are [angular; linear-at-world-origin].
 #pragma once
 #include "hoic_types.h"
 #include "hoic_math.h"
 
-// ---- one-time load of the lane-resident constants and of the joint tables kept in LDS
-__device__ void dev_load_constants(const DevModel& m, Work& w, LaneK& lk) {
-  const int tid = threadIdx.x;
-  const int b = tid < m.nbody ? tid : 0;
-  lk.b_parent = m.body_parent[b]; lk.b_depth = tid < m.nbody ? m.body_depth[b] : -1; lk.b_jntadr = m.body_jntadr[b];
-  lk.b_jntnum = m.body_jntnum[b]; lk.b_dofadr = m.body_dofadr[b]; lk.b_dofnum = m.body_dofnum[b];
-  lk.b_subtree = m.body_subtree[b]; lk.b_mask = m.body_dofmask[b];
-  for (int i = 0; i < 3; i++) { lk.b_pos[i] = m.body_pos[b][i]; lk.b_ipos[i] = m.body_ipos[b][i]; lk.b_inertia[i] = m.body_inertia[b][i]; }
-  for (int i = 0; i < 4; i++) { lk.b_quat[i] = m.body_quat[b][i]; lk.b_iquat[i] = m.body_iquat[b][i]; }
-  lk.b_mass = m.body_mass[b];
-  const int g = (tid >= 32 && tid - 32 < m.ngeom) ? tid - 32 : 0;
-  lk.g_body = m.geom_bodyid[g];
-  for (int i = 0; i < 3; i++) lk.g_pos[i] = m.geom_pos[g][i];
-  for (int i = 0; i < 4; i++) lk.g_quat[i] = m.geom_quat[g][i];
-  const int d = tid < m.nv ? tid : 0;
-  lk.d_body = m.dof_bodyid[d]; lk.d_jnt = m.dof_jntid[d]; lk.d_jtype = m.jnt_type[lk.d_jnt]; lk.d_k = d - m.jnt_dofadr[lk.d_jnt];
-  lk.d_arm = m.dof_armature[d]; lk.d_damp = m.dof_damping[d]; lk.d_floss = m.dof_frictionloss[d]; lk.d_flR = m.dof_flR[d]; lk.d_flB = m.dof_flB[d];
-  lk.d_act = -1;
-  for (int u = 0; u < m.nu; u++) if (m.act_dofid[u] == d) lk.d_act = u;
-  const int j = tid < m.njnt ? tid : 0;
-  lk.j_type = m.jnt_type[j]; lk.j_qadr = m.jnt_qposadr[j]; lk.j_dadr = m.jnt_dofadr[j];
-  lk.j_limited = (tid < m.njnt) ? m.jnt_limited[j] : 0;
-  lk.j_lo = m.jnt_range[j][0]; lk.j_hi = m.jnt_range[j][1]; lk.j_margin = m.jnt_margin[j]; lk.j_K = m.jnt_K[j]; lk.j_B = m.jnt_B[j];
-  lk.j_diag = m.jnt_diag[j];
-  for (int i = 0; i < 5; i++) lk.j_solimp[i] = m.jnt_solimp[j][i];
-  for (int ps = 0; ps < 2; ps++) {
-    const int p = ps * NT + tid, pp = p < m.npair ? p : 0;
-    const int g1 = m.pair_geom1[pp], g2 = m.pair_geom2[pp];
-    lk.p_g1[ps] = g1; lk.p_g2[ps] = g2; lk.p_t1[ps] = p < m.npair ? m.geom_type[g1] : -1; lk.p_t2[ps] = m.geom_type[g2];
-    for (int i = 0; i < 3; i++) { lk.p_s1[ps][i] = m.geom_size[g1][i]; lk.p_s2[ps][i] = m.geom_size[g2][i]; }
-    lk.p_mesh[ps] = m.geom_meshid[g2];
-    lk.p_margin[ps] = m.pair_margin[pp];
-    lk.p_bound[ps] = m.geom_rbound[g1] + m.geom_rbound[g2] + m.pair_margin[pp];
-  }
-  for (int r = 0; r < 4; r++) {
-    const int e = tid + r * NT;
-    if (e < m.nM) { lk.m_i[r] = m.mi[e]; lk.m_j[r] = m.mj[e]; lk.m_arm[r] = (lk.m_i[r] == lk.m_j[r]) ? m.dof_armature[lk.m_i[r]] : 0.f; }
-    else { lk.m_i[r] = -1; lk.m_j[r] = 0; lk.m_arm[r] = 0.f; }
-  }
-  if (tid < m.njnt) {
-    for (int i = 0; i < 3; i++) { w.k_jaxis[tid][i] = m.jnt_axis[tid][i]; w.k_jpos[tid][i] = m.jnt_pos[tid][i]; }
-    w.k_jq0[tid] = m.qpos0[m.jnt_qposadr[tid]];
-    w.k_jtype[tid] = (unsigned char)m.jnt_type[tid]; w.k_jqadr[tid] = (unsigned char)m.jnt_qposadr[tid];
-  }
-  if (tid < NB) w.k_bmask[tid] = tid < m.nbody ? m.body_dofmask[tid] : 0u;
-  __syncthreads();
+// per-dof constants pinned in registers for the launch (lane & 31 = dof); everything else is re-read from DevModel
+__device__ void dev_load_constants(const DevModel& m, DofK& dk) {
+  const int d = threadIdx.x & 31;
+  const bool v = d < m.nv;
+  dk.arm = v ? m.dof_armature[d] : 0.f; dk.damp = v ? m.dof_damping[d] : 0.f; dk.floss = v ? m.dof_frictionloss[d] : 0.f;
+  dk.flR = v ? m.dof_flR[d] : 1.f; dk.flB = v ? m.dof_flB[d] : 0.f; dk.act = v ? m.dof_actid[d] : -1;
 }
 
-// ---- kinematics: body frames, joint anchors/axes, geoms, motion axes S, body inertias about the origin
-__device__ void dev_kinematics(const DevModel& m, const LaneK& lk, Work& w, const float* q) {
+// ---- kinematics: body frames, geoms, motion axes S, body inertias about the origin
+__device__ void dev_kinematics(const DevModel& m, Work& w, const float* q) {
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    w.xpos[0][0] = w.xpos[0][1] = w.xpos[0][2] = 0.f;
-    w.xquat[0][0] = 1.f; w.xquat[0][1] = w.xquat[0][2] = w.xquat[0][3] = 0.f;
-    for (int i = 0; i < 9; i++) w.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f;
+  const bool isb = tid < m.nbody;
+  float P[3] = {0.f, 0.f, 0.f}, Q[4] = {1.f, 0.f, 0.f, 0.f};
+  // 1. transform of each body relative to its parent, with the joint axes / anchors in the parent frame
+  if (isb) {
+    const int b = tid, ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+    for (int i = 0; i < 3; i++) P[i] = m.body_pos[b][i];
+    for (int i = 0; i < 4; i++) Q[i] = m.body_quat[b][i];
+    for (int j = ja; j < ja + jn; j++) {
+      const int ty = m.jnt_type[j], qa = m.jnt_qposadr[j];
+      if (ty == HOIC_JNT_FREE) {
+        for (int i = 0; i < 3; i++) P[i] = q[qa + i];
+        for (int i = 0; i < 4; i++) Q[i] = q[qa + 3 + i];
+        normquat(Q);
+      } else {
+        const float jax[3] = {m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]};
+        const float jps[3] = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
+        float ax[3], t[3], an[3];
+        qrot(Q, jax, ax); qrot(Q, jps, t);
+        for (int i = 0; i < 3; i++) { an[i] = P[i] + t[i]; w.sc.dyn.u.j.jax[j][i] = ax[i]; w.sc.dyn.u.j.janc[j][i] = an[i]; }
+        const float qq = q[qa] - m.qpos0[qa];
+        if (ty == HOIC_JNT_SLIDE) {
+          for (int i = 0; i < 3; i++) P[i] += ax[i] * qq;
+        } else {
+          float sn, cs;
+          sincos_pi(0.5f * qq, &sn, &cs);
+          const float ql[4] = {cs, sn * jax[0], sn * jax[1], sn * jax[2]};
+          float qn[4];
+          mulquat(Q, ql, qn);
+          for (int i = 0; i < 4; i++) Q[i] = qn[i];
+          qrot(Q, jps, t);
+          for (int i = 0; i < 3; i++) P[i] = an[i] - t[i];
+        }
+      }
+    }
+    normquat(Q);
+    for (int i = 0; i < 3; i++) w.xpos[b][i] = P[i];
+    for (int i = 0; i < 4; i++) w.xquat[b][i] = Q[i];
   }
   __syncthreads();
-  for (int lev = 1; lev <= m.nlevel; lev++) {
-    if (lk.b_depth == lev) {
-      const int b = tid, p = lk.b_parent, ja = lk.b_jntadr, jn = lk.b_jntnum;
-      float pos[3], quat[4], R[9], t[3];
-      if (jn == 1 && w.k_jtype[ja] == HOIC_JNT_FREE) {
-        const int qa = w.k_jqadr[ja];
-        for (int i = 0; i < 3; i++) pos[i] = q[qa + i];
-        for (int i = 0; i < 4; i++) quat[i] = q[qa + 3 + i];
-        normquat(quat);
-        quat2mat(quat, R);
-        for (int i = 0; i < 3; i++) { w.xanchor[ja][i] = pos[i]; w.xaxis[ja][i] = R[3 * i + 2]; }
-      } else {
-        matvec(w.xmat[p], lk.b_pos, t);
-        for (int i = 0; i < 3; i++) pos[i] = w.xpos[p][i] + t[i];
-        mulquat(w.xquat[p], lk.b_quat, quat);
-        quat2mat(quat, R);
-        for (int j = ja; j < ja + jn; j++) {
-          const float jax[3] = {w.k_jaxis[j][0], w.k_jaxis[j][1], w.k_jaxis[j][2]};
-          const float jps[3] = {w.k_jpos[j][0], w.k_jpos[j][1], w.k_jpos[j][2]};
-          matvec(R, jps, t);
-          float anchor[3], axis[3];
-          for (int i = 0; i < 3; i++) anchor[i] = pos[i] + t[i];
-          matvec(R, jax, axis);
-          for (int i = 0; i < 3; i++) { w.xanchor[j][i] = anchor[i]; w.xaxis[j][i] = axis[i]; }
-          const float qq = q[w.k_jqadr[j]] - w.k_jq0[j];
-          if (w.k_jtype[j] == HOIC_JNT_SLIDE) {
-            for (int i = 0; i < 3; i++) pos[i] += axis[i] * qq;
-          } else {
-            float sn, cs;
-            sincosf(0.5f * qq, &sn, &cs);
-            float ql[4] = {cs, sn * jax[0], sn * jax[1], sn * jax[2]}, qn[4];
-            mulquat(quat, ql, qn);
-            for (int i = 0; i < 4; i++) quat[i] = qn[i];
-            quat2mat(quat, R);
-            matvec(R, jps, t);
-            for (int i = 0; i < 3; i++) pos[i] = anchor[i] - t[i];
-          }
-        }
-        normquat(quat);
-        quat2mat(quat, R);
-      }
-      for (int i = 0; i < 3; i++) w.xpos[b][i] = pos[i];
-      for (int i = 0; i < 4; i++) w.xquat[b][i] = quat[i];
-      for (int i = 0; i < 9; i++) w.xmat[b][i] = R[i];
+  // 2. pointer jumping: after round r a body's transform is relative to its ancestor 2^(r+1) levels up
+  for (int r = 0; r < m.nround; r++) {
+    const int src = isb ? m.body_jump[r][tid] : -1;
+    if (src >= 0) {
+      float Ps[3], Qs[4], t[3], qn[4];
+      for (int i = 0; i < 3; i++) Ps[i] = w.xpos[src][i];
+      for (int i = 0; i < 4; i++) Qs[i] = w.xquat[src][i];
+      qrot(Qs, P, t);
+      for (int i = 0; i < 3; i++) P[i] = Ps[i] + t[i];
+      mulquat(Qs, Q, qn);
+      for (int i = 0; i < 4; i++) Q[i] = qn[i];
+    }
+    __syncthreads();
+    if (src >= 0) {
+      for (int i = 0; i < 3; i++) w.xpos[tid][i] = P[i];
+      for (int i = 0; i < 4; i++) w.xquat[tid][i] = Q[i];
     }
     __syncthreads();
   }
+  if (isb) {
+    normquat(Q);
+    for (int i = 0; i < 4; i++) w.xquat[tid][i] = Q[i];
+  }
+  __syncthreads();
   PT(21);
-  // per body: inertial frame and spatial inertia about the world origin (m, h = m c, Io: xx yy zz xy xz yz)
-  if (tid < m.nbody) {
+  // 3a. per body: spatial inertia about the world origin (m, h = m c, Io: xx yy zz xy xz yz)
+  if (isb) {
     const int b = tid;
+    const float ip[3] = {m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]};
+    const float iq[4] = {m.body_iquat[b][0], m.body_iquat[b][1], m.body_iquat[b][2], m.body_iquat[b][3]};
     float c[3], t[3], qi[4], Ri[9];
-    matvec(w.xmat[b], lk.b_ipos, t);
-    for (int i = 0; i < 3; i++) { c[i] = w.xpos[b][i] + t[i]; w.xipos[b][i] = c[i]; }
-    mulquat(w.xquat[b], lk.b_iquat, qi);
+    qrot(Q, ip, t);
+    for (int i = 0; i < 3; i++) c[i] = P[i] + t[i];
+    mulquat(Q, iq, qi);
     quat2mat(qi, Ri);
-    const float mass = lk.b_mass, p0 = lk.b_inertia[0], p1 = lk.b_inertia[1], p2 = lk.b_inertia[2];
+    const float mass = m.body_mass[b], p0 = m.body_inertia[b][0], p1 = m.body_inertia[b][1], p2 = m.body_inertia[b][2];
     float Ic[6];  // xx yy zz xy xz yz about the centre of mass
     Ic[0] = Ri[0] * p0 * Ri[0] + Ri[1] * p1 * Ri[1] + Ri[2] * p2 * Ri[2];
     Ic[1] = Ri[3] * p0 * Ri[3] + Ri[4] * p1 * Ri[4] + Ri[5] * p2 * Ri[5];
@@ -137,37 +115,49 @@ __device__ void dev_kinematics(const DevModel& m, const LaneK& lk, Work& w, cons
     I[4] = Ic[0] + mass * (cc - c[0] * c[0]); I[5] = Ic[1] + mass * (cc - c[1] * c[1]); I[6] = Ic[2] + mass * (cc - c[2] * c[2]);
     I[7] = Ic[3] - mass * c[0] * c[1]; I[8] = Ic[4] - mass * c[0] * c[2]; I[9] = Ic[5] - mass * c[1] * c[2];
   }
-  PT(22);
-  // per geom (second half-wave so it overlaps the body work)
-  {
-    const int g = tid - 32;
-    if (g >= 0 && g < m.ngeom) {
-      const int b = lk.g_body;
-      float t[3], qg[4];
-      matvec(w.xmat[b], lk.g_pos, t);
-      for (int i = 0; i < 3; i++) w.gxpos[g][i] = w.xpos[b][i] + t[i];
-      mulquat(w.xquat[b], lk.g_quat, qg);
-      quat2mat(qg, w.gxmat[g]);
-    }
-  }
-  // per dof: motion axis about the origin
+  // 3b. per dof: motion axis about the origin (the joint frames of step 1 moved to the world by the parent pose)
   if (tid < m.nv) {
-    const int d = tid, j = lk.d_jnt, ty = lk.d_jtype;
+    const int d = tid, j = m.dof_jntid[d], ty = m.jnt_type[j], b = m.dof_bodyid[d];
     float* S = w.S[d];
-    if (ty == HOIC_JNT_SLIDE) {
-      S[0] = S[1] = S[2] = 0.f;
-      for (int i = 0; i < 3; i++) S[3 + i] = w.xaxis[j][i];
-    } else if (ty == HOIC_JNT_HINGE) {
-      for (int i = 0; i < 3; i++) S[i] = w.xaxis[j][i];
-      cross3(w.xanchor[j], w.xaxis[j], S + 3);
-    } else {
-      const int kk = lk.d_k, b = lk.d_body;
-      if (kk < 3) { for (int i = 0; i < 6; i++) S[i] = 0.f; S[3 + kk] = 1.f; }
+    if (ty == HOIC_JNT_FREE) {
+      const int kk = d - m.jnt_dofadr[j];
+      if (kk < 3) { for (int i = 0; i < 6; i++) S[i] = (i == 3 + kk) ? 1.f : 0.f; }
       else {
-        float ax[3] = {w.xmat[b][kk - 3], w.xmat[b][3 + kk - 3], w.xmat[b][6 + kk - 3]};
+        const float e[3] = {kk == 3 ? 1.f : 0.f, kk == 4 ? 1.f : 0.f, kk == 5 ? 1.f : 0.f};
+        float ax[3];
+        qrot(w.xquat[b], e, ax);
         for (int i = 0; i < 3; i++) S[i] = ax[i];
         cross3(w.xpos[b], ax, S + 3);
       }
+    } else {
+      const int p = m.body_parent[b];
+      const float la[3] = {w.sc.dyn.u.j.jax[j][0], w.sc.dyn.u.j.jax[j][1], w.sc.dyn.u.j.jax[j][2]};
+      float ax[3];
+      qrot(w.xquat[p], la, ax);
+      if (ty == HOIC_JNT_SLIDE) {
+        for (int i = 0; i < 3; i++) { S[i] = 0.f; S[3 + i] = ax[i]; }
+      } else {
+        const float lc[3] = {w.sc.dyn.u.j.janc[j][0], w.sc.dyn.u.j.janc[j][1], w.sc.dyn.u.j.janc[j][2]};
+        float an[3];
+        qrot(w.xquat[p], lc, an);
+        for (int i = 0; i < 3; i++) { an[i] += w.xpos[p][i]; S[i] = ax[i]; }
+        cross3(an, ax, S + 3);
+      }
+    }
+  }
+  PT(22);
+  // 3c. per geom (upper half-wave)
+  {
+    const int g = tid - 32;
+    if (g >= 0 && g < m.ngeom) {
+      const int b = m.geom_bodyid[g];
+      const float gp[3] = {m.geom_pos[g][0], m.geom_pos[g][1], m.geom_pos[g][2]};
+      const float gq[4] = {m.geom_quat[g][0], m.geom_quat[g][1], m.geom_quat[g][2], m.geom_quat[g][3]};
+      float t[3], qg[4];
+      qrot(w.xquat[b], gp, t);
+      for (int i = 0; i < 3; i++) w.gxpos[g][i] = w.xpos[b][i] + t[i];
+      mulquat(w.xquat[b], gq, qg);
+      quat2mat(qg, w.gxmat[g]);
     }
   }
   __syncthreads();
@@ -183,31 +173,43 @@ HD void inert_mul(const float* I, const float* v, float* f) {
   f[3] = I[0] * vo[0] + wxh[0]; f[4] = I[0] * vo[1] + wxh[1]; f[5] = I[0] * vo[2] + wxh[2];
 }
 
-// ---- joint-space inertia: composite rigid body sums over index ranges, then the tree-sparse entries of M
-__device__ void dev_mass_matrix(const DevModel& m, const LaneK& lk, Work& w) {
+// ---- joint-space inertia: composite rigid body sums over index ranges, then row (lane & 31) of M in registers:
+// M[i][j] = S_j . (Ic_body(i) S_i) for j an ancestor-or-self dof of i, mirrored for descendants, 0 elsewhere
+__device__ void dev_mass_matrix(const DevModel& m, Work& w, const DofK& dk, MReg& M) {
   const int tid = threadIdx.x;
   if (tid < m.nbody) {
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
-    const int e = tid + lk.b_subtree;
+    const int e = tid + m.body_subtree[tid];
     for (int b = tid; b < e; b++)
       for (int i = 0; i < 10; i++) acc[i] += w.sc.dyn.I10[b][i];
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
+  __syncthreads();   // (also: the joint frames in sc.dyn.u.j are dead from here on, u.f takes their place)
+  const int d = tid & 31;
+  const bool vd = d < m.nv;
+  float Si[6], fSi[6];
+  for (int i = 0; i < 6; i++) { Si[i] = vd ? w.S[d][i] : 0.f; fSi[i] = 0.f; }
+  if (vd) inert_mul(w.sc.dyn.Ic[m.dof_bodyid[d]], Si, fSi);
+  if (tid < 32) for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[d][i] = fSi[i];
   __syncthreads();
-  if (tid < m.nv) inert_mul(w.sc.dyn.Ic[lk.d_body], w.S[tid], w.sc.dyn.fS[tid]);
-  __syncthreads();
+  const unsigned am = vd ? (m.dof_amask[d] | (1u << d)) : 0u, dm = vd ? m.dof_dmask[d] : 0u;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int i = lk.m_i[r], j = lk.m_j[r];
-    if (i >= 0) {
-      float v = lk.m_arm[r];
-      for (int c = 0; c < 6; c++) v += w.S[j][c] * w.sc.dyn.fS[i][c];
-      w.M[i * LD + j] = v;
-      w.M[j * LD + i] = v;
-    }
+  for (int j = 0; j < NV; j++) {
+    const float a = dot6(w.S[j], fSi), bb = dot6(Si, w.sc.dyn.u.f.fS[j]);   // uniform addresses: LDS broadcasts
+    float v = ((am >> j) & 1u) ? a : (((dm >> j) & 1u) ? bb : 0.f);
+    if (j == d) v += dk.arm;
+    M.r[j] = v;
   }
   __syncthreads();
+}
+
+// out = (M x)[lane & 31], x in LDS (uniform reads)
+HD float dev_Mx(const MReg& M, const float* x) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) { s0 = fmaf(M.r[k], x[k], s0); s1 = fmaf(M.r[k + 1], x[k + 1], s1); }
+  return s0 + s1;
 }
 
 HD void cross_motion(const float* v, const float* s, float* o) {
@@ -221,57 +223,64 @@ HD void cross_force(const float* v, const float* f, float* o) {
   o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
 }
 
-// ---- bias forces (Coriolis, centrifugal, gravity): recursive Newton-Euler with zero joint acceleration
-__device__ void dev_bias(const DevModel& m, const LaneK& lk, Work& w, const float* qvel) {
+// ---- bias forces (Coriolis, centrifugal, gravity): Newton-Euler with zero joint acceleration, without a tree walk:
+//   cdd_d = (velocity of the chain above dof d) x S_d * qvel_d          (lane = dof)
+//   V_b = sum_{d on path(b)} S_d qvel_d,  A_b = a_world + sum cdd_d       (lane = body)
+//   f_b = I_b A_b + V_b x* I_b V_b;  subtree range sums;  bias_d = S_d . fsub_body(d)
+__device__ void dev_bias(const DevModel& m, Work& w, const float* qvel) {
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    for (int i = 0; i < 6; i++) { w.sc.dyn.cvel[0][i] = 0.f; w.sc.dyn.cacc[0][i] = 0.f; w.sc.dyn.cfrc[0][i] = 0.f; }
-    for (int i = 0; i < 3; i++) w.sc.dyn.cacc[0][3 + i] = -m.gravity[i];
+  if (tid < m.nv) {
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sd[6];
+    unsigned mk = m.dof_amask[tid];
+    while (mk) {
+      const int e = __ffs(mk) - 1;
+      mk &= mk - 1;
+      const float qd = qvel[e];
+#pragma unroll
+      for (int i = 0; i < 6; i++) v[i] = fmaf(w.S[e][i], qd, v[i]);
+    }
+    cross_motion(v, w.S[tid], sd);
+    const float qd = qvel[tid];
+    for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[tid][i] = sd[i] * qd;
   }
   __syncthreads();
-  for (int lev = 1; lev <= m.nlevel; lev++) {
-    if (lk.b_depth == lev) {
-      const int b = tid, p = lk.b_parent;
-      float v[6], a[6];
-      for (int i = 0; i < 6; i++) { v[i] = w.sc.dyn.cvel[p][i]; a[i] = w.sc.dyn.cacc[p][i]; }
-      const int da = lk.b_dofadr;
-      for (int kk = 0; kk < lk.b_dofnum; kk++) {
-        const int dd = da + kk;
-        float sd[6];
-        const float qd = qvel[dd];
-        cross_motion(v, w.S[dd], sd);
-        for (int i = 0; i < 6; i++) { a[i] += sd[i] * qd; v[i] += w.S[dd][i] * qd; }
+  if (tid < m.nbody) {
+    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned mk = m.body_dofmask[tid];
+    if (mk) {
+      float V[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, A[6] = {0.f, 0.f, 0.f, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+      while (mk) {
+        const int e = __ffs(mk) - 1;
+        mk &= mk - 1;
+        const float qd = qvel[e];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { V[i] = fmaf(w.S[e][i], qd, V[i]); A[i] += w.sc.dyn.u.f.fS[e][i]; }
       }
       float Iv[6], Ia[6], x[6];
-      inert_mul(w.sc.dyn.I10[b], v, Iv); inert_mul(w.sc.dyn.I10[b], a, Ia); cross_force(v, Iv, x);
-      for (int i = 0; i < 6; i++) { w.sc.dyn.cvel[b][i] = v[i]; w.sc.dyn.cacc[b][i] = a[i]; w.sc.dyn.cfrc[b][i] = Ia[i] + x[i]; }
+      inert_mul(w.sc.dyn.I10[tid], V, Iv); inert_mul(w.sc.dyn.I10[tid], A, Ia); cross_force(V, Iv, x);
+      for (int i = 0; i < 6; i++) f[i] = Ia[i] + x[i];
     }
-    __syncthreads();
-  }
-  // subtree force sums (range sums again), then project on the motion axes
-  float sub[6] = {0, 0, 0, 0, 0, 0};
-  if (tid < m.nbody) {
-    const int e = tid + lk.b_subtree;
-    for (int b = tid; b < e; b++)
-      for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.cfrc[b][i];
+    for (int i = 0; i < 6; i++) w.sc.dyn.u.f.cfrc[tid][i] = f[i];
   }
   __syncthreads();
-  if (tid < m.nbody) for (int i = 0; i < 6; i++) w.sc.dyn.cacc[tid][i] = sub[i];  // reuse cacc as subtree force
-  __syncthreads();
-  if (tid < m.nv) {
-    const int b = lk.d_body;
-    float s = 0.f;
-    for (int i = 0; i < 6; i++) s += w.S[tid][i] * w.sc.dyn.cacc[b][i];
-    w.bias[tid] = s;
-    w.passive[tid] = -lk.d_damp * qvel[tid];
+  if (tid < m.nbody) {   // subtree force sums (range sums again), kept in the Ic slots
+    float sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m.body_dofnum[tid] > 0) {
+      const int e = tid + m.body_subtree[tid];
+      for (int b = tid; b < e; b++)
+        for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.u.f.cfrc[b][i];
+    }
+    for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
   }
+  __syncthreads();
+  if (tid < NV) w.bias[tid] = (tid < m.nv) ? dot6(w.S[tid], w.sc.dyn.Ic[m.dof_bodyid[tid]]) : 0.f;
   __syncthreads();
 }
 
 // J^T (f at point, torque) of a body into qfrc, with the kinematics currently in the workspace (mj_applyFT,
 // call sites uhc/envs/ho_im4.py:492-500,527-535)
-HD float dev_apply_ft_dof(const Work& w, int dof, int body, const float* f, const float* tq, const float* point) {
-  if (!((w.k_bmask[body] >> dof) & 1u)) return 0.f;
+HD float dev_apply_ft_dof(const DevModel& m, const Work& w, int dof, int body, const float* f, const float* tq, const float* point) {
+  if (!((m.body_dofmask[body] >> dof) & 1u)) return 0.f;
   float wxp[3];
   cross3(w.S[dof], point, wxp);
   float r = 0.f;

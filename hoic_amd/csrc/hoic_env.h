@@ -23,44 +23,43 @@ struct ExpertView {
   }
 };
 
-// ---- position + velocity stages of the forward pass on state (q, v); leaves M, bias, contacts, S in LDS
-__device__ void dev_forward_kin(const DevModel& m, const LaneK& lk, Work& w, const float* q, const float* v, int* overflow) {
-  dev_kinematics(m, lk, w, q); PT(3);
-  dev_mass_matrix(m, lk, w); PT(4);
-  dev_bias(m, lk, w, v); PT(5);
-  dev_collision(m, lk, w, overflow); PT(6);
+// ---- position + velocity stages of the forward pass on state (q, v); leaves M (registers), bias, contacts, S
+__device__ void dev_forward_kin(const DevModel& m, Work& w, const DofK& dk, MReg& M, const float* q, const float* v, int* overflow) {
+  dev_kinematics(m, w, q); PT(3);
+  dev_mass_matrix(m, w, dk, M); PT(4);
+  dev_bias(m, w, v); PT(5);
+  dev_collision(m, w, overflow); PT(6);
 }
 
-// ---- stable PD torque (ho_im4.py:412-486) using M and bias currently in LDS (i.e. lagged)
-__device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const ExpertView& ev) {
-  const int tid = threadIdx.x, n = m.hand_nv;
+// ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass
+__device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev) {
+  const int tid = threadIdx.x, d = tid & 31, n = m.hand_nv;
   const float dt = m.timestep;
-  float err = 0.f, kp = 0.f, kd = 0.f;
-  if (tid < n) {
+  float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
+  if (d < n) {
     const float* ref = ev.ex->hand_dof + (size_t)ev.frame(0) * m.hand_nq;
     float target;
-    if (tid < 3) target = ref[tid] + 0.1f * w.action[tid];
-    else if (tid < 6) target = ref[tid] + 0.3f * w.action[tid];
-    else target = (cfg.c.pd_rel ? ref[tid] : cfg.base_pose[tid]) + cfg.ctrl_scale[tid] * w.action[tid];
-    err = w.qpos[tid] + w.qvel[tid] * dt - target;
-    if (tid >= 3) {
+    const float a = w.action[d];
+    if (d < 3) target = ref[d] + 0.1f * a;
+    else if (d < 6) target = ref[d] + 0.3f * a;
+    else target = (cfg.c.pd_rel ? ref[d] : cfg.base_pose[d]) + cfg.ctrl_scale[d] * a;
+    qv = w.qvel[d];
+    err = w.qpos[d] + qv * dt - target;
+    if (d >= 3) {
       while (err > 3.14159265358979f) err -= 6.28318530717959f;
       while (err < -3.14159265358979f) err += 6.28318530717959f;
     }
-    kp = cfg.c.jkp[tid]; kd = cfg.c.jkd[tid];
+    kp = cfg.c.jkp[d]; kd = cfg.c.jkd[d];
+    rhs = -w.bias[d] - kp * err - kd * qv;
   }
-  if (tid < NV) {
-    w.tv2[tid] = kd * dt;
-    w.tv[tid] = (tid < n) ? (-w.bias[tid] - kp * err - kd * w.qvel[tid]) : 0.f;
-  }
-  __syncthreads();
   PT(20);
-  dev_hsolve(m, w, w.tv2, n, false, w.tv);
+  const float acc = dev_hsolve(m, w, M, kd * dt, n, false, rhs);
   if (tid < NV) {
     float tq = 0.f;
     if (tid < n) {
-      tq = -kp * err - kd * (w.qvel[tid] + w.tv[tid] * dt);
-      tq = fminf(fmaxf(tq, -cfg.c.torque_lim[tid]), cfg.c.torque_lim[tid]);
+      tq = -kp * err - kd * (qv + acc * dt);
+      const float lim = cfg.c.torque_lim[tid];
+      tq = fminf(fmaxf(tq, -lim), lim);
     }
     w.ctrl[tid] = tq;
   }
@@ -74,8 +73,8 @@ __device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, co
     float s = 0.f;
     if (tid < m.nv) {
       const float f[3] = {0.f, 0.f, m.hand_mass * 9.8f}, z[3] = {0.f, 0.f, 0.f};
-      s = dev_apply_ft_dof(w, tid, 3, f, z, w.gxpos[2]);                       // ho_im4.py:527-535
-      if (cfg.c.residual_force) s += dev_apply_ft_dof(w, tid, m.obj_body, vf, vt, &w.qpos[m.hand_nq]);  // :492-500
+      s = dev_apply_ft_dof(m, w, tid, 3, f, z, w.gxpos[2]);                       // ho_im4.py:527-535
+      if (cfg.c.residual_force) s += dev_apply_ft_dof(m, w, tid, m.obj_body, vf, vt, &w.qpos[m.hand_nq]);  // :492-500
     }
     w.applied[tid] = s;
   }
@@ -88,7 +87,7 @@ __device__ void dev_record_contact(const DevModel& m, Work& w) {
   if (tid < NHG) {
     const int g = m.hand_geom0 + tid;
     for (int c = 0; c < w.ncon; c++) {
-      const int p = w.c_pair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+      const int g1 = w.c_g1[c], g2 = w.c_g2[c];
       if (g1 == g && g2 >= m.obj_geom0 && g2 <= m.obj_geom1) {
         for (int i = 0; i < 3; i++) w.rec_sum[tid][i] += w.c_pos[c][i];
         for (int i = 0; i < 9; i++) w.rec_sum[tid][3 + i] += w.c_frame[c][i];
@@ -124,7 +123,7 @@ __device__ void dev_classify_contact(const DevModel& m, Work& w) {
   const bool has = tid < NHG && w.rec_cnt[tid] > 0;
   const unsigned long long mask = __ballot(has);
   const int idx = __popcll(mask & ((1ull << tid) - 1ull));
-  if (tid == 0) w.n_avg = __popcll(mask);
+  if (tid == 0) w.sc.post.n_avg = __popcll(mask);
   if (has) {
     float f[12];
     const float inv = 1.f / (float)w.rec_cnt[tid];
@@ -139,9 +138,9 @@ __device__ void dev_classify_contact(const DevModel& m, Work& w) {
     cross3(n, t1, t2);
     tn = 1.f / sqrtf(dot3(t2, t2));
     for (int i = 0; i < 3; i++) t2[i] *= tn;
-    for (int i = 0; i < 12; i++) w.avg_cps[idx][i] = f[i];
-    w.avg_geom[idx] = tid + m.hand_geom0;
-    w.avg_ts[idx] = (float)w.rec_cnt[tid];
+    for (int i = 0; i < 12; i++) w.sc.post.avg_cps[idx][i] = f[i];
+    w.sc.post.avg_geom[idx] = tid + m.hand_geom0;
+    w.sc.post.avg_ts[idx] = (float)w.rec_cnt[tid];
   }
   __syncthreads();
 }
@@ -182,7 +181,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     for (int i = 0; i < 9; i++) Rm[i] = Rf[i];
   }
   double F[3], tau[3], I[9], ow[3], oa[3], ooa[3];
-  for (int i = 0; i < 3; i++) { ow[i] = w.gangvel[lastg][i]; oa[i] = w.obj_avg_acc[i]; ooa[i] = w.obj_avg_acc[3 + i]; }
+  for (int i = 0; i < 3; i++) { ow[i] = w.sc.post.gangvel[lastg][i]; oa[i] = w.sc.post.obj_avg_acc[i]; ooa[i] = w.sc.post.obj_avg_acc[3 + i]; }
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       double s = 0;
@@ -199,14 +198,14 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   tau[0] = Ioa[0] + ow[1] * Iw[2] - ow[2] * Iw[1];
   tau[1] = Ioa[1] + ow[2] * Iw[0] - ow[0] * Iw[2];
   tau[2] = Ioa[2] + ow[0] * Iw[1] - ow[1] * Iw[0];
-  if (w.n_avg == 0)
+  if (w.sc.post.n_avg == 0)
     return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + w_t * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
-  const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.n_avg * npt * 4;
+  const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.sc.post.n_avg * npt * 4;
   const double inv = 1.0 / sqrt(1.0 + mu * mu);
   double a[QPC][6], cc[QPC];
   bool valid[QPC];
   const double obj_p[3] = {w.qpos[nq - 7], w.qpos[nq - 6], w.qpos[nq - 5]};
-  const double obj_v[3] = {w.gvel[lastg][0], w.gvel[lastg][1], w.gvel[lastg][2]};
+  const double obj_v[3] = {w.sc.post.gvel[lastg][0], w.sc.post.gvel[lastg][1], w.sc.post.gvel[lastg][2]};
 #pragma unroll
   for (int jj = 0; jj < QPC; jj++) {
     const int col = tid + jj * NT;
@@ -215,17 +214,17 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     cc[jj] = 0.0;
     if (!valid[jj]) continue;
     const int pt = col >> 2, e = col & 3, ci = pt / npt, j = pt % npt;
-    const float* cp = w.avg_cps[ci];
+    const float* cp = w.sc.post.avg_cps[ci];
     double pos[3], fn[3], t1[3], t2[3];
     for (int i = 0; i < 3; i++) { pos[i] = cp[i]; fn[i] = cp[3 + i]; t1[i] = cp[6 + i]; t2[i] = cp[9 + i]; }
-    const int g1 = w.avg_geom[ci];
+    const int g1 = w.sc.post.avg_geom[ci];
     const double* dl = (j == 1 || j == 2) ? t1 : t2;
     const double sg = (j == 0) ? 0.0 : ((j & 1) ? dx : -dx);
     double p[3], crh[3], cro[3], rel[3], relt[3];
     for (int k = 0; k < 3; k++) { p[k] = pos[k] + sg * dl[k]; crh[k] = p[k] - (double)w.gxpos[g1][k]; cro[k] = p[k] - obj_p[k]; }
-    const double gw[3] = {w.gangvel[g1][0], w.gangvel[g1][1], w.gangvel[g1][2]};
-    const double cvh[3] = {w.gvel[g1][0] + gw[1] * crh[2] - gw[2] * crh[1], w.gvel[g1][1] + gw[2] * crh[0] - gw[0] * crh[2],
-                           w.gvel[g1][2] + gw[0] * crh[1] - gw[1] * crh[0]};
+    const double gw[3] = {w.sc.post.gangvel[g1][0], w.sc.post.gangvel[g1][1], w.sc.post.gangvel[g1][2]};
+    const double cvh[3] = {w.sc.post.gvel[g1][0] + gw[1] * crh[2] - gw[2] * crh[1], w.sc.post.gvel[g1][1] + gw[2] * crh[0] - gw[0] * crh[2],
+                           w.sc.post.gvel[g1][2] + gw[0] * crh[1] - gw[1] * crh[0]};
     const double cvo[3] = {obj_v[0] + ow[1] * cro[2] - ow[2] * cro[1], obj_v[1] + ow[2] * cro[0] - ow[0] * cro[2],
                            obj_v[2] + ow[0] * cro[1] - ow[1] * cro[0]};
     for (int k = 0; k < 3; k++) rel[k] = cvo[k] - cvh[k];
@@ -233,7 +232,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     const double vn = fn[0] * rel[0] + fn[1] * rel[1] + fn[2] * rel[2];
     for (int k = 0; k < 3; k++) relt[k] = rel[k] - vn * fn[k];
     const double nvn = fabs(vn) * sqrt(nn), nvt = sqrt(relt[0] * relt[0] + relt[1] * relt[1] + relt[2] * relt[2]);
-    const double ts = (double)w.avg_ts[pt / 5] / (double)cfg.c.sim_step;   // cp_ts[i // 5] quirk (:1012)
+    const double ts = (double)w.sc.post.avg_ts[pt / 5] / (double)cfg.c.sim_step;   // cp_ts[i // 5] quirk (:1012)
     const double d1 = relt[0] * t1[0] + relt[1] * t1[1] + relt[2] * t1[2], d2 = relt[0] * t2[0] + relt[1] * t2[1] + relt[2] * t2[2];
     const double dirs[4] = {-d1, d1, -d2, d2};
     int am = 0;

@@ -36,6 +36,32 @@ HD void normquat(float* q) {
   float inv = 1.f / n;
   q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
+// rotate v by the unit quaternion q:  v + 2 w (u x v) + 2 u x (u x v)
+HD void qrot(const float* q, const float* v, float* o) {
+  float t[3], c[3];
+  cross3(q + 1, v, t);
+  t[0] *= 2.f; t[1] *= 2.f; t[2] *= 2.f;
+  cross3(q + 1, t, c);
+  const float x = v[0] + q[0] * t[0] + c[0], y = v[1] + q[0] * t[1] + c[1], z = v[2] + q[0] * t[2] + c[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+// sin / cos with a three-term Cody-Waite reduction by pi/2 and the cephes minimax polynomials (about 1 ulp for
+// |x| < 100; joint half-angles stay below pi).  No slow path, no scratch: unlike sincosf this is a fixed
+// sequence of 25 VALU operations.
+HD void sincos_pi(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(k, -1.5703125f, x);
+  r = fmaf(k, -4.837512969970703125e-4f, r);
+  r = fmaf(k, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float s = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.f));
+  const int q = (int)k & 3;
+  const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+HD float dot6(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
 HD void matvec(const float* R, const float* v, float* o) {
   float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
         z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];

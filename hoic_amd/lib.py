@@ -41,7 +41,7 @@ class RewardParams(C.Structure):
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_enable_timing",
-           "hoic_last_step_ms"]
+           "hoic_last_step_ms", "hoic_last_poststep_ms"]
 
 
 def build(force: bool = False) -> str:
@@ -85,8 +85,10 @@ def load():
     L.hoic_enable_timing.argtypes = [vp, i32]
     L.hoic_last_step_ms.argtypes = [vp]
     L.hoic_last_step_ms.restype = f32
+    L.hoic_last_poststep_ms.argtypes = [vp]
+    L.hoic_last_poststep_ms.restype = f32
     for n in EXPORTS:
-        if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms"):
+        if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms", "hoic_last_poststep_ms"):
             getattr(L, n).restype = i32
     _lib = L
     return L
@@ -224,7 +226,11 @@ class BatchedSim:
         _chk(self.L.hoic_enable_timing(self.h, int(on)), "hoic_enable_timing")
 
     def last_step_ms(self):
+        """duration of the last substep-kernel launch (the dominant kernel), HIP events on the launch stream"""
         return float(self.L.hoic_last_step_ms(self.h))
+
+    def last_poststep_ms(self):
+        return float(self.L.hoic_last_poststep_ms(self.h))
 
     def probe_forward(self, qpos, qvel, ctrl=None, applied=None, warm=None, do_step=False):
         """mj_forward (+ Euler) at arbitrary states; returns a dict of numpy arrays."""

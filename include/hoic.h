@@ -107,10 +107,13 @@ int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const fl
                            int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
                            float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream);
 
-/* duration in milliseconds of the most recent hoic_step kernel launch measured with HIP events on the
- * launch stream (negative if timing was not enabled via hoic_enable_timing) */
+/* hoic_step is two launches: the substep kernel (15 fused substeps, the dominant kernel) and the post-step
+ * kernel (contact averaging, residual-force QP, termination, reward, observation).  Durations in milliseconds of
+ * the most recent launches, measured with HIP events on the launch stream (negative if timing was not enabled
+ * via hoic_enable_timing): hoic_last_step_ms = substep kernel, hoic_last_poststep_ms = post-step kernel. */
 int32_t hoic_enable_timing(hoic_sim* s, int32_t enable);
 float hoic_last_step_ms(hoic_sim* s);
+float hoic_last_poststep_ms(hoic_sim* s);
 
 #ifdef __cplusplus
 }
