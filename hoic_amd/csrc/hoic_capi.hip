@@ -41,12 +41,10 @@ __device__ void store_state(const DevState& st, const Work& w, int env) {
   }
 }
 
-// mj_forward dynamics on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
-__device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const DofK& dk, MReg& M, int* overflow) {
+// velocity / acceleration stages of mj_forward on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
+// (dev_forward_kin has run on the same state)
+__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const DofK& dk, const MReg& M) {
   const int tid = threadIdx.x, d = tid & 31;
-  dev_forward_kin(m, w, dk, M, w.qpos, w.qvel, overflow);
-  RowK rk;
-  dev_make_constraint(m, w, dk, rk, w.qpos, w.qvel); PT(7);
   float fs = 0.f;
   if (d < m.nv) {
     const float act = dk.act >= 0 ? w.ctrl[dk.act] : 0.f;
@@ -54,10 +52,23 @@ __device__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w
   }
   if (tid < NV) w.fsmooth[tid] = fs;
   PT(20);
-  const float a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs); PT(8);
+  float a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs); PT(8);     // unconstrained acceleration
+#ifdef HOIC_EXP_EXTRA_HSOLVE   // cost experiment: extra dependent solves per forward pass
+  for (int rep = 0; rep < HOIC_EXP_EXTRA_HSOLVE; rep++) a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs + 1e-30f * a0);
+#endif
   if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
   __syncthreads();
+  RowK rk;
+  dev_make_constraint(m, w, dk, rk, w.qpos, w.qvel); PT(7);
+#ifdef HOIC_EXP_CONS
+  for (int rep = 0; rep < HOIC_EXP_CONS; rep++) { asm volatile("" ::: "memory"); dev_make_constraint(m, w, dk, rk, w.qpos, w.qvel); }
+#endif
+#ifndef HOIC_X_NOSOLVE
   dev_solve(m, w, M, dk, rk, cfg.c.solver_iterations); PT(9);
+#endif
+#ifdef HOIC_EXP_SOLVE
+  for (int rep = 0; rep < HOIC_EXP_SOLVE; rep++) { asm volatile("" ::: "memory"); dev_solve(m, w, M, dk, rk, cfg.c.solver_iterations); }
+#endif
   float bad = 0.f;
   if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
   return !(wave_max(bad) > 0.f);
@@ -98,9 +109,11 @@ __device__ void dev_euler(const DevModel& m, Work& w, const DofK& dk, const MReg
 // Leaves the new state in HBM and a hand-over record (lagged body / geom poses, contact sums, 15-substep finite
 // differences) for the post-step kernel.
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
-                                                          DevExpert ex, DevState st, const float* __restrict__ action) {
+                                                          const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
+                                                          const float* __restrict__ action) {
+  // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
-  const DevModel& m = *mp; const DevConfig& cfg = *cp;
+  const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
   const int env = blockIdx.x, tid = threadIdx.x;
   load_state(m, st, w, env);
   DofK dk;
@@ -122,23 +135,55 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   int* ovf = &st.overflow[env];
   float* post = st.post + (size_t)env * PB_SIZE;
   float* oldg = st.oldg + (size_t)env * OG_SIZE;
-  // quantities of the previous forward pass (one-substep lag): recompute them from the lagged state
-  dev_forward_kin(m, w, dk, M, w.qlag, w.vlag, tid == 0 ? ovf : nullptr);
-  for (int g = tid; g < m.ngeom; g += NT) {
-    for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
-    for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
-  }
-  const float old_objvel = (tid < 6) ? w.qvel[m.nv - 6 + tid] : 0.f;
+  // One loop, three modes, so that every stage has a single (inlined) call site:
+  //   mode 0  the forward pass on the lagged state: quantities of the previous forward pass (one-substep lag,
+  //           SURVEY.md row Q1) are recomputed instead of being persisted
+  //   mode 1  a substep: control glue, forward dynamics, Euler
+  //   mode 2  after a failed substep: kinematics of the restored state for the observation / reward
+  float old_objvel = 0.f;
   bool ok = true;
+#ifdef HOIC_DBG_NSUB
+  const int nsub = HOIC_DBG_NSUB;
+#else
   const int nsub = cfg.c.sim_step;
-  for (int i = 0; i < nsub; i++) {
+#endif
+  int mode = 0, done_sub = 0;
+  while (true) {
+    // the model / config pointers are laundered every pass: otherwise the compiler hoists the (loop-invariant)
+    // model-constant loads out of the loop and pins them in registers
+    const DevModel* mq = mp; const DevConfig* cq = cp;
+    asm volatile("" : "+s"(mq), "+s"(cq));
+    const DevModel& ml = *mq; const DevConfig& cl = *cq;
     PT(0);
-    dev_record_contact(m, w); PT(2);           // :543 (contacts of the previous forward pass)
-    dev_pd_torque(m, cfg, w, M, ev); PT(1);    // :518-523
-    dev_applied(m, cfg, w, vf, vt);            // :526-540
-    ok = dev_forward_dyn(m, cfg, w, dk, M, tid == 0 ? ovf : nullptr);   // :545 mj_step = forward ...
-    if (!ok) break;
-    dev_euler(m, w, dk, M); PT(10);            //              ... + Euler
+    if (mode == 1) {
+      dev_record_contact(ml, w); PT(2);           // :543 (contacts of the previous forward pass)
+#ifndef HOIC_X_NOPD
+      dev_pd_torque(ml, cl, w, M, ev); PT(1);     // :518-523
+#endif
+      dev_applied(ml, cl, w, vf, vt);             // :526-540
+    }
+    dev_forward_kin(ml, w, dk, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
+    if (mode == 0) {
+      for (int g = tid; g < ml.ngeom; g += NT) {
+        for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
+        for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
+      }
+      old_objvel = (tid < 6) ? w.qvel[ml.nv - 6 + tid] : 0.f;
+      mode = 1;
+      if (nsub <= 0) break;
+      continue;
+    }
+    if (mode == 2) break;
+    ok = dev_forward_dyn(ml, cl, w, dk, M);       // :545 mj_step = forward ...
+    if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
+      if (tid < NQP) w.qpos[tid] = w.qlag[tid];
+      if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
+      __syncthreads();
+      mode = 2;
+      continue;
+    }
+    dev_euler(ml, w, dk, M); PT(10);              //              ... + Euler
+    if (++done_sub >= nsub) break;
   }
   PT(0);
   if (ok) {
@@ -157,11 +202,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       dev_matrix_to_axis_angle(Rd, aa);                                                         // :556-559
       for (int i = 0; i < 3; i++) post[PB_GANGVEL + g * 3 + i] = aa[i] * idt;
     }
-  } else {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
-    if (tid < NQP) w.qpos[tid] = w.qlag[tid];
-    if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
-    __syncthreads();
-    dev_kinematics(m, w, w.qpos);
   }
   if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
   for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
@@ -307,14 +347,18 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   DofK dk;
   dev_load_constants(m, dk);
   MReg M;
-  const bool ok = dev_forward_dyn(m, cfg, w, dk, M, nullptr);
+  dev_forward_kin(m, w, dk, M, w.qpos, w.qvel, nullptr);
+  const bool ok = dev_forward_dyn(m, cfg, w, dk, M);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
   if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
   if (a.gxmat) for (int k = tid; k < m.ngeom * 9; k += NT) a.gxmat[(size_t)env * m.ngeom * 9 + k] = w.gxmat[k / 9][k % 9];
-  if (a.qM && tid < m.nv) {
+  if (a.qM && (tid & 31) < m.nv) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) if (k < m.nv) a.qM[((size_t)env * m.nv + tid) * m.nv + k] = M.r[k];
+    for (int reg = 0; reg < 16; reg++) {
+      const int r = MREG_ROW(reg, tid >> 5);
+      if (r < m.nv) a.qM[((size_t)env * m.nv + r) * m.nv + (tid & 31)] = M.r[reg];
+    }
   }
   if (a.bias && tid < m.nv) a.bias[(size_t)env * m.nv + tid] = w.bias[tid];
   if (a.asmooth && tid < m.nv) a.asmooth[(size_t)env * m.nv + tid] = w.asmooth[tid];
@@ -346,6 +390,8 @@ struct hoic_sim {
   DevConfig hcfg;
   DevConfig* d_cfg = nullptr;
   DevExpert ex{};
+  DevExpert* d_ex = nullptr;   // device copies of the pointer tables (substep kernel)
+  DevState* d_st = nullptr;
   std::vector<void*> ex_allocs;
   DevState st{};
   int *d_iota_seq = nullptr, *d_iota_start = nullptr;
@@ -485,6 +531,16 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     }
     for (int i = 0; i < m.nbody; i++) if (anc[i] != 0) { set_err("model blob: kinematic tree deeper than 8 levels"); return false; }
   }
+  for (int i = 0; i < m.nbody; i++) {
+    int path[32], np = 0;
+    for (int d = lastdof[i]; d >= 0; d = dparent[d]) path[np++] = d;
+    if (np > 12) { set_err("model blob: more than 12 dofs on a body's path"); return false; }
+    for (int k = 0; k < 3; k++) m.body_path[i][k] = 0xFFFFFFFFu;
+    for (int k = 0; k < np; k++) {   // root first
+      const int d = path[np - 1 - k];
+      m.body_path[i][k >> 2] = (m.body_path[i][k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((unsigned)d << (8 * (k & 3)));
+    }
+  }
   for (int d = 0; d < m.nv; d++) {
     unsigned am = 0;
     for (int e = dparent[d]; e >= 0; e = dparent[e]) am |= 1u << e;
@@ -575,6 +631,9 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
        hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
+  ok = hipMalloc(&s->d_ex, sizeof(DevExpert)) == hipSuccess && hipMalloc(&s->d_st, sizeof(DevState)) == hipSuccess;
+  if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
+  hipMemcpy(s->d_st, &s->st, sizeof(DevState), hipMemcpyHostToDevice);
   hipMemcpy(s->d_model, &s->hm, sizeof(DevModel), hipMemcpyHostToDevice);
   hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice);
   hipMemset(s->st.qpos, 0, n * NQP * 4); hipMemset(s->st.qlag, 0, n * NQP * 4); hipMemset(s->st.qvel, 0, n * NV * 4);
@@ -591,7 +650,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->d_iota_seq, s->d_iota_start};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -654,6 +713,7 @@ extern "C" int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* se
   if (!x.seq_off || !x.seq_len || !x.hand_dof || !x.hand_dof_vel || !x.obj_pose || !x.obj_vel || !x.obj_angvel || !x.body_pos || !x.body_quat) {
     set_err("hoic_set_expert: hipMalloc failed"); return HOIC_ERR_DEVICE;
   }
+  HIPCHK(hipMemcpy(s->d_ex, &s->ex, sizeof(DevExpert), hipMemcpyHostToDevice));
   s->has_expert = true;
   return HOIC_OK;
 }
@@ -675,7 +735,7 @@ extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, f
   if (!s->has_expert) { set_err("hoic_step: set_expert has not been called"); return HOIC_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
   if (s->timing) hipEventRecord(s->ev0, st);
-  hipLaunchKernelGGL(hoic_substep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action);
+  hipLaunchKernelGGL(hoic_substep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action);
   if (s->timing) hipEventRecord(s->ev1, st);
   hipLaunchKernelGGL(hoic_poststep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
                      d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start);

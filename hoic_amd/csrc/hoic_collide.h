@@ -178,7 +178,7 @@ HD int clip_poly(const float (*p)[2], int n, int axis, float lim, float sgn, flo
   }
   return mcount;
 }
-__device__ __noinline__ void col_box_box(const float* pa, const float* Ra, const float* ha, const float* pb,
+__device__ __forceinline__ void col_box_box(const float* pa, const float* Ra, const float* ha, const float* pb,
                                          const float* Rb, const float* hb, LaneContacts& o) {
   float A[3][3], B[3][3], R[3][3], Q[3][3], t[3], tw[3];
   for (int i = 0; i < 3; i++) { matcol(Ra, i, A[i]); matcol(Rb, i, B[i]); tw[i] = pb[i] - pa[i]; }
@@ -322,7 +322,7 @@ HD void lc_keep_deepest(LaneContacts& o, float dist, const float* pos, const flo
       if (q == slot) { o.dist[q] = dist; for (int i = 0; i < 3; i++) { o.pos[q][i] = pos[i]; o.nrm[q][i] = n[i]; } }
   }
 }
-__device__ __noinline__ void col_plane_mesh(const DevModel& m, const float* pp, const float* pR, const float* mp,
+__device__ __forceinline__ void col_plane_mesh(const DevModel& m, const float* pp, const float* pR, const float* mp,
                                             const float* mR, int mesh, LaneContacts& o) {
   const HullRef h = get_hull(m, mesh);
   float n[3];
@@ -346,7 +346,7 @@ __device__ __noinline__ void col_plane_mesh(const DevModel& m, const float* pp, 
     o.n++;
   }
 }
-__device__ __noinline__ void col_capsule_mesh(const DevModel& m, const float* cp, const float* cR, const float* cs,
+__device__ __forceinline__ void col_capsule_mesh(const DevModel& m, const float* cp, const float* cR, const float* cs,
                                               const float* mp, const float* mR, int mesh, LaneContacts& o) {
   const HullRef h = get_hull(m, mesh);
   float ax[3], rel[3], pc[3], al[3], a[3], d[3];
@@ -397,7 +397,7 @@ __device__ __noinline__ void col_capsule_mesh(const DevModel& m, const float* cp
     o.n++;
   }
 }
-__device__ __noinline__ void col_box_mesh(const DevModel& m, const float* bp, const float* bR, const float* bh,
+__device__ __forceinline__ void col_box_mesh(const DevModel& m, const float* bp, const float* bR, const float* bh,
                                           const float* mp, const float* mR, int mesh, LaneContacts& o) {
   const HullRef h = get_hull(m, mesh);
   for (int v = 0; v < h.nv; v++) {
@@ -442,7 +442,7 @@ HD void make_frame(float* f) {
 }
 
 // ---- collision driver: lane = pair (two passes when npair > 64); contacts compacted into the workspace
-__device__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
+__device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
   const int tid = threadIdx.x;
   if (tid == 0) w.ncon = 0;
   __syncthreads();

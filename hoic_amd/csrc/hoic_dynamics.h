@@ -22,37 +22,71 @@ __device__ void dev_load_constants(const DevModel& m, DofK& dk) {
   const bool v = d < m.nv;
   dk.arm = v ? m.dof_armature[d] : 0.f; dk.damp = v ? m.dof_damping[d] : 0.f; dk.floss = v ? m.dof_frictionloss[d] : 0.f;
   dk.flR = v ? m.dof_flR[d] : 1.f; dk.flB = v ? m.dof_flB[d] : 0.f; dk.act = v ? m.dof_actid[d] : -1;
+  const int b = threadIdx.x < m.nbody ? threadIdx.x : 0;
+  for (int i = 0; i < 3; i++) dk.bpath[i] = threadIdx.x < m.nbody ? m.body_path[b][i] : 0xFFFFFFFFu;
+}
+
+// sum_{d on the packed path} S[d] * x[d]  (+ optional extra[d]) as straight-line code: all LDS reads are issued
+// before the first FMA needs them (one latency instead of one per dof); `below` keeps only dofs < below
+template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[3], const float* x, const float (*extra)[6],
+                                          int below, float* V, float* A) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    if (i == 6) __builtin_amdgcn_sched_barrier(0);   // two batches of six gathers in flight, not twelve (register peak)
+    const unsigned e = (path[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    const bool on = e < (unsigned)below;
+    const int d = on ? (int)e : 0;
+    const float xd = on ? x[d] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) V[k] = fmaf(w.S[d][k], xd, V[k]);
+    if (EXTRA) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) A[k] += on ? extra[d][k] : 0.f;
+    }
+  }
 }
 
 // ---- kinematics: body frames, geoms, motion axes S, body inertias about the origin
-__device__ void dev_kinematics(const DevModel& m, Work& w, const float* q) {
+__device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const float* q) {
   const int tid = threadIdx.x;
   const bool isb = tid < m.nbody;
   float P[3] = {0.f, 0.f, 0.f}, Q[4] = {1.f, 0.f, 0.f, 0.f};
+  // 0. lane = joint: joint rotation quaternion / slide displacement (all sincos calls in parallel, constants by
+  //    independent loads); parked in the inertia scratch, which is not written before step 3
+  float (*jrec)[12] = reinterpret_cast<float (*)[12]>(&w.sc.dyn.I10[0][0]);   // [axis 3 | pos 3 | quat 4 or disp | type]
+  if (tid < m.njnt) {
+    const int j = tid, ty = m.jnt_type[j], qa = m.jnt_qposadr[j];
+    float* r = jrec[j];
+    for (int i = 0; i < 3; i++) { r[i] = m.jnt_axis[j][i]; r[3 + i] = m.jnt_pos[j][i]; }
+    float sn = 0.f, cs = 1.f;
+    const float qq = (ty == HOIC_JNT_FREE) ? 0.f : q[qa] - m.qpos0[qa];
+    if (ty == HOIC_JNT_HINGE) sincos_pi(0.5f * qq, &sn, &cs);
+    r[6] = (ty == HOIC_JNT_SLIDE) ? qq : cs; r[7] = sn * r[0]; r[8] = sn * r[1]; r[9] = sn * r[2];
+    r[10] = __int_as_float(ty); r[11] = __int_as_float(qa);
+  }
+  __syncthreads();
   // 1. transform of each body relative to its parent, with the joint axes / anchors in the parent frame
   if (isb) {
     const int b = tid, ja = m.body_jntadr[b], jn = m.body_jntnum[b];
     for (int i = 0; i < 3; i++) P[i] = m.body_pos[b][i];
     for (int i = 0; i < 4; i++) Q[i] = m.body_quat[b][i];
     for (int j = ja; j < ja + jn; j++) {
-      const int ty = m.jnt_type[j], qa = m.jnt_qposadr[j];
+      const float* r = jrec[j];
+      const int ty = __float_as_int(r[10]);
       if (ty == HOIC_JNT_FREE) {
+        const int qa = __float_as_int(r[11]);
         for (int i = 0; i < 3; i++) P[i] = q[qa + i];
         for (int i = 0; i < 4; i++) Q[i] = q[qa + 3 + i];
         normquat(Q);
       } else {
-        const float jax[3] = {m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]};
-        const float jps[3] = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
+        const float jax[3] = {r[0], r[1], r[2]}, jps[3] = {r[3], r[4], r[5]};
         float ax[3], t[3], an[3];
         qrot(Q, jax, ax); qrot(Q, jps, t);
         for (int i = 0; i < 3; i++) { an[i] = P[i] + t[i]; w.sc.dyn.u.j.jax[j][i] = ax[i]; w.sc.dyn.u.j.janc[j][i] = an[i]; }
-        const float qq = q[qa] - m.qpos0[qa];
         if (ty == HOIC_JNT_SLIDE) {
-          for (int i = 0; i < 3; i++) P[i] += ax[i] * qq;
+          for (int i = 0; i < 3; i++) P[i] += ax[i] * r[6];
         } else {
-          float sn, cs;
-          sincos_pi(0.5f * qq, &sn, &cs);
-          const float ql[4] = {cs, sn * jax[0], sn * jax[1], sn * jax[2]};
+          const float ql[4] = {r[6], r[7], r[8], r[9]};
           float qn[4];
           mulquat(Q, ql, qn);
           for (int i = 0; i < 4; i++) Q[i] = qn[i];
@@ -175,7 +209,7 @@ HD void inert_mul(const float* I, const float* v, float* f) {
 
 // ---- joint-space inertia: composite rigid body sums over index ranges, then row (lane & 31) of M in registers:
 // M[i][j] = S_j . (Ic_body(i) S_i) for j an ancestor-or-self dof of i, mirrored for descendants, 0 elsewhere
-__device__ void dev_mass_matrix(const DevModel& m, Work& w, const DofK& dk, MReg& M) {
+__device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, const DofK& dk, MReg& M) {
   const int tid = threadIdx.x;
   if (tid < m.nbody) {
     float acc[10];
@@ -186,7 +220,7 @@ __device__ void dev_mass_matrix(const DevModel& m, Work& w, const DofK& dk, MReg
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
   __syncthreads();   // (also: the joint frames in sc.dyn.u.j are dead from here on, u.f takes their place)
-  const int d = tid & 31;
+  const int d = opaque(tid & 31);
   const bool vd = d < m.nv;
   float Si[6], fSi[6];
   for (int i = 0; i < 6; i++) { Si[i] = vd ? w.S[d][i] : 0.f; fSi[i] = 0.f; }
@@ -194,22 +228,32 @@ __device__ void dev_mass_matrix(const DevModel& m, Work& w, const DofK& dk, MReg
   if (tid < 32) for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[d][i] = fSi[i];
   __syncthreads();
   const unsigned am = vd ? (m.dof_amask[d] | (1u << d)) : 0u, dm = vd ? m.dof_dmask[d] : 0u;
+  const int hi = tid >> 5;
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const float a = dot6(w.S[j], fSi), bb = dot6(Si, w.sc.dyn.u.f.fS[j]);   // uniform addresses: LDS broadcasts
+  for (int reg = 0; reg < 16; reg++) {
+    const int j = MREG_ROW(reg, hi);          // per half-wave uniform: LDS broadcasts
+    const float a = dot6(w.S[j], fSi), bb = dot6(Si, w.sc.dyn.u.f.fS[j]);
     float v = ((am >> j) & 1u) ? a : (((dm >> j) & 1u) ? bb : 0.f);
     if (j == d) v += dk.arm;
-    M.r[j] = v;
+    M.r[reg] = v;
   }
   __syncthreads();
 }
 
-// out = (M x)[lane & 31], x in LDS (uniform reads)
+// (M x)[lane & 31] on every lane, x in LDS: each half-wave sums its 16 columns, one cross-half add
 HD float dev_Mx(const MReg& M, const float* x) {
+  const int hi = threadIdx.x >> 5;
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-  for (int k = 0; k < NV; k += 2) { s0 = fmaf(M.r[k], x[k], s0); s1 = fmaf(M.r[k + 1], x[k + 1], s1); }
-  return s0 + s1;
+  for (int g = 0; g < 4; g++) {
+    const float* xp = x + 8 * g + 4 * hi;
+    s0 = fmaf(M.r[4 * g], xp[0], s0); s1 = fmaf(M.r[4 * g + 1], xp[1], s1);
+    s0 = fmaf(M.r[4 * g + 2], xp[2], s0); s1 = fmaf(M.r[4 * g + 3], xp[3], s1);
+  }
+  const float s = s0 + s1;
+  const unsigned v = __float_as_uint(s);
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // .x: low-half value on both halves, .y: high-half value
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 HD void cross_motion(const float* v, const float* s, float* o) {
@@ -227,18 +271,13 @@ HD void cross_force(const float* v, const float* f, float* o) {
 //   cdd_d = (velocity of the chain above dof d) x S_d * qvel_d          (lane = dof)
 //   V_b = sum_{d on path(b)} S_d qvel_d,  A_b = a_world + sum cdd_d       (lane = body)
 //   f_b = I_b A_b + V_b x* I_b V_b;  subtree range sums;  bias_d = S_d . fsub_body(d)
-__device__ void dev_bias(const DevModel& m, Work& w, const float* qvel) {
+__device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const DofK& dk, const float* qvel) {
   const int tid = threadIdx.x;
   if (tid < m.nv) {
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sd[6];
-    unsigned mk = m.dof_amask[tid];
-    while (mk) {
-      const int e = __ffs(mk) - 1;
-      mk &= mk - 1;
-      const float qd = qvel[e];
-#pragma unroll
-      for (int i = 0; i < 6; i++) v[i] = fmaf(w.S[e][i], qd, v[i]);
-    }
+    const int b = m.dof_bodyid[tid];
+    const unsigned pth[3] = {m.body_path[b][0], m.body_path[b][1], m.body_path[b][2]};
+    path_gather<false>(w, pth, qvel, nullptr, tid, v, nullptr);   // dofs above `tid` on its path
     cross_motion(v, w.S[tid], sd);
     const float qd = qvel[tid];
     for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[tid][i] = sd[i] * qd;
@@ -246,16 +285,9 @@ __device__ void dev_bias(const DevModel& m, Work& w, const float* qvel) {
   __syncthreads();
   if (tid < m.nbody) {
     float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    unsigned mk = m.body_dofmask[tid];
-    if (mk) {
+    if (dk.bpath[0] != 0xFFFFFFFFu) {
       float V[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, A[6] = {0.f, 0.f, 0.f, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-      while (mk) {
-        const int e = __ffs(mk) - 1;
-        mk &= mk - 1;
-        const float qd = qvel[e];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { V[i] = fmaf(w.S[e][i], qd, V[i]); A[i] += w.sc.dyn.u.f.fS[e][i]; }
-      }
+      path_gather<true>(w, dk.bpath, qvel, w.sc.dyn.u.f.fS, 0xFF, V, A);
       float Iv[6], Ia[6], x[6];
       inert_mul(w.sc.dyn.I10[tid], V, Iv); inert_mul(w.sc.dyn.I10[tid], A, Ia); cross_force(V, Iv, x);
       for (int i = 0; i < 6; i++) f[i] = Ia[i] + x[i];

@@ -5,6 +5,9 @@
 #define HD __device__ __forceinline__
 #define MINVALF 1e-15f
 
+// hides a lane-varying loop-invariant value from the optimiser so that the lane masks derived from it are
+// recomputed on the spot (one v_cmp) instead of being hoisted out of the substep loop into (spilling) SGPR pairs
+HD int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 HD float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 HD void cross3(const float* a, const float* b, float* o) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];

@@ -34,8 +34,17 @@ template <int J> HD float hs_row_bcast(const f32x16& acc) {
   return __uint_as_float(half ? r.y : r.x);
 }
 
+template <int LANE> HD void hs_writelane(float& dst, float uniform_val) {
+  const int sv = __builtin_amdgcn_readfirstlane(__float_as_int(uniform_val));
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "n"(LANE));
+}
+// `col` is made opaque at every step so that the lane masks (col > J ...) are recomputed on the spot (one v_cmp)
+// instead of being hoisted out of the substep loop as ~100 loop-invariant SGPR pairs, which spill.
 template <int J> struct HsFactor {
   static HD void run(f32x16& acc, float& y, float& dinv, int col, int hi, float* T) {
+#ifndef HOIC_NO_OPAQUE
+    asm volatile("" : "+v"(col));
+#endif
     const float u0 = hs_row_bcast<J>(acc);           // u0[lane&31] = A[J][.] = L[.][J] * d_J
     const float r1 = hs_row_bcast<J + 1>(acc);
     const float inv0 = __builtin_amdgcn_rcpf(fmaxf(rl(u0, J), 1e-30f));
@@ -44,12 +53,17 @@ template <int J> struct HsFactor {
     const float inv1 = __builtin_amdgcn_rcpf(fmaxf(rl(u1, J + 1), 1e-30f));
     const float l1 = u1 * inv1;
     if (J < 30) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? -l1 : -l0, hi ? u1 : u0, acc, 0, 0, 0);
-    if (col == J) dinv = inv0;
-    if (col == J + 1) dinv = inv1;
+    // 1/d_J lands in lane J (only the low half-wave carries the solution)
+#ifndef HOIC_NO_WRITELANE
+    hs_writelane<J>(dinv, inv0);
+    hs_writelane<J + 1>(dinv, inv1);
+#else
+    dinv = (col == J) ? inv0 : ((col == J + 1) ? inv1 : dinv);
+#endif
     const float y0 = rl(y, J);
-    if (col > J) y -= l0 * y0;
+    y = (col > J) ? fmaf(-l0, y0, y) : y;
     const float y1 = rl(y, J + 1);
-    if (col > J + 1) y -= l1 * y1;
+    y = (col > J + 1) ? fmaf(-l1, y1, y) : y;
     T[(J + hi) * LD + col] = hi ? l1 : l0;           // T[k][c] = L[c][k]
     HsFactor<J + 2>::run(acc, y, dinv, col, hi, T);
   }
@@ -59,12 +73,12 @@ template <> struct HsFactor<32> { static HD void run(f32x16&, float&, float&, in
 // diag: per-lane diagonal increment of row/col (lane & 31); use_rows: add the active contact rows through the
 // MFMA; rhs: per-lane right-hand side (lane & 31).  Returns x[lane & 31] (both half-waves hold the solution).
 __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MReg& M, float dg, int nact, bool use_rows, float rhs) {
-  const int lane = threadIdx.x, col = lane & 31, hi = lane >> 5;
+  const int lane = opaque(threadIdx.x), col = lane & 31, hi = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
-    const int rlo = (reg & 3) + 8 * (reg >> 2), r = rlo + 4 * hi;
-    float v = hi ? M.r[rlo + 4] : M.r[rlo];
+    const int r = MREG_ROW(reg, hi);
+    float v = M.r[reg];
     if (r == col) v += dg;
     if (r >= nact || col >= nact) v = (r == col) ? 1.f : 0.f;
     acc[reg] = v;
@@ -99,14 +113,24 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
   PT(16);
   y *= dinv;
   __syncthreads();
-  float lc[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) lc[k] = T[col * LD + k];        // L[k][col], valid for k > col
+  // backward substitution in two halves (16 columns of L in flight at a time keeps the register peak down)
   float x = y;
+  int colx = col;
 #pragma unroll
-  for (int k = 31; k > 0; k--) {
-    const float xk = rl(x, k);
-    if (col < k) x -= lc[k] * xk;
+  for (int h = 1; h >= 0; h--) {
+    float lc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + 16 * h + k];        // L[16h+k][col], valid for 16h+k > col
+#ifndef HOIC_NO_OPAQUE
+    asm volatile("" : "+v"(colx));     // keep the lane masks from being hoisted (see HsFactor)
+#endif
+#pragma unroll
+    for (int k = 15; k >= 0; k--) {
+      const int kk = 16 * h + k;
+      if (kk == 0) continue;
+      const float xk = rl(x, kk);
+      x = (colx < kk) ? fmaf(-lc[k], xk, x) : x;
+    }
   }
   __syncthreads();
   PT(18);
@@ -135,19 +159,12 @@ struct RowEval { float jar_f, force_f, curv_f, jar_l, force_l, curv_l, jar_c[NCS
 
 // ---- u[c][k] = (contact-frame Jacobian row k of contact c) . x, Jacobian-free:
 // body spatial velocities V_b = sum_{d on the path of b} S[d] x[d], then W[c][k] . (V_b2 - V_b1)
-__device__ void dev_basis_dot(const DevModel& m, Work& w, const float* x) {
+__device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const DofK& dk, const float* x) {
   const int tid = threadIdx.x;
   if (w.ncon == 0) return;
   if (tid < m.nbody) {
     float V[6] = {0, 0, 0, 0, 0, 0};
-    unsigned mk = m.body_dofmask[tid];
-    while (mk) {
-      const int d = __ffs(mk) - 1;
-      mk &= mk - 1;
-      const float xd = x[d];
-#pragma unroll
-      for (int i = 0; i < 6; i++) V[i] = fmaf(w.S[d][i], xd, V[i]);
-    }
+    path_gather<false>(w, dk.bpath, x, nullptr, 0xFF, V, nullptr);
 #pragma unroll
     for (int i = 0; i < 6; i++) w.bV[tid][i] = V[i];
   }
@@ -187,7 +204,7 @@ HD float cost_onesided(float D, float jar, float& force, float& curv) {
 }
 
 // ---- constraint rows for the current kinematics / contacts
-__device__ void dev_make_constraint(const DevModel& m, Work& w, const DofK& dk, RowK& rk, const float* qpos, const float* qvel) {
+__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, const DofK& dk, RowK& rk, const float* qpos, const float* qvel) {
   const int tid = threadIdx.x, d = tid & 31;
   // friction loss and joint limit of dof d (one side per joint can be active: every range is wider than twice
   // the margin; slide and hinge joints have exactly one dof)
@@ -245,7 +262,7 @@ __device__ void dev_make_constraint(const DevModel& m, Work& w, const DofK& dk, 
   }
   __syncthreads();
   // reference accelerations of the contact rows
-  dev_basis_dot(m, w, qvel);
+  dev_basis_dot(m, w, dk, qvel);
   for (int r = tid; r < w.nrow; r += NT) {
     const int c = w.cr_con[r];
     w.cr_aref[r] = -w.c_B[c] * dev_crow_times(w, r) + w.c_aref0[c];
@@ -253,33 +270,44 @@ __device__ void dev_make_constraint(const DevModel& m, Work& w, const DofK& dk, 
   __syncthreads();
 }
 
-// jar, force, curvature of every row at acceleration x (LDS); returns the constraint cost (wave-reduced)
-__device__ float dev_eval_rows(const DevModel& m, Work& w, const DofK& dk, const RowK& rk, const float* x, RowEval& ev) {
+// ---- row state.  jar = J x - aref of every row: per-dof rows in the registers of lane & 31 = dof (both
+// half-waves), contact rows NCSLOT per lane.  dev_rows_jar needs one Jacobian product (dev_basis_dot);
+// dev_rows_cost turns jar into cost, forces and curvatures (contact rows: LDS cr_force / cr_curv) and is cheap.
+__device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const DofK& dk, const RowK& rk, const float* x, bool with_aref, RowEval& ev) {
   const int tid = threadIdx.x;
-  dev_basis_dot(m, w, x);
-  float cost = 0.f;
-  ev.jar_f = ev.force_f = ev.curv_f = ev.jar_l = ev.force_l = ev.curv_l = 0.f;
-  if ((tid & 31) < m.nv) {     // both half-waves keep the per-dof rows (the solve needs the curvature on all 64 lanes)
-    const float xd = x[tid & 31];
-    ev.jar_f = xd - rk.f_aref;
-    cost = cost_friction(dk, ev.jar_f, ev.force_f, ev.curv_f);
-    if (rk.l_sign != 0.f) {
-      ev.jar_l = rk.l_sign * xd - rk.l_aref;
-      cost += cost_onesided(rk.l_D, ev.jar_l, ev.force_l, ev.curv_l);
-    }
-    if (tid >= 32) cost = 0.f;
-  }
+  dev_basis_dot(m, w, dk, x);
+  const float xd = ((tid & 31) < m.nv) ? x[tid & 31] : 0.f;
+  ev.jar_f = xd - (with_aref ? rk.f_aref : 0.f);
+  ev.jar_l = rk.l_sign * xd - (with_aref ? rk.l_aref : 0.f);
   const int nrow = w.nrow;
 #pragma unroll
   for (int k = 0; k < NCSLOT; k++) {
     ev.jar_c[k] = 0.f;
     if (k * NT < nrow) {
       const int r = tid + k * NT;
+      if (r < nrow) ev.jar_c[k] = dev_crow_times(w, r) - (with_aref ? w.cr_aref[r] : 0.f);
+    }
+  }
+}
+// D_c: curvature constant of this lane's contact rows (c_D of the row's contact), loaded once per solve
+__device__ __forceinline__ float dev_rows_cost(const DevModel& m, Work& w, const DofK& dk, const RowK& rk, const float (&D_c)[NCSLOT], RowEval& ev) {
+  const int tid = threadIdx.x;
+  float cost = 0.f;
+  ev.force_f = ev.curv_f = ev.force_l = ev.curv_l = 0.f;
+  if ((tid & 31) < m.nv) {     // both half-waves keep the per-dof rows (the solve needs the curvature on all 64 lanes)
+    cost = cost_friction(dk, ev.jar_f, ev.force_f, ev.curv_f);
+    if (rk.l_sign != 0.f) cost += cost_onesided(rk.l_D, ev.jar_l, ev.force_l, ev.curv_l);
+    if (tid >= 32) cost = 0.f;
+  }
+  const int nrow = w.nrow;
+#pragma unroll
+  for (int k = 0; k < NCSLOT; k++) {
+    if (k * NT < nrow) {
+      const int r = tid + k * NT;
       if (r < nrow) {
-        const float jar = dev_crow_times(w, r) - w.cr_aref[r];
         float f, cv;
-        cost += cost_onesided(w.c_D[w.cr_con[r]], jar, f, cv);
-        ev.jar_c[k] = jar; w.cr_force[r] = f; w.cr_curv[r] = cv;
+        cost += cost_onesided(D_c[k], ev.jar_c[k], f, cv);
+        w.cr_force[r] = f; w.cr_curv[r] = cv;
       }
     }
   }
@@ -287,29 +315,39 @@ __device__ float dev_eval_rows(const DevModel& m, Work& w, const DofK& dk, const
   return wave_sum(cost);
 }
 
-// (J^T force)[lane & 31] from the last evaluation: per-contact wrench G_c = sum_k g_k W[c][k], then
+// (J^T force)[lane & 31] from the last dev_rows_cost: per-contact wrench G_c = sum_k g_k W[c][k], then
 // S[i] . sum_c sg(i,c) G_c, plus the per-dof rows
-__device__ float dev_jt_force(const DevModel& m, Work& w, const RowK& rk, const RowEval& ev) {
-  const int tid = threadIdx.x, d = tid & 31;
-  if (tid < w.ncon) {
-    const int c = tid, r0 = w.c_row0[c], nr = w.c_nrow[c];
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int e = 0; e < nr; e++) g[0] += w.cr_force[r0 + e];
-    if (nr > 1) for (int k = 1; 2 * k - 1 < nr; k++) g[k] = w.c_mu[c][k - 1] * (w.cr_force[r0 + 2 * (k - 1)] - w.cr_force[r0 + 2 * (k - 1) + 1]);
-    const float* fr = w.c_frame[c];
-    for (int i = 0; i < 3; i++) {
-      w.c_G[c][i] = g[0] * w.c_pxf[c][0][i] + g[1] * w.c_pxf[c][1][i] + g[2] * w.c_pxf[c][2][i] + g[3] * fr[i];
-      w.c_G[c][3 + i] = g[0] * fr[i] + g[1] * fr[3 + i] + g[2] * fr[6 + i];
+__device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const RowK& rk, const RowEval& ev) {
+  const int tid = opaque(threadIdx.x), d = tid & 31;
+  const int ncon = w.ncon;
+  if (tid < ((ncon + 3) & ~3)) {
+    const int c = tid;
+    float G[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < ncon) {
+      const int r0 = w.c_row0[c], nr = w.c_nrow[c];
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < nr; e++) g[0] += w.cr_force[r0 + e];
+      if (nr > 1) for (int k = 1; 2 * k - 1 < nr; k++) g[k] = w.c_mu[c][k - 1] * (w.cr_force[r0 + 2 * (k - 1)] - w.cr_force[r0 + 2 * (k - 1) + 1]);
+      const float* fr = w.c_frame[c];
+      for (int i = 0; i < 3; i++) {
+        G[i] = g[0] * w.c_pxf[c][0][i] + g[1] * w.c_pxf[c][1][i] + g[2] * w.c_pxf[c][2][i] + g[3] * fr[i];
+        G[3 + i] = g[0] * fr[i] + g[1] * fr[3 + i] + g[2] * fr[6 + i];
+      }
     }
+    for (int i = 0; i < 6; i++) w.c_G[c][i] = G[i];   // zero padding up to a multiple of 4 contacts
   }
   __syncthreads();
   float s = ev.force_f + rk.l_sign * ev.force_l;
-  if (w.ncon > 0) {
+  if (ncon > 0) {
     float G[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = 0; c < w.ncon; c++) {
-      const float sg = (float)((w.c_mpos[c] >> d) & 1u) - (float)((w.c_mneg[c] >> d) & 1u);
+    for (int c0 = 0; c0 < ncon; c0 += 4) {     // four contacts per trip: their LDS reads share one wait
 #pragma unroll
-      for (int i = 0; i < 6; i++) G[i] = fmaf(sg, w.c_G[c][i], G[i]);
+      for (int k = 0; k < 4; k++) {
+        const int c = c0 + k;
+        const float sg = (float)((w.c_mpos[c] >> d) & 1u) - (float)((w.c_mneg[c] >> d) & 1u);
+#pragma unroll
+        for (int i = 0; i < 6; i++) G[i] = fmaf(sg, w.c_G[c][i], G[i]);
+      }
     }
     s += dot6(w.S[d], G);
   }
@@ -318,30 +356,33 @@ __device__ float dev_jt_force(const DevModel& m, Work& w, const RowK& rk, const 
 }
 
 // ---- Newton with exact line search.  In: M, fsmooth, asmooth, warm, rows.  Out: qacc, fcon (LDS).
-__device__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const DofK& dk, const RowK& rk, int maxit) {
+// The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
+// line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
+__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const DofK& dk, const RowK& rk, int maxit) {
   const int tid = threadIdx.x, d = tid & 31;
   const bool vd = d < m.nv;
   const float scale = 1.f / (m.meaninertia * (float)max(m.nv, 1));
-  const float fs = w.fsmooth[d];
-  RowEval ev;
-  // warm start choice: cost(warm) vs cost(asmooth); the row state of the LAST evaluation (warm) is reused by
-  // the first iteration when warm wins (the usual case)
-  float gw = 0.f;
-  if (tid < m.nv) gw = 0.5f * (dev_Mx(M, w.warm) - fs) * (w.warm[tid] - w.asmooth[tid]);
-  gw = wave_sum(gw);
-  const float cs = dev_eval_rows(m, w, dk, rk, w.asmooth, ev);
-  const float cw = gw + dev_eval_rows(m, w, dk, rk, w.warm, ev);
-  bool have_eval = cw < cs;
-  float qacc = vd ? (have_eval ? w.warm[d] : w.asmooth[d]) : 0.f;   // per-lane copy of the iterate
-  if (tid < NV) w.qacc[tid] = qacc;
-  __syncthreads();
+  const float fs = w.fsmooth[d], a0 = w.asmooth[d], wm = w.warm[d];
+  const int nrow = w.nrow;
+  float D_c[NCSLOT];
+#pragma unroll
+  for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; D_c[k] = (r < nrow) ? w.c_D[w.cr_con[r]] : 0.f; }
+  // warm start choice: cost(warm) vs cost(asmooth)
+  const float Mw = vd ? dev_Mx(M, w.warm) : 0.f;
+  const float gw = wave_sum((tid < m.nv) ? 0.5f * (Mw - fs) * (wm - a0) : 0.f);
+  RowEval ev, evw;
+  dev_rows_jar(m, w, dk, rk, w.asmooth, true, ev);
+  const float cs = dev_rows_cost(m, w, dk, rk, D_c, ev);
+  dev_rows_jar(m, w, dk, rk, w.warm, true, evw);
+  const float cw = gw + dev_rows_cost(m, w, dk, rk, D_c, evw);
+  const bool usewarm = cw < cs;
+  float qacc = vd ? (usewarm ? wm : a0) : 0.f, Ma = vd ? (usewarm ? Mw : fs) : 0.f;   // M asmooth = fsmooth
+  if (usewarm) ev = evw;
+  else dev_rows_cost(m, w, dk, rk, D_c, ev);      // forces / curvatures back to the asmooth state
   int it = 0;
   bool fresh = false;     // jtf holds J'f of the current qacc
   float jtf = 0.f;
   for (; it < maxit; it++) {
-    const float Ma = vd ? dev_Mx(M, w.qacc) : 0.f;
-    if (!have_eval) dev_eval_rows(m, w, dk, rk, w.qacc, ev);
-    have_eval = false;
     jtf = dev_jt_force(m, w, rk, ev);
     const float g = vd ? (Ma - fs - jtf) : 0.f;
     const float g2 = wave_sum(tid < 32 ? g * g : 0.f);
@@ -352,33 +393,23 @@ __device__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const DofK&
     if (tid < NV) w.search[tid] = vd ? sd : 0.f;
     __syncthreads();
     // line-search quantities
+    const float Ms = vd ? dev_Mx(M, w.search) : 0.f;
     float gq = 0.f, hh = 0.f, g0 = 0.f;
-    if (tid < m.nv) {
-      const float Ms = dev_Mx(M, w.search);
-      gq = (Ma - fs) * sd; hh = sd * Ms; g0 = g * sd;
-    }
+    if (tid < m.nv) { gq = (Ma - fs) * sd; hh = sd * Ms; g0 = g * sd; }
     gq = wave_sum(gq); hh = wave_sum(hh); g0 = wave_sum(g0);
-    dev_basis_dot(m, w, w.search);
-    const int nrow = w.nrow;
-    const float jv_f = (tid < m.nv) ? sd : 0.f, jv_l = rk.l_sign * jv_f;
-    float jv_c[NCSLOT], D_c[NCSLOT];
-#pragma unroll
-    for (int k = 0; k < NCSLOT; k++) {
-      const int r = tid + k * NT;
-      jv_c[k] = 0.f; D_c[k] = 0.f;
-      if (r < nrow) { jv_c[k] = dev_crow_times(w, r); D_c[k] = w.c_D[w.cr_con[r]]; }
-    }
+    RowEval jv;
+    dev_rows_jar(m, w, dk, rk, w.search, false, jv);
     float a = 0.f, lo = 0.f, hi = -1.f, alpha = 0.f;
     for (int ls = 0; ls < 10; ls++) {
       float dphi = 0.f, ddphi = 0.f, f, cv;
       if (tid < m.nv) {
-        cost_friction(dk, ev.jar_f + a * jv_f, f, cv);
-        dphi -= f * jv_f; ddphi += cv * jv_f * jv_f;
-        if (rk.l_sign != 0.f) { cost_onesided(rk.l_D, ev.jar_l + a * jv_l, f, cv); dphi -= f * jv_l; ddphi += cv * jv_l * jv_l; }
+        cost_friction(dk, ev.jar_f + a * jv.jar_f, f, cv);
+        dphi -= f * jv.jar_f; ddphi += cv * jv.jar_f * jv.jar_f;
+        if (rk.l_sign != 0.f) { cost_onesided(rk.l_D, ev.jar_l + a * jv.jar_l, f, cv); dphi -= f * jv.jar_l; ddphi += cv * jv.jar_l * jv.jar_l; }
       }
 #pragma unroll
       for (int k = 0; k < NCSLOT; k++)
-        if (k * NT < nrow) { cost_onesided(D_c[k], ev.jar_c[k] + a * jv_c[k], f, cv); dphi -= f * jv_c[k]; ddphi += cv * jv_c[k] * jv_c[k]; }
+        if (k * NT < nrow) { cost_onesided(D_c[k], ev.jar_c[k] + a * jv.jar_c[k], f, cv); dphi -= f * jv.jar_c[k]; ddphi += cv * jv.jar_c[k] * jv.jar_c[k]; }
       dphi = wave_sum(dphi) + gq + a * hh; ddphi = wave_sum(ddphi) + hh;
       alpha = a;
       if (fabsf(dphi) < 1e-4f * fabsf(g0) + 1e-12f) break;
@@ -389,15 +420,17 @@ __device__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const DofK&
       a = an;
     }
     const float dq = alpha * sd;
-    qacc += vd ? dq : 0.f;
+    qacc += vd ? dq : 0.f; Ma = fmaf(alpha, Ms, Ma);
+    ev.jar_f = fmaf(alpha, jv.jar_f, ev.jar_f); ev.jar_l = fmaf(alpha, jv.jar_l, ev.jar_l);
+#pragma unroll
+    for (int k = 0; k < NCSLOT; k++) ev.jar_c[k] = fmaf(alpha, jv.jar_c[k], ev.jar_c[k]);
+    dev_rows_cost(m, w, dk, rk, D_c, ev);
     const float st = wave_max((tid < m.nv) ? fabsf(dq) / (1.f + fabsf(qacc)) : 0.f);
-    if (tid < NV) w.qacc[tid] = qacc;
-    __syncthreads();
     if (st < 1e-7f) { it++; break; }
   }
-  // forces at the final acceleration
-  if (!fresh) { dev_eval_rows(m, w, dk, rk, w.qacc, ev); jtf = dev_jt_force(m, w, rk, ev); }
-  if (tid < NV) w.fcon[tid] = vd ? jtf : 0.f;
+  // forces at the final acceleration (the row state already belongs to it)
+  if (!fresh) jtf = dev_jt_force(m, w, rk, ev);
+  if (tid < NV) { w.fcon[tid] = vd ? jtf : 0.f; w.qacc[tid] = qacc; }
   if (tid == 0) w.solver_iter = it;
   __syncthreads();
 }

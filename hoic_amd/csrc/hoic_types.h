@@ -42,6 +42,7 @@ struct DevModel {
   int body_subtree[NB];
   int body_jump[MAXROUND][NB];  // round r composes body b with body_jump[r][b] (-1: already in the world frame)
   unsigned body_dofmask[NB];    // dofs on the path root -> body
+  unsigned body_path[NB][3];    // the same path as up to 12 packed dof indices (0xFF = none), root first
   float body_pos[NB][3], body_quat[NB][4], body_ipos[NB][3], body_iquat[NB][4], body_mass[NB], body_inertia[NB][3];
   // joints / dofs
   int jnt_type[NJ], jnt_qposadr[NJ], jnt_dofadr[NJ], jnt_bodyid[NJ], jnt_limited[NJ];
@@ -116,11 +117,14 @@ struct DevState {
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
 };
 
-// joint-space inertia matrix, one row per lane: lane l holds row (l & 31) (both half-waves hold a copy)
-struct MReg { float r[NV]; };
+// joint-space inertia matrix in the layout of a v_mfma_f32_32x32x2_f32 accumulator: lane (col + 32*hi) holds, in
+// register reg, M[row][col] with row = (reg & 3) + 8 * (reg >> 2) + 4 * hi.  M is symmetric, so the same 16 values are
+// also one half of ROW col (columns `row`): matrix-vector products need one cross-half add, the solves a plain copy.
+struct MReg { float r[16]; };
+#define MREG_ROW(reg, hi) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hi))
 
-// per-dof constants of the solver kept in registers for the whole launch (lane & 31 = dof)
-struct DofK { float arm, damp, floss, flR, flB; int act; };
+// per-lane constants kept in registers for the whole launch (lane & 31 = dof; bpath: lane = body)
+struct DofK { float arm, damp, floss, flR, flB; int act; unsigned bpath[3]; /* lane = body: body_path */ };
 
 // per-env LDS workspace
 struct Work {

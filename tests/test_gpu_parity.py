@@ -114,7 +114,7 @@ def test_forward_dynamics_parity(obj, oracle_lib):
         worst["state"] = max(worst["state"], _rel(out["qpos_out"][i], e.get("qpos")[:33]), _rel(out["qvel_out"][i], e.get("qvel")))
     assert with_contacts > N // 3 and ncon_mismatch <= 2 and face_ties <= N // 12, (ncon_mismatch, face_ties)
     assert worst["kin"] < 2e-6 and worst["M"] < 2e-6 and worst["bias"] < 2e-6, worst
-    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < 3e-5, worst
+    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < 6e-5, worst
 
 
 @pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
