@@ -43,12 +43,13 @@ __device__ void store_state(const DevState& st, const Work& w, int env) {
 
 // velocity / acceleration stages of mj_forward on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
 // (dev_forward_kin has run on the same state)
-__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const DofK& dk, const MReg& M) {
-  const int tid = threadIdx.x, d = tid & 31;
+__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M) {
+  const int tid = opaque(threadIdx.x), d = tid & 31;
   float fs = 0.f;
   if (d < m.nv) {
-    const float act = dk.act >= 0 ? w.ctrl[dk.act] : 0.f;
-    fs = -dk.damp * w.qvel[d] - w.bias[d] + w.applied[d] + act;   // passive (joint damping) - bias + applied + actuation
+    const int ai = w.k_act[d];
+    const float act = ai >= 0 ? w.ctrl[ai] : 0.f;
+    fs = -w.k_damp[d] * w.qvel[d] - w.bias[d] + w.applied[d] + act;   // passive (joint damping) - bias + applied + actuation
   }
   if (tid < NV) w.fsmooth[tid] = fs;
   PT(20);
@@ -59,15 +60,15 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
   __syncthreads();
   RowK rk;
-  dev_make_constraint(m, w, dk, rk, w.qpos, w.qvel); PT(7);
+  dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
 #ifdef HOIC_EXP_CONS
-  for (int rep = 0; rep < HOIC_EXP_CONS; rep++) { asm volatile("" ::: "memory"); dev_make_constraint(m, w, dk, rk, w.qpos, w.qvel); }
+  for (int rep = 0; rep < HOIC_EXP_CONS; rep++) { asm volatile("" ::: "memory"); dev_make_constraint(m, w, rk, w.qpos, w.qvel); }
 #endif
 #ifndef HOIC_X_NOSOLVE
-  dev_solve(m, w, M, dk, rk, cfg.c.solver_iterations); PT(9);
+  dev_solve(m, w, M, rk, cfg.c.solver_iterations); PT(9);
 #endif
 #ifdef HOIC_EXP_SOLVE
-  for (int rep = 0; rep < HOIC_EXP_SOLVE; rep++) { asm volatile("" ::: "memory"); dev_solve(m, w, M, dk, rk, cfg.c.solver_iterations); }
+  for (int rep = 0; rep < HOIC_EXP_SOLVE; rep++) { asm volatile("" ::: "memory"); dev_solve(m, w, M, rk, cfg.c.solver_iterations); }
 #endif
   float bad = 0.f;
   if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
@@ -75,12 +76,12 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
 }
 
 // semi-implicit Euler with implicit joint damping; also records the pre-integration state (lag) and warm start
-__device__ void dev_euler(const DevModel& m, Work& w, const DofK& dk, const MReg& M) {
-  const int tid = threadIdx.x, d = tid & 31;
+__device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
+  const int tid = opaque(threadIdx.x), d = tid & 31;
   const float h = m.timestep;
   const float rhs = (d < m.nv) ? (w.fsmooth[d] + w.fcon[d]) : 0.f;
   PT(20);
-  const float acc = dev_hsolve(m, w, M, h * dk.damp, m.nv, false, rhs);
+  const float acc = dev_hsolve(m, w, M, h * w.k_damp[d], m.nv, false, rhs);
   if (tid < NQP) w.qlag[tid] = w.qpos[tid];
   if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
   __syncthreads();
@@ -116,8 +117,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
   const int env = blockIdx.x, tid = threadIdx.x;
   load_state(m, st, w, env);
-  DofK dk;
-  dev_load_constants(m, dk);
+  dev_load_constants(m, w);
   MReg M;
 #ifdef HOIC_PHASE_TIMING
   if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
       dev_applied(ml, cl, w, vf, vt);             // :526-540
     }
-    dev_forward_kin(ml, w, dk, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
+    dev_forward_kin(ml, w, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
     if (mode == 0) {
       for (int g = tid; g < ml.ngeom; g += NT) {
         for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       continue;
     }
     if (mode == 2) break;
-    ok = dev_forward_dyn(ml, cl, w, dk, M);       // :545 mj_step = forward ...
+    ok = dev_forward_dyn(ml, cl, w, M);       // :545 mj_step = forward ...
     if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
       if (tid < NQP) w.qpos[tid] = w.qlag[tid];
       if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       mode = 2;
       continue;
     }
-    dev_euler(ml, w, dk, M); PT(10);              //              ... + Euler
+    dev_euler(ml, w, M); PT(10);              //              ... + Euler
     if (++done_sub >= nsub) break;
   }
   PT(0);
@@ -344,11 +344,10 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   }
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; }
   __syncthreads();
-  DofK dk;
-  dev_load_constants(m, dk);
+  dev_load_constants(m, w);
   MReg M;
-  dev_forward_kin(m, w, dk, M, w.qpos, w.qvel, nullptr);
-  const bool ok = dev_forward_dyn(m, cfg, w, dk, M);
+  dev_forward_kin(m, w, M, w.qpos, w.qvel, nullptr);
+  const bool ok = dev_forward_dyn(m, cfg, w, M);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
   if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
       } else for (int i = 0; i < 16; i++) r[i] = 0.f;
     }
   }
-  if (a.do_step && ok) dev_euler(m, w, dk, M);
+  if (a.do_step && ok) dev_euler(m, w, M);
   if (a.qpos_out && tid < m.nq) a.qpos_out[(size_t)env * m.nq + tid] = w.qpos[tid];
   if (a.qvel_out && tid < m.nv) a.qvel_out[(size_t)env * m.nv + tid] = w.qvel[tid];
 }
@@ -549,6 +548,15 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     for (int u = 0; u < m.nu; u++) if (m.act_dofid[u] == d) m.dof_actid[d] = u;
   }
   for (int d = 0; d < m.nv; d++) {
+    const int j = m.dof_jntid[d], b = m.dof_bodyid[d];
+    m.dof_jtype[d] = m.jnt_type[j]; m.dof_k[d] = d - m.jnt_dofadr[j]; m.dof_parentbody[d] = m.body_parent[b];
+    m.dof_qadr[d] = m.jnt_qposadr[j];
+    m.dof_limited[d] = (m.jnt_limited[j] && m.jnt_type[j] != HOIC_JNT_FREE) ? 1 : 0;
+    for (int k = 0; k < 3; k++) m.dof_bpath[d][k] = m.body_path[b][k];
+    m.dof_range[d][0] = m.jnt_range[j][0]; m.dof_range[d][1] = m.jnt_range[j][1]; m.dof_margin[d] = m.jnt_margin[j];
+    for (int k = 0; k < 5; k++) m.dof_solimp[d][k] = m.jnt_solimp[j][k];
+  }
+  for (int d = 0; d < m.nv; d++) {
     unsigned dm = 0;
     for (int e = 0; e < m.nv; e++) if (e != d && ((m.dof_amask[e] >> d) & 1u)) dm |= 1u << e;
     m.dof_dmask[d] = dm;
@@ -564,6 +572,7 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
   for (int j = 0; j < m.njnt; j++) {
     kb_from_solref(&jsolref[2 * j], &jsolimp[5 * j], m.timestep, false, m.jnt_K[j], m.jnt_B[j]);
     m.jnt_diag[j] = (float)invw[m.jnt_dofadr[j]];
+    if (m.jnt_type[j] != HOIC_JNT_FREE) { const int d = m.jnt_dofadr[j]; m.dof_limK[d] = m.jnt_K[j]; m.dof_limB[d] = m.jnt_B[j]; m.dof_limdiag[d] = m.jnt_diag[j]; }
     if (m.jnt_limited[j] && m.jnt_type[j] != HOIC_JNT_FREE && m.jnt_range[j][1] - m.jnt_range[j][0] <= 2 * m.jnt_margin[j]) {
       set_err("model blob: joint range narrower than twice its margin is not supported"); return false;
     }
@@ -583,6 +592,8 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
     m.pair_type1[p] = m.geom_type[g1]; m.pair_type2[p] = m.geom_type[g2]; m.pair_mesh[p] = m.geom_meshid[g2];
     m.pair_bound[p] = m.geom_rbound[g1] + m.geom_rbound[g2] + m.pair_margin[p];
+    for (int k = 0; k < 3; k++) { m.pair_size1[p][k] = m.geom_size[g1][k]; m.pair_size2[p][k] = m.geom_size[g2][k]; }
+    m.pair_mpos[p] = m.body_dofmask[b2] & ~m.body_dofmask[b1]; m.pair_mneg[p] = m.body_dofmask[b1] & ~m.body_dofmask[b2];
     if (m.pair_type1[p] == HOIC_GEOM_MESH) { set_err("model blob: a mesh must be the second geom of a pair"); return false; }
   }
   std::vector<int> mva, mvn, mpa, mpn; std::vector<double> mv, mpl;

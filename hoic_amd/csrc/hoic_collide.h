@@ -8,15 +8,20 @@
 #include "hoic_types.h"
 #include "hoic_math.h"
 
+// Contacts found by one lane (= one pair): staged in LDS (Work::col_lc, one column per lane), so that the narrow
+// phase holds neither 28 more registers nor a scratch-memory copy (dynamic indexing of a register array would put
+// it there; scratch round trips go to L2/HBM and used to dominate this stage).
 struct LaneContacts {
   int n;
-  float dist[4], pos[4][3], nrm[4][3];
+  float* b;   // &col_lc[lane]
 };
-
-HD void lc_set(LaneContacts& o, int k, float dist, const float* pos, const float* n) {
-  o.dist[k] = dist;
-  for (int i = 0; i < 3; i++) { o.pos[k][i] = pos[i]; o.nrm[k][i] = n[i]; }
+HD float& lc_at(const LaneContacts& o, int q, int k) { return o.b[(q * 7 + k) * NT]; }
+HD void lc_put(LaneContacts& o, int slot, float dist, const float* pos, const float* n) {
+  if (slot < 0) return;
+  lc_at(o, slot, 0) = dist;
+  for (int i = 0; i < 3; i++) { lc_at(o, slot, 1 + i) = pos[i]; lc_at(o, slot, 4 + i) = n[i]; }
 }
+HD void lc_push(LaneContacts& o, float dist, const float* pos, const float* n) { lc_put(o, o.n, dist, pos, n); o.n++; }
 
 HD void col_plane_sphere(const float* pp, const float* pn, const float* c, float r, LaneContacts& o) {
   float d[3] = {c[0] - pp[0], c[1] - pp[1], c[2] - pp[2]};
@@ -24,8 +29,7 @@ HD void col_plane_sphere(const float* pp, const float* pn, const float* c, float
   if (dist >= 0.f) return;
   float pos[3];
   for (int i = 0; i < 3; i++) pos[i] = c[i] - pn[i] * (r + 0.5f * dist);
-  lc_set(o, o.n, dist, pos, pn);
-  o.n++;
+  lc_push(o, dist, pos, pn);
 }
 HD void col_plane_capsule(const float* pp, const float* pR, const float* cp, const float* cR, const float* size, LaneContacts& o) {
   float n[3], ax[3], e[3];
@@ -46,8 +50,7 @@ HD void col_plane_box(const float* pp, const float* pR, const float* bp, const f
     if (dist >= 0.f) continue;
     float pos[3];
     for (int i = 0; i < 3; i++) pos[i] = wv[i] - 0.5f * dist * n[i];
-    lc_set(o, o.n, dist, pos, n);
-    o.n++;
+    lc_push(o, dist, pos, n);
   }
 }
 
@@ -85,8 +88,7 @@ HD void col_capsule_capsule(const float* p1, const float* R1, const float* s1, c
   if (len < 1e-12f) { d[0] = 1.f; d[1] = d[2] = 0.f; } else { float inv = 1.f / len; d[0] *= inv; d[1] *= inv; d[2] *= inv; }
   float pos[3];
   for (int i = 0; i < 3; i++) pos[i] = c1[i] + d[i] * (s1[0] + 0.5f * dist);
-  lc_set(o, o.n, dist, pos, d);
-  o.n++;
+  lc_push(o, dist, pos, d);
 }
 
 // sphere (centre c in the box frame) vs box; outputs in the box frame
@@ -141,152 +143,202 @@ HD void col_capsule_box(const float* cp, const float* cR, const float* cs, const
   mattvec(bR, rel, pc); mattvec(bR, ax, al);
   for (int i = 0; i < 3; i++) { a[i] = pc[i] - cs[1] * al[i]; b[i] = pc[i] + cs[1] * al[i]; }
   const float r = cs[0];
-  float tc[3]; int nc = 0;
   float dist, pos[3], n[3];
-  if (sphere_box_local(a, r, h, dist, pos, n)) tc[nc++] = 0.f;
-  if (sphere_box_local(b, r, h, dist, pos, n)) tc[nc++] = 1.f;
-  if (nc < 2) {
-    float ts = seg_box_t(a, b, h);
-    bool dup = false;
-    for (int k = 0; k < nc; k++) if (fabsf(ts - tc[k]) < 1e-4f) dup = true;
-    if (!dup) tc[nc++] = ts;
+  // candidate axis parameters in the order of the sequential list: the two ends if they touch, else the closest point
+  const bool h0 = sphere_box_local(a, r, h, dist, pos, n), h1 = sphere_box_local(b, r, h, dist, pos, n);
+  float tc[3] = {0.f, 1.f, 0.f};
+  bool tv[3] = {h0, h1, false};
+  if (!(h0 && h1)) {
+    const float ts = seg_box_t(a, b, h);
+    tc[2] = ts;
+    tv[2] = !((h0 && fabsf(ts) < 1e-4f) || (h1 && fabsf(ts - 1.f) < 1e-4f));
   }
   int cnt = 0;
-  for (int k = 0; k < nc && cnt < 2; k++) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (!tv[k] || cnt >= 2) continue;
     float c[3];
     for (int i = 0; i < 3; i++) c[i] = a[i] + tc[k] * (b[i] - a[i]);
     if (!sphere_box_local(c, r, h, dist, pos, n)) continue;
     float pw[3], nw[3];
     matvec(bR, pos, pw); matvec(bR, n, nw);
     for (int i = 0; i < 3; i++) pw[i] += bp[i];
-    lc_set(o, o.n, dist, pw, nw);
-    o.n++; cnt++;
+    lc_push(o, dist, pw, nw);
+    cnt++;
   }
 }
 
-// ---- box-box: separating-axis test, then reference-face clipping (or one edge-edge point)
-HD int clip_poly(const float (*p)[2], int n, int axis, float lim, float sgn, float (*q)[2]) {
-  int mcount = 0;
-  for (int i = 0; i < n; i++) {
-    const float* a = p[i]; const float* b = p[(i + 1) % n];
-    float da = sgn * a[axis] - lim, db = sgn * b[axis] - lim;
-    if (da <= 0.f) { q[mcount][0] = a[0]; q[mcount][1] = a[1]; mcount++; }
-    if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
-      float t = da / (da - db);
-      q[mcount][0] = a[0] + t * (b[0] - a[0]); q[mcount][1] = a[1] + t * (b[1] - a[1]); mcount++;
-    }
-  }
-  return mcount;
-}
-__device__ __forceinline__ void col_box_box(const float* pa, const float* Ra, const float* ha, const float* pb,
-                                         const float* Rb, const float* hb, LaneContacts& o) {
+// ---- box-box, wave-cooperative: the same separating-axis test / reference-face clipping as col_box_box (and as
+// oracle/ho_collide.c box_box), with the fifteen axes on fifteen lanes and the clipped polygon one vertex per lane.
+// The per-lane version walks ~3000 dependent instructions over scratch-resident polygons on ONE lane while 63
+// idle; this one is a few hundred wave-wide steps.  All inputs are wave-uniform (every lane passes the same pair);
+// decisions keep the sequential tie-breaks (first axis with the smallest penetration, polygon order).
+// Returns the number of contacts n <= 4 (wave-uniform) and writes them into the owner lane's staging column `o`.
+// polybuf (LDS): 32 floats of staging for the clipping.
+__device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra, const float* ha, const float* pb, const float* Rb,
+                                                const float* hb, const LaneContacts& o, float* polybuf) {
+  const int lane = opaque(threadIdx.x);
   float A[3][3], B[3][3], R[3][3], Q[3][3], t[3], tw[3];
   for (int i = 0; i < 3; i++) { matcol(Ra, i, A[i]); matcol(Rb, i, B[i]); tw[i] = pb[i] - pa[i]; }
   for (int i = 0; i < 3; i++) {
     t[i] = dot3(tw, A[i]);
     for (int j = 0; j < 3; j++) { R[i][j] = dot3(A[i], B[j]); Q[i][j] = fabsf(R[i][j]) + 1e-6f; }
   }
-  float best = 1e30f, bestn[3] = {0, 0, 0}; int code = -1;
-  for (int i = 0; i < 3; i++) {
-    float ra = ha[i], rb = hb[0] * Q[i][0] + hb[1] * Q[i][1] + hb[2] * Q[i][2];
-    float pen = ra + rb - fabsf(t[i]);
-    if (pen < 0.f) return;
-    if (pen < best) { best = pen; code = i; float s = t[i] < 0.f ? -1.f : 1.f; for (int k = 0; k < 3; k++) bestn[k] = s * A[i][k]; }
-  }
-  for (int j = 0; j < 3; j++) {
-    float tb = t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j];
-    float ra = ha[0] * Q[0][j] + ha[1] * Q[1][j] + ha[2] * Q[2][j], rb = hb[j];
-    float pen = ra + rb - fabsf(tb);
-    if (pen < 0.f) return;
-    if (pen < best) { best = pen; code = 3 + j; float s = tb < 0.f ? -1.f : 1.f; for (int k = 0; k < 3; k++) bestn[k] = s * B[j][k]; }
-  }
-  float beste = 1e30f, en[3] = {0, 0, 0}; int ecode = -1;
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      float L[3];
-      cross3(A[i], B[j], L);
-      float len = sqrtf(dot3(L, L));
-      if (len < 1e-4f) continue;
-      float inv = 1.f / len;
+  // ---- separating axes, lane = axis: 0-2 faces of A, 3-5 faces of B, 6-14 edge pairs (i, j) = ((lane-6)/3, (lane-6)%3)
+  float pen = 1e30f, nrm[3] = {0.f, 0.f, 0.f};
+  bool valid = false;
+  if (lane < 3) {
+    const int i = lane;
+    const float ti = sel3(t[0], t[1], t[2], i);
+    const float rb = hb[0] * sel3(Q[0][0], Q[1][0], Q[2][0], i) + hb[1] * sel3(Q[0][1], Q[1][1], Q[2][1], i) + hb[2] * sel3(Q[0][2], Q[1][2], Q[2][2], i);
+    pen = sel3(ha[0], ha[1], ha[2], i) + rb - fabsf(ti);
+    const float sg = ti < 0.f ? -1.f : 1.f;
+    float Ai[3]; sel3v(A, i, Ai);
+    for (int k = 0; k < 3; k++) nrm[k] = sg * Ai[k];
+    valid = true;
+  } else if (lane < 6) {
+    const int j = lane - 3;
+    const float tb = t[0] * sel3(R[0][0], R[0][1], R[0][2], j) + t[1] * sel3(R[1][0], R[1][1], R[1][2], j) + t[2] * sel3(R[2][0], R[2][1], R[2][2], j);
+    const float ra = ha[0] * sel3(Q[0][0], Q[0][1], Q[0][2], j) + ha[1] * sel3(Q[1][0], Q[1][1], Q[1][2], j) + ha[2] * sel3(Q[2][0], Q[2][1], Q[2][2], j);
+    pen = ra + sel3(hb[0], hb[1], hb[2], j) - fabsf(tb);
+    const float sg = tb < 0.f ? -1.f : 1.f;
+    float Bj[3]; sel3v(B, j, Bj);
+    for (int k = 0; k < 3; k++) nrm[k] = sg * Bj[k];
+    valid = true;
+  } else if (lane < 15) {
+    const int i = (lane - 6) / 3, j = (lane - 6) % 3;
+    float Ai[3], Bj[3], L[3];
+    sel3v(A, i, Ai); sel3v(B, j, Bj);
+    cross3(Ai, Bj, L);
+    const float len = sqrtf(dot3(L, L));
+    if (len >= 1e-4f) {
+      const float inv = 1.f / len;
       for (int k = 0; k < 3; k++) L[k] *= inv;
       float ra = 0.f, rb = 0.f;
       for (int k = 0; k < 3; k++) { ra += ha[k] * fabsf(dot3(A[k], L)); rb += hb[k] * fabsf(dot3(B[k], L)); }
-      float tl = dot3(tw, L), pen = ra + rb - fabsf(tl);
-      if (pen < 0.f) return;
-      if (pen < beste) { beste = pen; ecode = 3 * i + j; float s = tl < 0.f ? -1.f : 1.f; for (int k = 0; k < 3; k++) en[k] = s * L[k]; }
+      const float tl = dot3(tw, L);
+      pen = ra + rb - fabsf(tl);
+      const float sg = tl < 0.f ? -1.f : 1.f;
+      for (int k = 0; k < 3; k++) nrm[k] = sg * L[k];
+      valid = true;
     }
-  if (ecode >= 0 && beste * 1.05f + 1e-6f < best) {
-    int i = ecode / 3, j = ecode % 3;
+  }
+  if (__ballot(valid && pen < 0.f) != 0ull) return 0;
+  const float best = wave_min(lane < 6 ? pen : 1e30f);
+  const int code = __ffsll((long long)__ballot(lane < 6 && pen == best)) - 1;
+  const bool isedge = lane >= 6 && valid;
+  const float beste = wave_min(isedge ? pen : 1e30f);
+  const unsigned long long emask = __ballot(isedge && pen == beste);
+  const int ecode = emask ? (__ffsll((long long)emask) - 1 - 6) : -1;
+  if (ecode >= 0 && beste * 1.05f + 1e-6f < best) {      // ---- edge-edge: one contact (uniform code on every lane)
+    const int i = ecode / 3, j = ecode % 3;
+    float en[3];
+    for (int k = 0; k < 3; k++) en[k] = rl(nrm[k], 6 + ecode);
     float ea[3], eb[3];
     for (int k = 0; k < 3; k++) { ea[k] = pa[k]; eb[k] = pb[k]; }
     for (int k = 0; k < 3; k++) {
-      if (k != i) { float s = dot3(en, A[k]) > 0.f ? 1.f : -1.f; for (int c = 0; c < 3; c++) ea[c] += s * ha[k] * A[k][c]; }
-      if (k != j) { float s = dot3(en, B[k]) > 0.f ? -1.f : 1.f; for (int c = 0; c < 3; c++) eb[c] += s * hb[k] * B[k][c]; }
+      if (k != i) { const float s = dot3(en, A[k]) > 0.f ? 1.f : -1.f; for (int c = 0; c < 3; c++) ea[c] += s * ha[k] * A[k][c]; }
+      if (k != j) { const float s = dot3(en, B[k]) > 0.f ? -1.f : 1.f; for (int c = 0; c < 3; c++) eb[c] += s * hb[k] * B[k][c]; }
     }
-    float r[3] = {ea[0] - eb[0], ea[1] - eb[1], ea[2] - eb[2]};
-    float bdot = dot3(A[i], B[j]), c1 = dot3(A[i], r), f1 = dot3(B[j], r), den = 1.f - bdot * bdot;
+    float Ai[3], Bj[3];
+    sel3v(A, i, Ai); sel3v(B, j, Bj);
+    const float r[3] = {ea[0] - eb[0], ea[1] - eb[1], ea[2] - eb[2]};
+    const float bdot = dot3(Ai, Bj), c1 = dot3(Ai, r), f1 = dot3(Bj, r), den = 1.f - bdot * bdot;
     float u = den > 1e-6f ? (bdot * f1 - c1) / den : 0.f, v = f1 + bdot * u;
-    u = fminf(fmaxf(u, -ha[i]), ha[i]); v = fminf(fmaxf(v, -hb[j]), hb[j]);
-    float pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = 0.5f * (ea[k] + u * A[i][k] + eb[k] + v * B[j][k]);
-    lc_set(o, 0, -beste, pos, en);
-    o.n = 1;
-    return;
+    const float hai = sel3(ha[0], ha[1], ha[2], i), hbj = sel3(hb[0], hb[1], hb[2], j);
+    u = fminf(fmaxf(u, -hai), hai); v = fminf(fmaxf(v, -hbj), hbj);
+    if (lane == 0) {
+      lc_at(o, 0, 0) = -beste;
+      for (int k = 0; k < 3; k++) { lc_at(o, 0, 1 + k) = 0.5f * (ea[k] + u * Ai[k] + eb[k] + v * Bj[k]); lc_at(o, 0, 4 + k) = en[k]; }
+    }
+    return 1;
   }
+  // ---- face contact: clip the incident face against the side planes of the reference face
+  float bestn[3];
+  for (int k = 0; k < 3; k++) bestn[k] = rl(nrm[k], code);
   const bool refA = code < 3; const int ax = refA ? code : code - 3;
-  const float* pr = refA ? pa : pb; const float* pi_ = refA ? pb : pa;
-  float(*Rr)[3] = refA ? A : B; float(*Ri)[3] = refA ? B : A;
-  const float* hr = refA ? ha : hb; const float* hi = refA ? hb : ha;
-  float nref[3];
-  for (int k = 0; k < 3; k++) nref[k] = refA ? bestn[k] : -bestn[k];
+  float pr[3], pi_[3], hr[3], hi[3], Rr[3][3], Ri[3][3], nref[3];
+  for (int k = 0; k < 3; k++) {
+    pr[k] = refA ? pa[k] : pb[k]; pi_[k] = refA ? pb[k] : pa[k]; hr[k] = refA ? ha[k] : hb[k]; hi[k] = refA ? hb[k] : ha[k];
+    nref[k] = refA ? bestn[k] : -bestn[k];
+    for (int c = 0; c < 3; c++) { Rr[k][c] = refA ? A[k][c] : B[k][c]; Ri[k][c] = refA ? B[k][c] : A[k][c]; }
+  }
   int iax = 0; float mind = 1e30f, isg = 1.f;
   for (int k = 0; k < 3; k++) {
-    float dd = dot3(Ri[k], nref);
+    const float dd = dot3(Ri[k], nref);
     if (-fabsf(dd) < mind) { mind = -fabsf(dd); iax = k; isg = dd > 0.f ? -1.f : 1.f; }
   }
   const int i1 = (iax + 1) % 3, i2 = (iax + 2) % 3, r1 = (ax + 1) % 3, r2 = (ax + 2) % 3;
+  float Riax[3], Ri1[3], Ri2[3], Rr1[3], Rr2[3];
+  sel3v(Ri, iax, Riax); sel3v(Ri, i1, Ri1); sel3v(Ri, i2, Ri2); sel3v(Rr, r1, Rr1); sel3v(Rr, r2, Rr2);
+  const float hiax = sel3(hi[0], hi[1], hi[2], iax), hi1 = sel3(hi[0], hi[1], hi[2], i1), hi2 = sel3(hi[0], hi[1], hi[2], i2);
+  const float hr1 = sel3(hr[0], hr[1], hr[2], r1), hr2 = sel3(hr[0], hr[1], hr[2], r2), hrax = sel3(hr[0], hr[1], hr[2], ax);
   float fc[3];
-  for (int k = 0; k < 3; k++) fc[k] = pi_[k] + isg * hi[iax] * Ri[iax][k] - pr[k];
-  float poly[16][2], tmp[16][2], vz[4];
-  const float sgs[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
-  for (int v = 0; v < 4; v++) {
+  for (int k = 0; k < 3; k++) fc[k] = pi_[k] + isg * hiax * Riax[k] - pr[k];
+  // incident-face corners: lane v in 0..3 (every lane computes corner lane & 3; lanes >= 4 are ignored)
+  float px, py, vz;
+  {
+    const int v = lane & 3;
+    const float sx = (v == 0 || v == 3) ? 1.f : -1.f, sy = (v < 2) ? 1.f : -1.f;   // (1,1) (-1,1) (-1,-1) (1,-1)
     float wv[3];
-    for (int k = 0; k < 3; k++) wv[k] = fc[k] + sgs[v][0] * hi[i1] * Ri[i1][k] + sgs[v][1] * hi[i2] * Ri[i2][k];
-    poly[v][0] = dot3(wv, Rr[r1]); poly[v][1] = dot3(wv, Rr[r2]); vz[v] = dot3(wv, nref);
+    for (int k = 0; k < 3; k++) wv[k] = fc[k] + sx * hi1 * Ri1[k] + sy * hi2 * Ri2[k];
+    px = dot3(wv, Rr1); py = dot3(wv, Rr2); vz = dot3(wv, nref);
   }
-  float m00 = poly[1][0] - poly[0][0], m01 = poly[1][1] - poly[0][1], m10 = poly[3][0] - poly[0][0], m11 = poly[3][1] - poly[0][1];
-  float det = m00 * m11 - m01 * m10, gx = 0.f, gy = 0.f;
+  const float p0x = rl(px, 0), p0y = rl(py, 0), z_0 = rl(vz, 0);
+  const float m00 = rl(px, 1) - p0x, m01 = rl(py, 1) - p0y, m10 = rl(px, 3) - p0x, m11 = rl(py, 3) - p0y;
+  const float det = m00 * m11 - m01 * m10;
+  float gx = 0.f, gy = 0.f;
   if (fabsf(det) > 1e-12f) {
-    float dz1 = vz[1] - vz[0], dz3 = vz[3] - vz[0];
+    const float dz1 = rl(vz, 1) - z_0, dz3 = rl(vz, 3) - z_0;
     gx = (dz1 * m11 - dz3 * m01) / det; gy = (dz3 * m00 - dz1 * m10) / det;
   }
-  float z0 = vz[0] - gx * poly[0][0] - gy * poly[0][1];
+  const float z0 = z_0 - gx * p0x - gy * p0y;
   int n = 4;
-  n = clip_poly(poly, n, 0, hr[r1], 1.f, tmp); if (!n) return;
-  n = clip_poly(tmp, n, 0, hr[r1], -1.f, poly); if (!n) return;
-  n = clip_poly(poly, n, 1, hr[r2], 1.f, tmp); if (!n) return;
-  n = clip_poly(tmp, n, 1, hr[r2], -1.f, poly); if (!n) return;
-  float depth[16]; int keep[16], nk = 0;
-  for (int v = 0; v < n; v++) {
-    float z = z0 + gx * poly[v][0] + gy * poly[v][1];
-    depth[v] = hr[ax] - z;
-    if (depth[v] > 0.f) keep[nk++] = v;
+#pragma unroll
+  for (int stage = 0; stage < 4; stage++) {
+    const int axis = stage >> 1; const float lim = axis ? hr2 : hr1, sgn = (stage & 1) ? -1.f : 1.f;
+    const int nxt = (lane + 1 < n) ? lane + 1 : 0;
+    const float bx = __shfl(px, nxt), by = __shfl(py, nxt);
+    const bool act = lane < n;
+    const float da = sgn * (axis ? py : px) - lim, db = sgn * (axis ? by : bx) - lim;
+    const bool e1 = act && da <= 0.f, e2 = act && ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f));
+    const int cnt = (e1 ? 1 : 0) + (e2 ? 1 : 0);
+    const int incl = wave_incl_scan(cnt);
+    const int pos = incl - cnt;
+    n = __builtin_amdgcn_readlane(incl, NT - 1);
+    if (n == 0) return 0;
+    if (e1) { polybuf[2 * pos] = px; polybuf[2 * pos + 1] = py; }
+    if (e2) {
+      const float tt = da / (da - db);
+      polybuf[2 * (pos + (e1 ? 1 : 0))] = px + tt * (bx - px); polybuf[2 * (pos + (e1 ? 1 : 0)) + 1] = py + tt * (by - py);
+    }
+    __syncthreads();
+    if (lane < n) { px = polybuf[2 * lane]; py = polybuf[2 * lane + 1]; }
+    __syncthreads();
   }
-  if (!nk) return;
-  int sel[4], ns = 0;
-  if (nk <= 4) { for (int k = 0; k < nk; k++) sel[ns++] = keep[k]; }
+  // depths, keep the penetrating vertices (polygon order), at most four of them
+  const float depth = hrax - (z0 + gx * px + gy * py);
+  const unsigned long long kmask = __ballot(lane < n && depth > 0.f);
+  const int nk = __popcll(kmask);
+  if (nk == 0) return 0;
+  const int krank = __popcll(kmask & ((1ull << lane) - 1ull));    // position of this lane's vertex in keep[]
+  const bool kept = (kmask >> lane) & 1ull;
+  int srank = -1;                                                    // output slot of this lane's vertex (-1: dropped)
+  int ns = nk;
+  if (nk <= 4) { if (kept) srank = krank; }
   else {
-    int d0 = 0;
-    for (int k = 1; k < nk; k++) if (depth[keep[k]] > depth[keep[d0]]) d0 = k;
-    for (int k = 0; k < 4; k++) sel[ns++] = keep[(d0 + (k * nk) / 4) % nk];
+    const float dmax = wave_max(kept ? depth : -1e30f);
+    const int d0lane = __ffsll((long long)__ballot(kept && depth == dmax)) - 1;       // first deepest vertex
+    const int d0 = __popcll(kmask & ((1ull << d0lane) - 1ull));
+    ns = 4;
+    for (int k = 0; k < 4; k++) if (kept && krank == (d0 + (k * nk) / 4) % nk) srank = k;
   }
-  for (int s = 0; s < ns; s++) {
-    int v = sel[s];
-    float z = hr[ax] - depth[v], pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = pr[k] + poly[v][0] * Rr[r1][k] + poly[v][1] * Rr[r2][k] + (z + 0.5f * depth[v]) * nref[k];
-    lc_set(o, s, -depth[v], pos, bestn);
+  if (srank >= 0) {
+    const float z = hrax - depth;
+    lc_at(o, srank, 0) = -depth;
+    for (int k = 0; k < 3; k++) { lc_at(o, srank, 1 + k) = pr[k] + px * Rr1[k] + py * Rr2[k] + (z + 0.5f * depth) * nref[k]; lc_at(o, srank, 4 + k) = bestn[k]; }
   }
-  o.n = ns;
+  return ns;
 }
 
 // ---- convex mesh (hull vertices + face planes in the geom frame) vs plane / capsule / box.
@@ -313,14 +365,11 @@ HD void lc_keep_deepest(LaneContacts& o, float dist, const float* pos, const flo
   if (o.n < 4) slot = o.n++;
   else {
     int wst = 0;
-    for (int q = 1; q < 4; q++) if (o.dist[q] > o.dist[wst]) wst = q;
-    if (dist < o.dist[wst]) slot = wst;
+    float wd = lc_at(o, 0, 0);
+    for (int q = 1; q < 4; q++) { const float dq = lc_at(o, q, 0); if (dq > wd) { wd = dq; wst = q; } }
+    if (dist < wd) slot = wst;
   }
-  if (slot >= 0) {
-    // slot is data dependent: write through selects so the arrays stay in registers
-    for (int q = 0; q < 4; q++)
-      if (q == slot) { o.dist[q] = dist; for (int i = 0; i < 3; i++) { o.pos[q][i] = pos[i]; o.nrm[q][i] = n[i]; } }
-  }
+  lc_put(o, slot, dist, pos, n);
 }
 __device__ __forceinline__ void col_plane_mesh(const DevModel& m, const float* pp, const float* pR, const float* mp,
                                             const float* mR, int mesh, LaneContacts& o) {
@@ -342,8 +391,7 @@ __device__ __forceinline__ void col_plane_mesh(const DevModel& m, const float* p
     float wv[3], pos[3];
     matvec(mR, h.v[bi[s]], wv);
     for (int i = 0; i < 3; i++) pos[i] = wv[i] + mp[i] - 0.5f * best[s] * n[i];
-    lc_set(o, o.n, best[s], pos, n);
-    o.n++;
+    lc_push(o, best[s], pos, n);
   }
 }
 __device__ __forceinline__ void col_capsule_mesh(const DevModel& m, const float* cp, const float* cR, const float* cs,
@@ -379,22 +427,23 @@ __device__ __forceinline__ void col_capsule_mesh(const DevModel& m, const float*
     for (int i = 0; i < 3; i++) nmin[i] = lam * h.pl[fl][i] + (1.f - lam) * h.pl[fr][i];
     normalize3(nmin);
   }
-  float tc[3], vc[3], nc3[3][3]; int nc = 0;
-  if (v0 < r) { tc[nc] = 0.f; vc[nc] = v0; for (int i = 0; i < 3; i++) nc3[nc][i] = h.pl[f0][i]; nc++; }
-  if (v1 < r) { tc[nc] = 1.f; vc[nc] = v1; for (int i = 0; i < 3; i++) nc3[nc][i] = h.pl[f1][i]; nc++; }
-  if (nc < 2 && vs < r) {
-    bool dup = false;
-    for (int q = 0; q < nc; q++) if (fabsf(ts - tc[q]) < 1e-4f) dup = true;
-    if (!dup) { tc[nc] = ts; vc[nc] = vs; for (int i = 0; i < 3; i++) nc3[nc][i] = nmin[i]; nc++; }
-  }
-  for (int q = 0; q < nc && q < 2; q++) {
+  // candidates in the order of the sequential list (end 0, end 1, interior minimum), at most two contacts
+  float tc[3] = {0.f, 1.f, ts}, vc[3] = {v0, v1, vs}, nc3[3][3];
+  for (int i = 0; i < 3; i++) { nc3[0][i] = h.pl[f0][i]; nc3[1][i] = h.pl[f1][i]; nc3[2][i] = nmin[i]; }
+  const bool c0 = v0 < r, c1 = v1 < r;
+  bool cv[3] = {c0, c1, false};
+  if (!(c0 && c1) && vs < r) cv[2] = !((c0 && fabsf(ts) < 1e-4f) || (c1 && fabsf(ts - 1.f) < 1e-4f));
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    if (!cv[q] || cnt >= 2) continue;
     const float* pl = nc3[q];
     float pos[3], nrm[3], pw[3], nw[3];
     for (int i = 0; i < 3; i++) { const float c = a[i] + tc[q] * d[i]; nrm[i] = -pl[i]; pos[i] = c - pl[i] * 0.5f * (r + vc[q]); }
     matvec(mR, pos, pw); matvec(mR, nrm, nw);
     for (int i = 0; i < 3; i++) pw[i] += mp[i];
-    lc_set(o, o.n, vc[q] - r, pw, nw);
-    o.n++;
+    lc_push(o, vc[q] - r, pw, nw);
+    cnt++;
   }
 }
 __device__ __forceinline__ void col_box_mesh(const DevModel& m, const float* bp, const float* bR, const float* bh,
@@ -443,18 +492,18 @@ HD void make_frame(float* f) {
 
 // ---- collision driver: lane = pair (two passes when npair > 64); contacts compacted into the workspace
 __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
-  const int tid = threadIdx.x;
+  const int tid = opaque(threadIdx.x);
   if (tid == 0) w.ncon = 0;
   __syncthreads();
   for (int ps = 0; ps * NT < m.npair; ps++) {
     const int p = ps * NT + tid;
-    LaneContacts lc;
-    lc.n = 0;
+    LaneContacts lc{0, &w.col_lc[tid]};
     int g1 = 0, g2 = 0;
+    bool isbb = false;
     if (p < m.npair) {
       g1 = m.pair_geom1[p]; g2 = m.pair_geom2[p];
       const int t1 = m.pair_type1[p], t2 = m.pair_type2[p];
-      const float bound = m.pair_bound[p], margin = m.pair_margin[p];
+      const float bound = m.pair_bound[p];
       const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1];
       const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2];
       bool test = true;
@@ -462,14 +511,14 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         float dv[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
         test = dot3(dv, dv) <= bound * bound;
       }
-      if (test) {
-        const float s1[3] = {m.geom_size[g1][0], m.geom_size[g1][1], m.geom_size[g1][2]};
-        const float s2[3] = {m.geom_size[g2][0], m.geom_size[g2][1], m.geom_size[g2][2]};
+      isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
+      if (test && !isbb) {
+        const float s1[3] = {m.pair_size1[p][0], m.pair_size1[p][1], m.pair_size1[p][2]};
+        const float s2[3] = {m.pair_size2[p][0], m.pair_size2[p][1], m.pair_size2[p][2]};
         if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_CAPSULE) col_plane_capsule(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_BOX) col_plane_box(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_CAPSULE) col_capsule_capsule(p1, R1, s1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_BOX) col_capsule_box(p1, R1, s1, p2, R2, s2, lc);
-        else if (t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX) col_box_box(p1, R1, s1, p2, R2, s2, lc);
         else if (t2 == HOIC_GEOM_MESH) {
           const int mesh = m.pair_mesh[p];
           if (t1 == HOIC_GEOM_CAPSULE) col_capsule_mesh(m, p1, R1, s1, p2, R2, mesh, lc);
@@ -477,25 +526,43 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
           else if (t1 == HOIC_GEOM_PLANE) col_plane_mesh(m, p1, R1, p2, R2, mesh, lc);
         }
       }
-      // margin filter
-      int k2 = 0;
-      for (int q = 0; q < lc.n; q++)
-        if (lc.dist[q] < margin) {
-          if (k2 != q) { lc.dist[k2] = lc.dist[q]; for (int i = 0; i < 3; i++) { lc.pos[k2][i] = lc.pos[q][i]; lc.nrm[k2][i] = lc.nrm[q][i]; } }
-          k2++;
-        }
-      lc.n = k2;
+    }
+    // box-box pairs: one after the other, the whole wave on each (col_box_box_wave)
+    {
+      unsigned long long bbmask = __ballot(isbb);
+      while (bbmask) {
+        const int L = __ffsll((long long)bbmask) - 1;
+        bbmask &= bbmask - 1;
+        const int pp = ps * NT + L, ga = m.pair_geom1[pp], gb = m.pair_geom2[pp];
+        float Pa[3], RA[9], Ha[3], Pb[3], RB[9], Hb[3];
+        for (int i = 0; i < 3; i++) { Pa[i] = w.gxpos[ga][i]; Pb[i] = w.gxpos[gb][i]; Ha[i] = m.pair_size1[pp][i]; Hb[i] = m.pair_size2[pp][i]; }
+        for (int i = 0; i < 9; i++) { RA[i] = w.gxmat[ga][i]; RB[i] = w.gxmat[gb][i]; }
+        const LaneContacts owner{0, &w.col_lc[L]};
+        const int nn = col_box_box_wave(Pa, RA, Ha, Pb, RB, Hb, owner, w.col_poly);
+        if (tid == L) lc.n = nn;
+      }
+      __syncthreads();
+    }
+    // margin filter, then the survivors go from the staging column to their positions in the contact list
+    int cnt = 0;
+    unsigned keepm = 0;
+    float margin = 0.f;
+    if (p < m.npair) {
+      margin = m.pair_margin[p];
+      for (int q = 0; q < lc.n; q++) if (lc_at(lc, q, 0) < margin) { keepm |= 1u << q; cnt++; }
     }
     // exclusive prefix sum of per-lane counts over the wave
-    const int cnt = lc.n, incl = wave_incl_scan(cnt);
-    const int start = w.ncon + incl - cnt;
+    const int incl = wave_incl_scan(cnt);
+    int c = w.ncon + incl - cnt;
     const int total = __builtin_amdgcn_readlane(incl, NT - 1);
     for (int q = 0; q < lc.n; q++) {
-      const int c = start + q;
-      if (c < MAXCON) {
-        w.c_dist[c] = lc.dist[q]; w.c_pair[c] = (unsigned char)p; w.c_g1[c] = (unsigned char)g1; w.c_g2[c] = (unsigned char)g2;
-        for (int i = 0; i < 3; i++) { w.c_pos[c][i] = lc.pos[q][i]; w.c_frame[c][i] = lc.nrm[q][i]; }
-        make_frame(w.c_frame[c]);
+      if ((keepm >> q) & 1u) {
+        if (c < MAXCON) {
+          w.c_dist[c] = lc_at(lc, q, 0); w.c_pair[c] = (unsigned char)p; w.c_g1[c] = (unsigned char)g1; w.c_g2[c] = (unsigned char)g2;
+          for (int i = 0; i < 3; i++) { w.c_pos[c][i] = lc_at(lc, q, 1 + i); w.c_frame[c][i] = lc_at(lc, q, 4 + i); }
+          make_frame(w.c_frame[c]);
+        }
+        c++;
       }
     }
     __syncthreads();

@@ -16,39 +16,45 @@
 #include "hoic_types.h"
 #include "hoic_math.h"
 
-// per-dof constants pinned in registers for the launch (lane & 31 = dof); everything else is re-read from DevModel
-__device__ void dev_load_constants(const DevModel& m, DofK& dk) {
-  const int d = threadIdx.x & 31;
-  const bool v = d < m.nv;
-  dk.arm = v ? m.dof_armature[d] : 0.f; dk.damp = v ? m.dof_damping[d] : 0.f; dk.floss = v ? m.dof_frictionloss[d] : 0.f;
-  dk.flR = v ? m.dof_flR[d] : 1.f; dk.flB = v ? m.dof_flB[d] : 0.f; dk.act = v ? m.dof_actid[d] : -1;
-  const int b = threadIdx.x < m.nbody ? threadIdx.x : 0;
-  for (int i = 0; i < 3; i++) dk.bpath[i] = threadIdx.x < m.nbody ? m.body_path[b][i] : 0xFFFFFFFFu;
+// model constants used every pass -> LDS (once per launch)
+__device__ __forceinline__ void dev_load_constants(const DevModel& m, Work& w) {
+  const int t = threadIdx.x;
+  if (t < NV) {
+    const bool v = t < m.nv;
+    w.k_arm[t] = v ? m.dof_armature[t] : 0.f; w.k_damp[t] = v ? m.dof_damping[t] : 0.f; w.k_floss[t] = v ? m.dof_frictionloss[t] : 0.f;
+    w.k_flR[t] = v ? m.dof_flR[t] : 1.f; w.k_flB[t] = v ? m.dof_flB[t] : 0.f; w.k_act[t] = v ? m.dof_actid[t] : -1;
+  }
+  if (t < NB) for (int i = 0; i < 3; i++) w.k_bpath[t][i] = t < m.nbody ? m.body_path[t][i] : 0xFFFFFFFFu;
+  __syncthreads();
 }
 
 // sum_{d on the packed path} S[d] * x[d]  (+ optional extra[d]) as straight-line code: all LDS reads are issued
 // before the first FMA needs them (one latency instead of one per dof); `below` keeps only dofs < below
 template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[3], const float* x, const float (*extra)[6],
                                           int below, float* V, float* A) {
+  // (the packed path is loop-invariant over the substeps: hidden from the optimiser, or the 12 unpacked indices and
+  // their scaled copies are hoisted out of the substep loop and spilled)
+  const unsigned pk[3] = {path[0], path[1], path[2]};
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     if (i == 6) __builtin_amdgcn_sched_barrier(0);   // two batches of six gathers in flight, not twelve (register peak)
-    const unsigned e = (path[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    const unsigned e = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
     const bool on = e < (unsigned)below;
     const int d = on ? (int)e : 0;
-    const float xd = on ? x[d] : 0.f;
+    const float msk = on ? 1.f : 0.f;
+    const float xd = x[d] * msk;               // unconditional loads (index 0 when off): no exec-masked branches
 #pragma unroll
     for (int k = 0; k < 6; k++) V[k] = fmaf(w.S[d][k], xd, V[k]);
     if (EXTRA) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) A[k] += on ? extra[d][k] : 0.f;
+      for (int k = 0; k < 6; k++) A[k] = fmaf(extra[d][k], msk, A[k]);
     }
   }
 }
 
 // ---- kinematics: body frames, geoms, motion axes S, body inertias about the origin
 __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const float* q) {
-  const int tid = threadIdx.x;
+  const int tid = opaque(threadIdx.x);
   const bool isb = tid < m.nbody;
   float P[3] = {0.f, 0.f, 0.f}, Q[4] = {1.f, 0.f, 0.f, 0.f};
   // 0. lane = joint: joint rotation quaternion / slide displacement (all sincos calls in parallel, constants by
@@ -151,10 +157,10 @@ __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const
   }
   // 3b. per dof: motion axis about the origin (the joint frames of step 1 moved to the world by the parent pose)
   if (tid < m.nv) {
-    const int d = tid, j = m.dof_jntid[d], ty = m.jnt_type[j], b = m.dof_bodyid[d];
+    const int d = tid, j = m.dof_jntid[d], ty = m.dof_jtype[d], b = m.dof_bodyid[d];
     float* S = w.S[d];
     if (ty == HOIC_JNT_FREE) {
-      const int kk = d - m.jnt_dofadr[j];
+      const int kk = m.dof_k[d];
       if (kk < 3) { for (int i = 0; i < 6; i++) S[i] = (i == 3 + kk) ? 1.f : 0.f; }
       else {
         const float e[3] = {kk == 3 ? 1.f : 0.f, kk == 4 ? 1.f : 0.f, kk == 5 ? 1.f : 0.f};
@@ -164,7 +170,7 @@ __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const
         cross3(w.xpos[b], ax, S + 3);
       }
     } else {
-      const int p = m.body_parent[b];
+      const int p = m.dof_parentbody[d];
       const float la[3] = {w.sc.dyn.u.j.jax[j][0], w.sc.dyn.u.j.jax[j][1], w.sc.dyn.u.j.jax[j][2]};
       float ax[3];
       qrot(w.xquat[p], la, ax);
@@ -209,8 +215,8 @@ HD void inert_mul(const float* I, const float* v, float* f) {
 
 // ---- joint-space inertia: composite rigid body sums over index ranges, then row (lane & 31) of M in registers:
 // M[i][j] = S_j . (Ic_body(i) S_i) for j an ancestor-or-self dof of i, mirrored for descendants, 0 elsewhere
-__device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, const DofK& dk, MReg& M) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg& M) {
+  const int tid = opaque(threadIdx.x);
   if (tid < m.nbody) {
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
@@ -234,7 +240,7 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, cons
     const int j = MREG_ROW(reg, hi);          // per half-wave uniform: LDS broadcasts
     const float a = dot6(w.S[j], fSi), bb = dot6(Si, w.sc.dyn.u.f.fS[j]);
     float v = ((am >> j) & 1u) ? a : (((dm >> j) & 1u) ? bb : 0.f);
-    if (j == d) v += dk.arm;
+    if (j == d) v += w.k_arm[d];
     M.r[reg] = v;
   }
   __syncthreads();
@@ -242,7 +248,7 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, cons
 
 // (M x)[lane & 31] on every lane, x in LDS: each half-wave sums its 16 columns, one cross-half add
 HD float dev_Mx(const MReg& M, const float* x) {
-  const int hi = threadIdx.x >> 5;
+  const int hi = opaque(threadIdx.x) >> 5;
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; g++) {
@@ -271,12 +277,11 @@ HD void cross_force(const float* v, const float* f, float* o) {
 //   cdd_d = (velocity of the chain above dof d) x S_d * qvel_d          (lane = dof)
 //   V_b = sum_{d on path(b)} S_d qvel_d,  A_b = a_world + sum cdd_d       (lane = body)
 //   f_b = I_b A_b + V_b x* I_b V_b;  subtree range sums;  bias_d = S_d . fsub_body(d)
-__device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const DofK& dk, const float* qvel) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float* qvel) {
+  const int tid = opaque(threadIdx.x);
   if (tid < m.nv) {
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sd[6];
-    const int b = m.dof_bodyid[tid];
-    const unsigned pth[3] = {m.body_path[b][0], m.body_path[b][1], m.body_path[b][2]};
+    const unsigned pth[3] = {m.dof_bpath[tid][0], m.dof_bpath[tid][1], m.dof_bpath[tid][2]};
     path_gather<false>(w, pth, qvel, nullptr, tid, v, nullptr);   // dofs above `tid` on its path
     cross_motion(v, w.S[tid], sd);
     const float qd = qvel[tid];
@@ -285,9 +290,10 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const DofK&
   __syncthreads();
   if (tid < m.nbody) {
     float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (dk.bpath[0] != 0xFFFFFFFFu) {
+    const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
+    if (bp[0] != 0xFFFFFFFFu) {
       float V[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, A[6] = {0.f, 0.f, 0.f, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-      path_gather<true>(w, dk.bpath, qvel, w.sc.dyn.u.f.fS, 0xFF, V, A);
+      path_gather<true>(w, bp, qvel, w.sc.dyn.u.f.fS, 0xFF, V, A);
       float Iv[6], Ia[6], x[6];
       inert_mul(w.sc.dyn.I10[tid], V, Iv); inert_mul(w.sc.dyn.I10[tid], A, Ia); cross_force(V, Iv, x);
       for (int i = 0; i < 6; i++) f[i] = Ia[i] + x[i];

@@ -24,23 +24,23 @@ struct ExpertView {
 };
 
 // ---- position + velocity stages of the forward pass on state (q, v); leaves M (registers), bias, contacts, S
-__device__ __forceinline__ void dev_forward_kin(const DevModel& m, Work& w, const DofK& dk, MReg& M, const float* q, const float* v, int* overflow) {
+__device__ __forceinline__ void dev_forward_kin(const DevModel& m, Work& w, MReg& M, const float* q, const float* v, int* overflow) {
   dev_kinematics(m, w, q); PT(3);
 #ifdef HOIC_EXP_KIN      // cost experiments (development aid): repeat one stage, measure the kernel-time delta
   for (int rep = 0; rep < HOIC_EXP_KIN; rep++) { asm volatile("" ::: "memory"); dev_kinematics(m, w, q); }
 #endif
-  dev_mass_matrix(m, w, dk, M); PT(4);
+  dev_mass_matrix(m, w, M); PT(4);
 #ifdef HOIC_EXP_MASS
-  for (int rep = 0; rep < HOIC_EXP_MASS; rep++) { asm volatile("" ::: "memory"); dev_mass_matrix(m, w, dk, M); }
+  for (int rep = 0; rep < HOIC_EXP_MASS; rep++) { asm volatile("" ::: "memory"); dev_mass_matrix(m, w, M); }
 #endif
 #ifndef HOIC_X_NOBIAS
-  dev_bias(m, w, dk, v); PT(5);
+  dev_bias(m, w, v); PT(5);
 #endif
 #ifdef HOIC_EXP_BIAS
-  for (int rep = 0; rep < HOIC_EXP_BIAS; rep++) { asm volatile("" ::: "memory"); dev_bias(m, w, dk, v); }
+  for (int rep = 0; rep < HOIC_EXP_BIAS; rep++) { asm volatile("" ::: "memory"); dev_bias(m, w, v); }
 #endif
   // the narrow phase is the register peak of the kernel: M is parked in the (idle) solve scratch across it
-  float* park = w.sc.T + threadIdx.x;
+  float* park = w.sc.T + opaque(threadIdx.x);
 #pragma unroll
   for (int i = 0; i < 16; i++) park[i * NT] = M.r[i];
 #ifndef HOIC_X_NOCOLL
@@ -56,7 +56,7 @@ __device__ __forceinline__ void dev_forward_kin(const DevModel& m, Work& w, cons
 
 // ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass
 __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev) {
-  const int tid = threadIdx.x, d = tid & 31, n = m.hand_nv;
+  const int tid = opaque(threadIdx.x), d = tid & 31, n = m.hand_nv;
   const float dt = m.timestep;
   float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
   if (d < n) {
@@ -91,7 +91,7 @@ __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, 
 
 // ---- generalized applied forces: gravity compensation + residual object wrench, lagged Jacobians
 __device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
-  const int tid = threadIdx.x;
+  const int tid = opaque(threadIdx.x);
   if (tid < NV) {
     float s = 0.f;
     if (tid < m.nv) {
@@ -106,7 +106,7 @@ __device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, co
 
 // ---- record_contact (ho_im4.py:883-889): lane = hand geom, deterministic accumulation order
 __device__ void dev_record_contact(const DevModel& m, Work& w) {
-  const int tid = threadIdx.x;
+  const int tid = opaque(threadIdx.x);
   if (tid < NHG) {
     const int g = m.hand_geom0 + tid;
     for (int c = 0; c < w.ncon; c++) {

@@ -112,6 +112,9 @@ HD float wave_max(float v) {
   v = fmaxf(v, dpp_mov<0x140>(v));
   return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
 }
+HD float wave_min(float v) { return -wave_max(-v); }
+HD float sel3(float v0, float v1, float v2, int i) { return i == 0 ? v0 : (i == 1 ? v1 : v2); }
+HD void sel3v(const float (*A)[3], int i, float* o) { for (int k = 0; k < 3; k++) o[k] = sel3(A[0][k], A[1][k], A[2][k], i); }
 HD double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -159,12 +159,13 @@ struct RowEval { float jar_f, force_f, curv_f, jar_l, force_l, curv_l, jar_c[NCS
 
 // ---- u[c][k] = (contact-frame Jacobian row k of contact c) . x, Jacobian-free:
 // body spatial velocities V_b = sum_{d on the path of b} S[d] x[d], then W[c][k] . (V_b2 - V_b1)
-__device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const DofK& dk, const float* x) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const float* x) {
+  const int tid = opaque(threadIdx.x);
   if (w.ncon == 0) return;
   if (tid < m.nbody) {
     float V[6] = {0, 0, 0, 0, 0, 0};
-    path_gather<false>(w, dk.bpath, x, nullptr, 0xFF, V, nullptr);
+    const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
+    path_gather<false>(w, bp, x, nullptr, 0xFF, V, nullptr);
 #pragma unroll
     for (int i = 0; i < 6; i++) w.bV[tid][i] = V[i];
   }
@@ -204,27 +205,26 @@ HD float cost_onesided(float D, float jar, float& force, float& curv) {
 }
 
 // ---- constraint rows for the current kinematics / contacts
-__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, const DofK& dk, RowK& rk, const float* qpos, const float* qvel) {
-  const int tid = threadIdx.x, d = tid & 31;
+__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, const float* qpos, const float* qvel) {
+  const int tid = opaque(threadIdx.x), d = tid & 31;
   // friction loss and joint limit of dof d (one side per joint can be active: every range is wider than twice
   // the margin; slide and hinge joints have exactly one dof)
   rk.f_aref = 0.f; rk.l_sign = 0.f; rk.l_D = 0.f; rk.l_aref = 0.f;
   if (d < m.nv) {
     const float qv = qvel[d];
-    rk.f_aref = -dk.flB * qv;
-    const int j = m.dof_jntid[d];
-    if (m.jnt_limited[j] && m.jnt_type[j] != HOIC_JNT_FREE) {
-      const float q = qpos[m.jnt_qposadr[j]], margin = m.jnt_margin[j];
-      const float dl = q - m.jnt_range[j][0], du = m.jnt_range[j][1] - q;
+    rk.f_aref = -w.k_flB[d] * qv;
+    if (m.dof_limited[d]) {
+      const float q = qpos[m.dof_qadr[d]], margin = m.dof_margin[d];
+      const float dl = q - m.dof_range[d][0], du = m.dof_range[d][1] - q;
       float dist = 0.f, sgn = 0.f;
       if (dl < margin) { dist = dl; sgn = 1.f; }
       else if (du < margin) { dist = du; sgn = -1.f; }
       if (sgn != 0.f) {
-        const float si[5] = {m.jnt_solimp[j][0], m.jnt_solimp[j][1], m.jnt_solimp[j][2], m.jnt_solimp[j][3], m.jnt_solimp[j][4]};
+        const float si[5] = {m.dof_solimp[d][0], m.dof_solimp[d][1], m.dof_solimp[d][2], m.dof_solimp[d][3], m.dof_solimp[d][4]};
         const float imp = dev_impedance(si, dist, margin);
-        const float R = fmaxf(MINVALF, (1.f - imp) * m.jnt_diag[j] / imp);
+        const float R = fmaxf(MINVALF, (1.f - imp) * m.dof_limdiag[d] / imp);
         rk.l_sign = sgn; rk.l_D = 1.f / R;
-        rk.l_aref = -m.jnt_B[j] * (sgn * qv) - m.jnt_K[j] * imp * (dist - margin);
+        rk.l_aref = -m.dof_limB[d] * (sgn * qv) - m.dof_limK[d] * imp * (dist - margin);
       }
     }
   }
@@ -246,8 +246,7 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
       w.c_nrow[c] = (unsigned char)nrow;
       const int b1 = m.pair_b1[p], b2 = m.pair_b2[p];
       w.c_b1[c] = (unsigned char)b1; w.c_b2[c] = (unsigned char)b2;
-      const unsigned m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2];
-      w.c_mpos[c] = m2 & ~m1; w.c_mneg[c] = m1 & ~m2;
+      w.c_mpos[c] = m.pair_mpos[p]; w.c_mneg[c] = m.pair_mneg[p];
       const float* f = w.c_frame[c];
       for (int k = 0; k < 3; k++) cross3(w.c_pos[c], f + 3 * k, w.c_pxf[c][k]);
     }
@@ -262,7 +261,7 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
   }
   __syncthreads();
   // reference accelerations of the contact rows
-  dev_basis_dot(m, w, dk, qvel);
+  dev_basis_dot(m, w, qvel);
   for (int r = tid; r < w.nrow; r += NT) {
     const int c = w.cr_con[r];
     w.cr_aref[r] = -w.c_B[c] * dev_crow_times(w, r) + w.c_aref0[c];
@@ -273,9 +272,9 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
 // ---- row state.  jar = J x - aref of every row: per-dof rows in the registers of lane & 31 = dof (both
 // half-waves), contact rows NCSLOT per lane.  dev_rows_jar needs one Jacobian product (dev_basis_dot);
 // dev_rows_cost turns jar into cost, forces and curvatures (contact rows: LDS cr_force / cr_curv) and is cheap.
-__device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const DofK& dk, const RowK& rk, const float* x, bool with_aref, RowEval& ev) {
-  const int tid = threadIdx.x;
-  dev_basis_dot(m, w, dk, x);
+__device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const RowK& rk, const float* x, bool with_aref, RowEval& ev) {
+  const int tid = opaque(threadIdx.x);
+  dev_basis_dot(m, w, x);
   const float xd = ((tid & 31) < m.nv) ? x[tid & 31] : 0.f;
   ev.jar_f = xd - (with_aref ? rk.f_aref : 0.f);
   ev.jar_l = rk.l_sign * xd - (with_aref ? rk.l_aref : 0.f);
@@ -291,7 +290,7 @@ __device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const D
 }
 // D_c: curvature constant of this lane's contact rows (c_D of the row's contact), loaded once per solve
 __device__ __forceinline__ float dev_rows_cost(const DevModel& m, Work& w, const DofK& dk, const RowK& rk, const float (&D_c)[NCSLOT], RowEval& ev) {
-  const int tid = threadIdx.x;
+  const int tid = opaque(threadIdx.x);
   float cost = 0.f;
   ev.force_f = ev.curv_f = ev.force_l = ev.curv_l = 0.f;
   if ((tid & 31) < m.nv) {     // both half-waves keep the per-dof rows (the solve needs the curvature on all 64 lanes)
@@ -358,12 +357,13 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
 // ---- Newton with exact line search.  In: M, fsmooth, asmooth, warm, rows.  Out: qacc, fcon (LDS).
 // The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
 // line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
-__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const DofK& dk, const RowK& rk, int maxit) {
-  const int tid = threadIdx.x, d = tid & 31;
+__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, int maxit) {
+  const int tid = opaque(threadIdx.x), d = tid & 31;
   const bool vd = d < m.nv;
   const float scale = 1.f / (m.meaninertia * (float)max(m.nv, 1));
   const float fs = w.fsmooth[d], a0 = w.asmooth[d], wm = w.warm[d];
   const int nrow = w.nrow;
+  const DofK dk{w.k_floss[d], w.k_flR[d]};
   float D_c[NCSLOT];
 #pragma unroll
   for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; D_c[k] = (r < nrow) ? w.c_D[w.cr_con[r]] : 0.f; }
@@ -371,9 +371,9 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   const float Mw = vd ? dev_Mx(M, w.warm) : 0.f;
   const float gw = wave_sum((tid < m.nv) ? 0.5f * (Mw - fs) * (wm - a0) : 0.f);
   RowEval ev, evw;
-  dev_rows_jar(m, w, dk, rk, w.asmooth, true, ev);
+  dev_rows_jar(m, w, rk, w.asmooth, true, ev);
   const float cs = dev_rows_cost(m, w, dk, rk, D_c, ev);
-  dev_rows_jar(m, w, dk, rk, w.warm, true, evw);
+  dev_rows_jar(m, w, rk, w.warm, true, evw);
   const float cw = gw + dev_rows_cost(m, w, dk, rk, D_c, evw);
   const bool usewarm = cw < cs;
   float qacc = vd ? (usewarm ? wm : a0) : 0.f, Ma = vd ? (usewarm ? Mw : fs) : 0.f;   // M asmooth = fsmooth
@@ -398,7 +398,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     if (tid < m.nv) { gq = (Ma - fs) * sd; hh = sd * Ms; g0 = g * sd; }
     gq = wave_sum(gq); hh = wave_sum(hh); g0 = wave_sum(g0);
     RowEval jv;
-    dev_rows_jar(m, w, dk, rk, w.search, false, jv);
+    dev_rows_jar(m, w, rk, w.search, false, jv);
     float a = 0.f, lo = 0.f, hi = -1.f, alpha = 0.f;
     for (int ls = 0; ls < 10; ls++) {
       float dphi = 0.f, ddphi = 0.f, f, cv;

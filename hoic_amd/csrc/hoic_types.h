@@ -50,6 +50,10 @@ struct DevModel {
   float jnt_diag[NJ];  // dof_invweight0 of the joint's dof (limit row diagApprox)
   float qpos0[NQP];
   int dof_bodyid[NV], dof_jntid[NV], dof_actid[NV];
+  // per-dof copies of the joint / body tables (flat: one load level, no joint -> dof -> body index chains)
+  int dof_jtype[NV], dof_k[NV], dof_parentbody[NV], dof_qadr[NV], dof_limited[NV];
+  unsigned dof_bpath[NV][3];   // body_path of the dof's body
+  float dof_range[NV][2], dof_margin[NV], dof_limK[NV], dof_limB[NV], dof_limdiag[NV], dof_solimp[NV][5];
   unsigned dof_amask[NV];   // dofs strictly above dof d on its path (ancestors)
   unsigned dof_dmask[NV];   // dofs strictly below dof d (every dof whose path contains d)
   float dof_armature[NV], dof_damping[NV], dof_frictionloss[NV];
@@ -62,6 +66,8 @@ struct DevModel {
   int pair_geom1[NPAIR], pair_geom2[NPAIR], pair_condim[NPAIR], pair_b1[NPAIR], pair_b2[NPAIR];
   int pair_type1[NPAIR], pair_type2[NPAIR], pair_mesh[NPAIR];
   float pair_bound[NPAIR];   // rbound1 + rbound2 + margin
+  float pair_size1[NPAIR][3], pair_size2[NPAIR][3];
+  unsigned pair_mpos[NPAIR], pair_mneg[NPAIR];   // dofs moving body2 only / body1 only
   float pair_mu[NPAIR][3], pair_K[NPAIR], pair_B[NPAIR], pair_solimp[NPAIR][5], pair_margin[NPAIR], pair_gap[NPAIR];
   float pair_Rscale[NPAIR];  // R = max(MINVAL,(1-imp)/imp) * Rscale  (pyramidal: 2 mu^2 tran (1+mu^2); condim 1: tran)
   // convex meshes (hull vertices and face planes in the geom frame)
@@ -123,14 +129,17 @@ struct DevState {
 struct MReg { float r[16]; };
 #define MREG_ROW(reg, hi) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hi))
 
-// per-lane constants kept in registers for the whole launch (lane & 31 = dof; bpath: lane = body)
-struct DofK { float arm, damp, floss, flR, flB; int act; unsigned bpath[3]; /* lane = body: body_path */ };
+// per-dof / per-body model constants used every pass live in LDS (Work::k_*): a read costs one LDS latency, not a
+// global / scratch round trip, and no register is pinned for the whole launch
+struct DofK { float floss, flR; };   // friction-loss row constants of dof (lane & 31), held in registers only inside the solve
 
 // per-env LDS workspace
 struct Work {
   float qpos[NQP], qvel[NV], qacc[NV], warm[NV], qlag[NQP], vlag[NV], action[NV];
   float ctrl[NV], applied[NV], bias[NV], fsmooth[NV], asmooth[NV], fcon[NV];
-  float grad[NV], search[NV], Ma[NV], tv[NV], tv2[NV];
+  // model constants used every pass (loaded once per launch)
+  float k_arm[NV], k_damp[NV], k_floss[NV], k_flR[NV], k_flB[NV]; int k_act[NV];
+  unsigned k_bpath[NB][3];
   // kinematics of the last forward pass
   float xpos[NB][3], xquat[NB][4];
   float S[NV][6];                      // motion axes [angular; linear at the world origin]
@@ -154,18 +163,26 @@ struct Work {
   int ncon, nrow, solver_iter, fail;
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
   unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
-  // derived per-contact data.  Jacobian-free contacts: row (c,k) of the contact Jacobian is
-  //   sg(dof,c) * S[dof] . W[c][k],   W[c][k] = [p x f_k ; f_k] (k = n,t1,t2),  [f_n ; 0] (spin)
-  // with p x f_k kept in c_pxf and f_k in c_frame.
-  float c_pxf[MAXCON][3][3], c_mu[MAXCON][3], c_D[MAXCON], c_aref0[MAXCON], c_B[MAXCON];
-  unsigned char c_nrow[MAXCON], c_b1[MAXCON], c_b2[MAXCON], c_row0[MAXCON];
-  unsigned c_mpos[MAXCON], c_mneg[MAXCON];   // dofs moving body2 only (+1) / body1 only (-1)
-  float c_G[MAXCON][6];
-  float u[MAXCON * 4];
-  float bV[NB][6];                           // body spatial velocities for J.x products
-  // contact rows (pyramid edges)
-  float cr_aref[NCROW], cr_force[NCROW], cr_curv[NCROW];
-  unsigned char cr_con[NCROW], cr_edge[NCROW];
+  union {
+    // ---- solver phase: derived per-contact data, contact rows, search direction.
+    // Jacobian-free contacts: row (c,k) of the contact Jacobian is
+    //   sg(dof,c) * S[dof] . W[c][k],   W[c][k] = [p x f_k ; f_k] (k = n,t1,t2),  [f_n ; 0] (spin)
+    // with p x f_k kept in c_pxf and f_k in c_frame.
+    struct {
+      float c_pxf[MAXCON][3][3], c_mu[MAXCON][3], c_D[MAXCON], c_aref0[MAXCON], c_B[MAXCON];
+      unsigned char c_nrow[MAXCON], c_b1[MAXCON], c_b2[MAXCON], c_row0[MAXCON];
+      unsigned c_mpos[MAXCON], c_mneg[MAXCON];   // dofs moving body2 only (+1) / body1 only (-1)
+      float c_G[MAXCON][6];
+      float u[MAXCON * 4];
+      float bV[NB][6];                           // body spatial velocities for J.x products
+      float cr_aref[NCROW], cr_force[NCROW], cr_curv[NCROW];   // contact rows (pyramid edges)
+      unsigned char cr_con[NCROW], cr_edge[NCROW];
+      float search[NV];
+    };
+    // ---- collision phase: every lane (= pair) stages up to 4 contacts of 7 floats (dist, pos, normal), element
+    // (q, k) of lane l at col_lc[(q * 7 + k) * NT + l]; clipping scratch of the wave-cooperative box-box
+    struct { float col_lc[4 * 7 * NT]; float col_poly[32]; };
+  };
   // contact bookkeeping over the env step (record_contact)
   float rec_sum[NHG][12]; int rec_cnt[NHG];
 #ifdef HOIC_PHASE_TIMING
