@@ -161,6 +161,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       dev_pd_torque(ml, cl, w, M, ev); PT(1);     // :518-523
 #endif
       dev_applied(ml, cl, w, vf, vt);             // :526-540
+#ifdef HOIC_EXP_GLUE
+      { asm volatile("" ::: "memory"); dev_record_contact(ml, w); dev_applied(ml, cl, w, vf, vt); }
+#endif
+#ifdef HOIC_EXP_PD
+      { asm volatile("" ::: "memory"); dev_pd_torque(ml, cl, w, M, ev); }
+#endif
     }
     dev_forward_kin(ml, w, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
     if (mode == 0) {
@@ -182,6 +188,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       mode = 2;
       continue;
     }
+#ifdef HOIC_EXP_EULER
+    { if (tid < NV) w.tv0[tid] = w.qvel[tid]; if (tid < NQP) w.tq0[tid] = w.qpos[tid]; __syncthreads(); dev_euler(ml, w, M);
+      if (tid < NV) w.qvel[tid] = w.tv0[tid]; if (tid < NQP) w.qpos[tid] = w.tq0[tid]; __syncthreads(); }
+#endif
     dev_euler(ml, w, M); PT(10);              //              ... + Euler
     if (++done_sub >= nsub) break;
   }
@@ -395,7 +405,9 @@ struct hoic_sim {
   DevState st{};
   int *d_iota_seq = nullptr, *d_iota_start = nullptr;
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  static const int NEV = 64;          // ring of timing events: steps are timed without a host sync per step
+  hipEvent_t ev[NEV][3] = {};
+  long long n_timed = 0, n_drained = 0;
   bool has_expert = false;
 };
 
@@ -663,9 +675,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
                   s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
-  if (s->ev0) hipEventDestroy(s->ev0);
-  if (s->ev1) hipEventDestroy(s->ev1);
-  if (s->ev2) hipEventDestroy(s->ev2);
+  for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   delete s;
 }
 
@@ -745,12 +755,13 @@ extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, f
   if ((d_next_seq == nullptr) != (d_next_start == nullptr)) { set_err("hoic_step: next_seq/next_start must come together"); return HOIC_ERR_ARG; }
   if (!s->has_expert) { set_err("hoic_step: set_expert has not been called"); return HOIC_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
-  if (s->timing) hipEventRecord(s->ev0, st);
+  hipEvent_t* e = s->timing ? s->ev[s->n_timed % hoic_sim::NEV] : nullptr;
+  if (e) hipEventRecord(e[0], st);
   hipLaunchKernelGGL(hoic_substep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action);
-  if (s->timing) hipEventRecord(s->ev1, st);
+  if (e) hipEventRecord(e[1], st);
   hipLaunchKernelGGL(hoic_poststep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
                      d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start);
-  if (s->timing) hipEventRecord(s->ev2, st);
+  if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -789,23 +800,40 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
 
 extern "C" int32_t hoic_enable_timing(hoic_sim* s, int32_t enable) {
   if (!s) return HOIC_ERR_ARG;
-  if (enable && !s->ev0) { HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); HIPCHK(hipEventCreate(&s->ev2)); }
+  if (enable && !s->ev[0][0])
+    for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) HIPCHK(hipEventCreate(&s->ev[i][k]));
   s->timing = enable != 0;
+  s->n_drained = s->n_timed;
   return HOIC_OK;
 }
-extern "C" float hoic_last_step_ms(hoic_sim* s) {
-  if (!s || !s->timing || !s->ev1) return -1.f;
-  if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.f;
+static float ev_ms(hipEvent_t a, hipEvent_t b) {
+  if (hipEventSynchronize(b) != hipSuccess) return -1.f;
   float ms = -1.f;
-  if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.f;
   return ms;
 }
+extern "C" float hoic_last_step_ms(hoic_sim* s) {
+  if (!s || !s->ev[0][0] || s->n_timed == 0) return -1.f;
+  hipEvent_t* e = s->ev[(s->n_timed - 1) % hoic_sim::NEV];
+  return ev_ms(e[0], e[1]);
+}
 extern "C" float hoic_last_poststep_ms(hoic_sim* s) {
-  if (!s || !s->timing || !s->ev2) return -1.f;
-  if (hipEventSynchronize(s->ev2) != hipSuccess) return -1.f;
-  float ms = -1.f;
-  if (hipEventElapsedTime(&ms, s->ev1, s->ev2) != hipSuccess) return -1.f;
-  return ms;
+  if (!s || !s->ev[0][0] || s->n_timed == 0) return -1.f;
+  hipEvent_t* e = s->ev[(s->n_timed - 1) % hoic_sim::NEV];
+  return ev_ms(e[1], e[2]);
+}
+extern "C" int32_t hoic_step_times(hoic_sim* s, float* substep_ms, float* poststep_ms, int32_t max_n) {
+  if (!s || !substep_ms || !poststep_ms || max_n <= 0) return HOIC_ERR_ARG;
+  if (!s->ev[0][0]) return 0;
+  long long first = s->n_drained;
+  if (s->n_timed - first > hoic_sim::NEV) first = s->n_timed - hoic_sim::NEV;     // older ones were overwritten
+  int n = 0;
+  for (long long i = first; i < s->n_timed && n < max_n; i++, n++) {
+    hipEvent_t* e = s->ev[i % hoic_sim::NEV];
+    substep_ms[n] = ev_ms(e[0], e[1]); poststep_ms[n] = ev_ms(e[1], e[2]);
+  }
+  s->n_drained = first + n;
+  return n;
 }
 
 // development aid (not part of include/hoic.h): per-phase shader-cycle counters of the last step, averaged over

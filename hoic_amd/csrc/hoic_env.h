@@ -39,16 +39,9 @@ __device__ __forceinline__ void dev_forward_kin(const DevModel& m, Work& w, MReg
 #ifdef HOIC_EXP_BIAS
   for (int rep = 0; rep < HOIC_EXP_BIAS; rep++) { asm volatile("" ::: "memory"); dev_bias(m, w, v); }
 #endif
-  // the narrow phase is the register peak of the kernel: M is parked in the (idle) solve scratch across it
-  float* park = w.sc.T + opaque(threadIdx.x);
-#pragma unroll
-  for (int i = 0; i < 16; i++) park[i * NT] = M.r[i];
 #ifndef HOIC_X_NOCOLL
   dev_collision(m, w, overflow); PT(6);
 #endif
-#pragma unroll
-  for (int i = 0; i < 16; i++) M.r[i] = park[i * NT];
-  __syncthreads();
 #ifdef HOIC_EXP_COLL
   for (int rep = 0; rep < HOIC_EXP_COLL; rep++) { asm volatile("" ::: "memory"); dev_collision(m, w, nullptr); }
 #endif

@@ -115,10 +115,24 @@ HD float wave_max(float v) {
 HD float wave_min(float v) { return -wave_max(-v); }
 HD float sel3(float v0, float v1, float v2, int i) { return i == 0 ? v0 : (i == 1 ? v1 : v2); }
 HD void sel3v(const float (*A)[3], int i, float* o) { for (int k = 0; k < 3; k++) o[k] = sel3(A[0][k], A[1][k], A[2][k], i); }
+// float64 wave sum on the DPP crossbar (two 32-bit moves per step) instead of six ds_bpermute round trips
+template <int CTRL> HD double dpp_mov_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+HD double rl_d(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 HD double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_mov_d<0xb1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_d<0x4e>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_d<0x141>(v);   // row_half_mirror
+  v += dpp_mov_d<0x140>(v);   // row_mirror
+  return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
 }
 // inclusive prefix sum of a small non-negative integer over the wave (ballot-free, DPP row shifts + readlanes)
 HD int wave_incl_scan(int v) {

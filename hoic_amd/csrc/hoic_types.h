@@ -137,6 +137,9 @@ struct DofK { float floss, flR; };   // friction-loss row constants of dof (lane
 struct Work {
   float qpos[NQP], qvel[NV], qacc[NV], warm[NV], qlag[NQP], vlag[NV], action[NV];
   float ctrl[NV], applied[NV], bias[NV], fsmooth[NV], asmooth[NV], fcon[NV];
+#ifdef HOIC_EXP_EULER
+  float tv0[NV], tq0[NQP];
+#endif
   // model constants used every pass (loaded once per launch)
   float k_arm[NV], k_damp[NV], k_floss[NV], k_flR[NV], k_flB[NV]; int k_act[NV];
   unsigned k_bpath[NB][3];

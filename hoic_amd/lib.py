@@ -41,7 +41,7 @@ class RewardParams(C.Structure):
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_enable_timing",
-           "hoic_last_step_ms", "hoic_last_poststep_ms"]
+           "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times"]
 
 
 def build(force: bool = False) -> str:
@@ -86,6 +86,7 @@ def load():
     L.hoic_last_step_ms.argtypes = [vp]
     L.hoic_last_step_ms.restype = f32
     L.hoic_last_poststep_ms.argtypes = [vp]
+    L.hoic_step_times.argtypes = [vp, vp, vp, i32]
     L.hoic_last_poststep_ms.restype = f32
     for n in EXPORTS:
         if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms", "hoic_last_poststep_ms"):
@@ -231,6 +232,14 @@ class BatchedSim:
 
     def last_poststep_ms(self):
         return float(self.L.hoic_last_poststep_ms(self.h))
+
+    def step_times(self, max_n=64):
+        """(substep_ms, poststep_ms) lists of the launches since the previous call (no per-step host sync)"""
+        a = (C.c_float * max_n)(); b = (C.c_float * max_n)()
+        n = self.L.hoic_step_times(self.h, a, b, max_n)
+        if n < 0:
+            raise HoicError("hoic_step_times failed")
+        return list(a[:n]), list(b[:n])
 
     def probe_forward(self, qpos, qvel, ctrl=None, applied=None, warm=None, do_step=False):
         """mj_forward (+ Euler) at arbitrary states; returns a dict of numpy arrays."""

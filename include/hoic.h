@@ -114,6 +114,10 @@ int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const fl
 int32_t hoic_enable_timing(hoic_sim* s, int32_t enable);
 float hoic_last_step_ms(hoic_sim* s);
 float hoic_last_poststep_ms(hoic_sim* s);
+/* Durations of the launches recorded since the previous call (a ring of 64 event sets, so that a rollout is timed
+ * without one host synchronisation per step); blocks until the last of them has finished.  Returns the number of
+ * entries written (<= max_n), or a negative hoic_status. */
+int32_t hoic_step_times(hoic_sim* s, float* substep_ms, float* poststep_ms, int32_t max_n);
 
 #ifdef __cplusplus
 }
