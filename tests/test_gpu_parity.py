@@ -117,6 +117,62 @@ def test_forward_dynamics_parity(obj, oracle_lib):
     assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < 6e-5, worst
 
 
+def test_box_box_contact_sets(box_blob, oracle_lib, setup):
+    """The wave-cooperative box-box routine (15 SAT axes on 15 lanes, clipped polygon one vertex per lane) against
+    the sequential oracle: face contacts (flat and tilted on the table), edge-edge contacts and separated pairs,
+    including the palm boxes against the object.  Contact sets must agree in count, order, distance and frame."""
+    cfg, ex, thresh = setup
+    N = 192
+    sim = _sim(box_blob, N, cfg, ex, thresh)
+    rng = np.random.default_rng(5)
+    A = sim.model.arrays
+    mid = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1])
+    qs = []
+    for i in range(N):
+        q = np.zeros(33); q[:26] = mid
+        kind = i % 4
+        quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+        if kind == 0:      # flat on the table, small yaw, slight penetration
+            a = rng.uniform(0, 2 * np.pi); quat = np.array([np.cos(a / 2), 0, 0, np.sin(a / 2)])
+            q[:3] = [0.0, 0.0, 0.95]; q[26:29] = [rng.uniform(-.2, .2), rng.uniform(-.2, .2), 0.5 + 0.049 - rng.uniform(0, 2e-3)]
+        elif kind == 1:    # tilted: one edge / corner pressed into the table
+            tilt = rng.normal(size=3) * 0.4; ang = np.linalg.norm(tilt)
+            quat = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * tilt / ang])
+            q[:3] = [0.0, 0.0, 0.95]; q[26:29] = [rng.uniform(-.2, .2), rng.uniform(-.2, .2), 0.5 + rng.uniform(0.02, 0.05)]
+        elif kind == 2:    # arbitrary orientation near the table surface
+            q[:3] = [0.0, 0.0, 0.95]; q[26:29] = [rng.uniform(-.2, .2), rng.uniform(-.2, .2), 0.5 + rng.uniform(0.01, 0.06)]
+        else:              # near the palm: palm boxes against the object, away from the table
+            q[:3] = [0.0, 0.0, 0.85]; q[3:6] = rng.normal(size=3) * 0.3
+            q[26:29] = np.array([0.0, 0.0, 0.85]) + rng.normal(size=3) * 0.03
+        q[29:33] = quat
+        qs.append(q)
+    qs = np.array(qs); vs = np.zeros((N, 32))
+    out = sim.probe_forward(qs, vs)
+    e = oracle_lib.OracleEnv(box_blob)
+    g_first_box = 1      # geoms 1 (table) and 2..5 (palm) are boxes, the object box is geom obj_geom0
+    og = sim.model.scalar("obj_geom0")
+    n_bb = n_multi = n_edge = mism = 0
+    for i in range(N):
+        e.set("qpos", qs[i]); e.set("qvel", vs[i]); e.set("qacc_warmstart", np.zeros(32)); e.forward()
+        c = e.contacts(); nc = len(c)
+        if nc != out["ncon"][i]:
+            mism += 1
+            continue
+        if nc == 0:
+            continue
+        g = out["contacts"][i, :nc]
+        assert np.array_equal(g[:, 13:16], c[:, 13:16])
+        bb = (c[:, 13] >= g_first_box) & (c[:, 13] <= 5) & (c[:, 14] == og)
+        n_bb += int(bb.sum())
+        for g1 in np.unique(c[bb, 13]):
+            k = int((bb & (c[:, 13] == g1)).sum())
+            n_multi += k >= 3; n_edge += k == 1
+        np.testing.assert_allclose(g[bb, 0], c[bb, 0], atol=3e-6)
+        np.testing.assert_allclose(g[bb, 1:13], c[bb, 1:13], atol=3e-5)
+    assert mism <= 3, mism                      # a vertex at |depth| ~ 1e-7 may exist in one precision only
+    assert n_bb > 150 and n_multi > 30 and n_edge > 5, (n_bb, n_multi, n_edge)
+
+
 @pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
 def test_env_step_parity_short_horizon(obj, oracle_lib):
     box_blob, cfg, ex, thresh = _obj_setup(obj)
