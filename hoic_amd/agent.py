@@ -102,6 +102,11 @@ class PPOLearner:
         advantages, returns = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau,
                                                   batch.next_values, dist_group=True if self.distributed else None)
         advantages = advantages.reshape(T * N, 1); returns = returns.reshape(T * N, 1)
+        self.optimize(states, actions, advantages, returns)
+        return time.time() - t0
+
+    def optimize(self, states, actions, advantages, returns):
+        """The 5 full-batch epochs of value and policy steps (agent_ppo.py:16-56) on flat [M, .] tensors."""
         with torch.no_grad(), self._autocast():
             fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
         vparams = list(self.value_net.parameters())
@@ -125,7 +130,6 @@ class PPOLearner:
                 self._policy_clip_used = True
             self.optimizer_policy.step()
         self.last_losses = (float(value_loss.detach()), float(surr.detach()))
-        return time.time() - t0
 
 
 class AgentHandMimic:

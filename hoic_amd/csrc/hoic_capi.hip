@@ -266,6 +266,7 @@ __global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __res
     if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt);                     // :631
     if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
   }
+  asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
   ev.cur_t += 1;                                                                                // :641
   float df[5];
   dev_ho_diff(m, w, ev, df);

@@ -447,8 +447,9 @@ __device__ __forceinline__ void col_capsule_mesh(const DevModel& m, const float*
   }
 }
 __device__ __forceinline__ void col_box_mesh(const DevModel& m, const float* bp, const float* bR, const float* bh,
-                                          const float* mp, const float* mR, int mesh, LaneContacts& o) {
+                                          const float* mp, const float* mR, int mesh, float mesh_rbound, LaneContacts& o) {
   const HullRef h = get_hull(m, mesh);
+  const float rb2 = mesh_rbound * mesh_rbound * 1.0001f + 1e-12f;
   for (int v = 0; v < h.nv; v++) {
     float wv[3], rel[3], p[3];
     matvec(mR, h.v[v], wv);
@@ -469,6 +470,7 @@ __device__ __forceinline__ void col_box_mesh(const DevModel& m, const float* bp,
     matvec(bR, loc, wc);
     for (int i = 0; i < 3; i++) { wc[i] += bp[i]; rel[i] = wc[i] - mp[i]; }
     mattvec(mR, rel, p);
+    if (dot3(p, p) > rb2) continue;        // outside the hull's bounding sphere: cannot be inside the hull
     const float zero[3] = {0.f, 0.f, 0.f}; int f;
     const float s = hull_line_max(h, p, zero, 0.f, f);
     if (s >= 0.f) continue;
@@ -506,10 +508,12 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
       const float bound = m.pair_bound[p];
       const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1];
       const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2];
-      bool test = true;
+      bool test;
       if (t1 != HOIC_GEOM_PLANE) {
         float dv[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
         test = dot3(dv, dv) <= bound * bound;
+      } else {        // bounding sphere of geom2 against the plane (exact reject: no point of geom2 can be within the margin)
+        test = (p2[0] - p1[0]) * R1[2] + (p2[1] - p1[1]) * R1[5] + (p2[2] - p1[2]) * R1[8] <= bound;
       }
       isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
       if (test && !isbb) {
@@ -522,7 +526,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         else if (t2 == HOIC_GEOM_MESH) {
           const int mesh = m.pair_mesh[p];
           if (t1 == HOIC_GEOM_CAPSULE) col_capsule_mesh(m, p1, R1, s1, p2, R2, mesh, lc);
-          else if (t1 == HOIC_GEOM_BOX) col_box_mesh(m, p1, R1, s1, p2, R2, mesh, lc);
+          else if (t1 == HOIC_GEOM_BOX) col_box_mesh(m, p1, R1, s1, p2, R2, mesh, m.geom_rbound[g2], lc);
           else if (t1 == HOIC_GEOM_PLANE) col_plane_mesh(m, p1, R1, p2, R2, mesh, lc);
         }
       }

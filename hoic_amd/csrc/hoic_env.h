@@ -165,23 +165,33 @@ __device__ void dev_classify_contact(const DevModel& m, Work& w) {
 //   min_l |l|^2/4 + b'l + 1/(2 eps) sum_i max(0, -(c_i + a_i'l))^2 ,  residual wrench = -l/2
 // (same formulation as oracle/ho_env.c; columns a_i live in registers, 6 per lane)
 #define QPC 6
-HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major, x in/out
-  double L[6][6];
-  for (int i = 0, k = 0; i < 6; i++) for (int j = 0; j <= i; j++, k++) L[i][j] = H[k];
+HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (overwritten by its Cholesky factor), x in/out
+#define HP(i, j) H[(i) * ((i) + 1) / 2 + (j)]
+#pragma unroll
   for (int j = 0; j < 6; j++) {
-    double s = L[j][j];
-    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    double s = HP(j, j);
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= HP(j, k) * HP(j, k);
     s = s > 1e-300 ? s : 1e-300;
-    const double l = sqrt(s);
-    L[j][j] = l;
+    const double l = sqrt(s), il = 1.0 / l;
+    HP(j, j) = l;
+#pragma unroll
     for (int i = j + 1; i < 6; i++) {
-      double t = L[i][j];
-      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-      L[i][j] = t / l;
+      double t = HP(i, j);
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= HP(i, k) * HP(j, k);
+      HP(i, j) = t * il;
     }
   }
-  for (int i = 0; i < 6; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i][k] * x[k]; x[i] = s / L[i][i]; }
-  for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= HP(i, k) * x[k]; x[i] = s / HP(i, i); }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) { double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= HP(k, i) * x[k]; x[i] = s / HP(i, i); }
+#undef HP
 }
 
 __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
@@ -218,7 +228,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + w_t * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
   const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.sc.post.n_avg * npt * 4;
   const double inv = 1.0 / sqrt(1.0 + mu * mu);
-  double a[QPC][6], cc[QPC];
+  float a[QPC][6], cc[QPC];    // columns kept in float32 (their inputs are float32 quantities); all arithmetic on them in float64
   bool valid[QPC];
   const double obj_p[3] = {w.qpos[nq - 7], w.qpos[nq - 6], w.qpos[nq - 5]};
   const double obj_v[3] = {w.sc.post.gvel[lastg][0], w.sc.post.gvel[lastg][1], w.sc.post.gvel[lastg][2]};
@@ -226,8 +236,8 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   for (int jj = 0; jj < QPC; jj++) {
     const int col = tid + jj * NT;
     valid[jj] = col < ncol;
-    for (int i = 0; i < 6; i++) a[jj][i] = 0.0;
-    cc[jj] = 0.0;
+    for (int i = 0; i < 6; i++) a[jj][i] = 0.f;
+    cc[jj] = 0.f;
     if (!valid[jj]) continue;
     const int pt = col >> 2, e = col & 3, ci = pt / npt, j = pt % npt;
     const float* cp = w.sc.post.avg_cps[ci];
@@ -257,11 +267,12 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     const double sgn = (e & 1) ? -1.0 : 1.0;
     double xv[3];
     for (int k = 0; k < 3; k++) xv[k] = (fn[k] + sgn * mu * tt[k]) * inv * ts;
-    a[jj][0] = xv[0]; a[jj][1] = xv[1]; a[jj][2] = xv[2];
-    a[jj][3] = swt * (cro[1] * xv[2] - cro[2] * xv[1]);
-    a[jj][4] = swt * (cro[2] * xv[0] - cro[0] * xv[2]);
-    a[jj][5] = swt * (cro[0] * xv[1] - cro[1] * xv[0]);
-    cc[jj] = ((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt);
+    a[jj][0] = (float)xv[0]; a[jj][1] = (float)xv[1]; a[jj][2] = (float)xv[2];
+    a[jj][3] = (float)(swt * (cro[1] * xv[2] - cro[2] * xv[1]));
+    a[jj][4] = (float)(swt * (cro[2] * xv[0] - cro[0] * xv[2]));
+    a[jj][5] = (float)(swt * (cro[0] * xv[1] - cro[1] * xv[0]));
+    cc[jj] = (float)(((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt));
+    __builtin_amdgcn_sched_barrier(0);   // one column at a time: interleaving the six constructions multiplies the live temporaries
   }
   const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
   double lam[6];
@@ -272,12 +283,12 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     for (int i = 0; i < 21; i++) H[i] = 0.0;
 #pragma unroll
     for (int jj = 0; jj < QPC; jj++) {
-      double sk = cc[jj];
-      for (int i = 0; i < 6; i++) sk += a[jj][i] * lam[i];
+      double sk = (double)cc[jj];
+      for (int i = 0; i < 6; i++) sk += (double)a[jj][i] * lam[i];
       s[jj] = sk;
       if (valid[jj] && sk < 0.0) {
         const double se = sk / eps;
-        for (int i = 0, k = 0; i < 6; i++) { g[i] += se * a[jj][i]; for (int j = 0; j <= i; j++, k++) H[k] += a[jj][i] * a[jj][j] / eps; }
+        for (int i = 0, k = 0; i < 6; i++) { g[i] += se * (double)a[jj][i]; for (int j = 0; j <= i; j++, k++) H[k] += (double)a[jj][i] * (double)a[jj][j] / eps; }
       }
     }
     for (int i = 0; i < 6; i++) g[i] = wave_sum_d(g[i]) + 0.5 * lam[i] + b[i];
@@ -292,7 +303,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     double gl = 0, dd = 0, bd = 0, av[QPC];
     for (int i = 0; i < 6; i++) { gl += lam[i] * dir[i]; dd += dir[i] * dir[i]; bd += b[i] * dir[i]; }
 #pragma unroll
-    for (int jj = 0; jj < QPC; jj++) { double v = 0; for (int i = 0; i < 6; i++) v += a[jj][i] * dir[i]; av[jj] = v; }
+    for (int jj = 0; jj < QPC; jj++) { double v = 0; for (int i = 0; i < 6; i++) v += (double)a[jj][i] * dir[i]; av[jj] = v; }
     double al = 1.0, lo = 0.0, hi = -1.0;
     for (int ls = 0; ls < 60; ls++) {
       double dphi = 0, ddphi = 0;

@@ -214,6 +214,56 @@ def test_env_step_parity_short_horizon(obj, oracle_lib):
     assert diverged <= max(2, compared // (20 if obj == "box" else 10)), (diverged, compared)
 
 
+def test_episode_reward_parity(box_blob, oracle_lib, setup):
+    """North-star parity statement: the same (seeded, randomly initialised) deterministic policy driven through the
+    float64 oracle and through the HIP simulator gives the same episode length and the same episode reward within
+    float32 tolerance, over whole episodes of several hundred env steps (6000+ substeps with contacts)."""
+    from hoic_amd.rl import PolicyGaussian
+    cfg, ex, thresh = setup
+    N = 4
+    sim = _sim(box_blob, N, cfg, ex, thresh)
+    torch.manual_seed(3)
+    pol = PolicyGaussian(cfg, 32, 617).eval()
+    pol_d = PolicyGaussian(cfg, 32, 617).to("cuda").eval(); pol_d.load_state_dict(pol.state_dict())
+    seqs = np.arange(N) % 4; starts = np.array([0, 40, 120, 200])
+    wk = cfg.reward_wk()
+    # oracle episodes
+    ref = []
+    for i in range(N):
+        o = _oracle(oracle_lib, box_blob, cfg, thresh, ex[seqs[i]]); obs = o.reset(int(starts[i]))
+        tot, n = 0.0, 0
+        with torch.no_grad():
+            for _ in range(600):
+                a = pol.select_action(torch.as_tensor(np.clip(obs, -5, 5)[None], dtype=torch.float32), mean_action=True)[0].numpy()
+                obs, info = o.step(a.astype(np.float64)); r, _ = o.reward(wk)
+                tot += r; n += 1
+                if info["done"]:
+                    break
+        ref.append((tot, n, o.get("qpos")[:33].copy()))
+    # the same on the GPU
+    obs = sim.reset(seqs, starts)
+    alive = torch.ones(N, dtype=torch.bool, device="cuda"); tot = torch.zeros(N, device="cuda", dtype=torch.float64); n = torch.zeros(N, device="cuda")
+    qfinal = [None] * N
+    with torch.no_grad():
+        for _ in range(600):
+            a = pol_d.select_action(torch.clamp(obs, -5, 5), mean_action=True)
+            obs, rew, _, flags, _ = sim.step(a)
+            tot += torch.where(alive, rew.double(), torch.zeros_like(tot)); n += alive.float()
+            done = flags[:, 2] != 0
+            if bool((alive & done).any()):
+                q = sim.get_state()[0].cpu().numpy()
+                for i in torch.nonzero(alive & done).flatten().tolist():
+                    qfinal[i] = q[i]
+            alive &= ~done
+            if not bool(alive.any()):
+                break
+    for i in range(N):
+        assert int(n[i]) == ref[i][1], (i, int(n[i]), ref[i][1])
+        assert ref[i][1] > 100
+        assert abs(float(tot[i]) - ref[i][0]) < 2e-3 * ref[i][0], (i, float(tot[i]), ref[i][0])
+        assert np.abs(qfinal[i][:33] - ref[i][2]).max() < 5e-3, (i, np.abs(qfinal[i][:33] - ref[i][2]).max())
+
+
 def test_glue_against_reference_goldens(box_blob, setup):
     """obs / reward / termination diffs of the HIP path against vectors produced by the REFERENCE's Python
     (tests/golden/env_glue.npz): load the golden state through set_state, make the expert the golden expert, and
