@@ -164,7 +164,6 @@ __device__ void dev_classify_contact(const DevModel& m, Work& w) {
 // ---- solve_rfc (ho_im4.py:941-1083) in float64: Newton on the 6-D dual of the non-negative QP
 //   min_l |l|^2/4 + b'l + 1/(2 eps) sum_i max(0, -(c_i + a_i'l))^2 ,  residual wrench = -l/2
 // (same formulation as oracle/ho_env.c; columns a_i live in registers, 6 per lane)
-#define QPC 6
 HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (overwritten by its Cholesky factor), x in/out
 #define HP(i, j) H[(i) * ((i) + 1) / 2 + (j)]
 #pragma unroll
@@ -227,18 +226,17 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   if (w.sc.post.n_avg == 0)
     return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + w_t * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
   const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.sc.post.n_avg * npt * 4;
+  const int nslot = (ncol + NT - 1) / NT;         // columns per lane actually present (typically 1-2 of at most 6)
   const double inv = 1.0 / sqrt(1.0 + mu * mu);
-  float a[QPC][6], cc[QPC];    // columns kept in float32 (their inputs are float32 quantities); all arithmetic on them in float64
-  bool valid[QPC];
+  // columns a_i (6) and offsets c_i live in LDS as float32 (their inputs are float32 quantities; all arithmetic on
+  // them is float64): the QP then needs ~130 registers instead of ~460, and its loops run over the columns that
+  // exist instead of six unrolled slots per lane
+  float* qc = w.col_lc;
   const double obj_p[3] = {w.qpos[nq - 7], w.qpos[nq - 6], w.qpos[nq - 5]};
   const double obj_v[3] = {w.sc.post.gvel[lastg][0], w.sc.post.gvel[lastg][1], w.sc.post.gvel[lastg][2]};
-#pragma unroll
-  for (int jj = 0; jj < QPC; jj++) {
+  for (int jj = 0; jj < nslot; jj++) {
     const int col = tid + jj * NT;
-    valid[jj] = col < ncol;
-    for (int i = 0; i < 6; i++) a[jj][i] = 0.f;
-    cc[jj] = 0.f;
-    if (!valid[jj]) continue;
+    if (col >= ncol) continue;
     const int pt = col >> 2, e = col & 3, ci = pt / npt, j = pt % npt;
     const float* cp = w.sc.post.avg_cps[ci];
     double pos[3], fn[3], t1[3], t2[3];
@@ -260,35 +258,49 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     const double nvn = fabs(vn) * sqrt(nn), nvt = sqrt(relt[0] * relt[0] + relt[1] * relt[1] + relt[2] * relt[2]);
     const double ts = (double)w.sc.post.avg_ts[pt / 5] / (double)cfg.c.sim_step;   // cp_ts[i // 5] quirk (:1012)
     const double d1 = relt[0] * t1[0] + relt[1] * t1[1] + relt[2] * t1[2], d2 = relt[0] * t2[0] + relt[1] * t2[1] + relt[2] * t2[2];
-    const double dirs[4] = {-d1, d1, -d2, d2};
-    int am = 0;
-    for (int k = 1; k < 4; k++) if (dirs[k] > dirs[am]) am = k;
+    int am = 0;                       // argmax of {-d1, d1, -d2, d2}, first maximum (static indexing: no private array)
+    double bestd = -d1;
+    if (d1 > bestd) { bestd = d1; am = 1; }
+    if (-d2 > bestd) { bestd = -d2; am = 2; }
+    if (d2 > bestd) { bestd = d2; am = 3; }
     const double* tt = e < 2 ? t1 : t2;
     const double sgn = (e & 1) ? -1.0 : 1.0;
     double xv[3];
     for (int k = 0; k < 3; k++) xv[k] = (fn[k] + sgn * mu * tt[k]) * inv * ts;
-    a[jj][0] = (float)xv[0]; a[jj][1] = (float)xv[1]; a[jj][2] = (float)xv[2];
-    a[jj][3] = (float)(swt * (cro[1] * xv[2] - cro[2] * xv[1]));
-    a[jj][4] = (float)(swt * (cro[2] * xv[0] - cro[0] * xv[2]));
-    a[jj][5] = (float)(swt * (cro[0] * xv[1] - cro[1] * xv[0]));
-    cc[jj] = (float)(((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt));
-    __builtin_amdgcn_sched_barrier(0);   // one column at a time: interleaving the six constructions multiplies the live temporaries
+    qc[0 * QP_MAXCOL + col] = (float)xv[0]; qc[1 * QP_MAXCOL + col] = (float)xv[1]; qc[2 * QP_MAXCOL + col] = (float)xv[2];
+    qc[3 * QP_MAXCOL + col] = (float)(swt * (cro[1] * xv[2] - cro[2] * xv[1]));
+    qc[4 * QP_MAXCOL + col] = (float)(swt * (cro[2] * xv[0] - cro[0] * xv[2]));
+    qc[5 * QP_MAXCOL + col] = (float)(swt * (cro[0] * xv[1] - cro[1] * xv[0]));
+    qc[6 * QP_MAXCOL + col] = (float)(((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt));
   }
+  __syncthreads();
   const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
+  const double ieps = 1.0 / eps;
   double lam[6];
   for (int i = 0; i < 6; i++) lam[i] = -2.0 * b[i];
   for (int it = 0; it < 60; it++) {
-    double g[6], H[21], s[QPC];
+    double g[6], H[21];
     for (int i = 0; i < 6; i++) g[i] = 0.0;
     for (int i = 0; i < 21; i++) H[i] = 0.0;
+    for (int jj = 0; jj < nslot; jj++) {
+      const int col = tid + jj * NT;
+      if (col < ncol) {
+        double a[6];
 #pragma unroll
-    for (int jj = 0; jj < QPC; jj++) {
-      double sk = (double)cc[jj];
-      for (int i = 0; i < 6; i++) sk += (double)a[jj][i] * lam[i];
-      s[jj] = sk;
-      if (valid[jj] && sk < 0.0) {
-        const double se = sk / eps;
-        for (int i = 0, k = 0; i < 6; i++) { g[i] += se * (double)a[jj][i]; for (int j = 0; j <= i; j++, k++) H[k] += (double)a[jj][i] * (double)a[jj][j] / eps; }
+        for (int i = 0; i < 6; i++) a[i] = (double)qc[i * QP_MAXCOL + col];
+        double sk = (double)qc[6 * QP_MAXCOL + col];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sk += a[i] * lam[i];
+        if (sk < 0.0) {
+          const double se = sk * ieps;
+#pragma unroll
+          for (int i = 0, k = 0; i < 6; i++) {
+            g[i] += se * a[i];
+            const double ai = a[i] * ieps;
+#pragma unroll
+            for (int j = 0; j <= i; j++, k++) H[k] += ai * a[j];
+          }
+        }
       }
     }
     for (int i = 0; i < 6; i++) g[i] = wave_sum_d(g[i]) + 0.5 * lam[i] + b[i];
@@ -296,21 +308,24 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     for (int i = 0, k = 0; i < 6; i++) { k += i; H[k] += 0.5; k++; }
     double gn = 0, ln = 0;
     for (int i = 0; i < 6; i++) { gn += g[i] * g[i]; ln += lam[i] * lam[i]; }
-    if (sqrt(gn) < 1e-12 * (1.0 + sqrt(ln))) break;
+    if (sqrt(gn) < 1e-9 * (1.0 + sqrt(ln))) break;      // H >= I/2: |lambda error| <= 2 |g|, far below the float32 result
     double dir[6];
     for (int i = 0; i < 6; i++) dir[i] = -g[i];
     chol6_solve(H, dir);
-    double gl = 0, dd = 0, bd = 0, av[QPC];
+    double gl = 0, dd = 0, bd = 0;
     for (int i = 0; i < 6; i++) { gl += lam[i] * dir[i]; dd += dir[i] * dir[i]; bd += b[i] * dir[i]; }
-#pragma unroll
-    for (int jj = 0; jj < QPC; jj++) { double v = 0; for (int i = 0; i < 6; i++) v += (double)a[jj][i] * dir[i]; av[jj] = v; }
     double al = 1.0, lo = 0.0, hi = -1.0;
     for (int ls = 0; ls < 60; ls++) {
       double dphi = 0, ddphi = 0;
+      for (int jj = 0; jj < nslot; jj++) {
+        const int col = tid + jj * NT;
+        if (col < ncol) {
+          double s0 = (double)qc[6 * QP_MAXCOL + col], av = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < QPC; jj++) {
-        const double sk = s[jj] + al * av[jj];
-        if (valid[jj] && sk < 0.0) { dphi += sk * av[jj] / eps; ddphi += av[jj] * av[jj] / eps; }
+          for (int i = 0; i < 6; i++) { const double ai = (double)qc[i * QP_MAXCOL + col]; s0 += ai * lam[i]; av += ai * dir[i]; }
+          const double sk = s0 + al * av;
+          if (sk < 0.0) { dphi += sk * av * ieps; ddphi += av * av * ieps; }
+        }
       }
       dphi = wave_sum_d(dphi) + 0.5 * (gl + al * dd) + bd; ddphi = wave_sum_d(ddphi) + 0.5 * dd;
       if (fabs(dphi) < 1e-13 * (1.0 + fabs(bd) + fabs(gl))) break;
@@ -319,7 +334,11 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
       if (hi >= 0 && (an <= lo || an >= hi)) an = 0.5 * (lo + hi);
       if (hi < 0 && an <= lo) an = 2 * al + 1e-12;
       if (hi >= 0 && hi - lo < 1e-15 * (1 + hi)) break;
+      // the 1-D function is piecewise quadratic: once the active set stops changing the Newton step is exact and
+      // repeats itself (the derivative test above sits below its own rounding noise, which is scaled by 1/eps)
+      const bool same = fabs(an - al) <= 1e-14 * (1.0 + fabs(al));
       al = an;
+      if (same) break;
     }
     double st = 0;
     for (int i = 0; i < 6; i++) { lam[i] += al * dir[i]; st += al * al * dir[i] * dir[i]; }

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 #include "../../include/hoic.h"
 
 #define NT 64            // lanes per env (one wavefront)
@@ -136,17 +137,12 @@ struct DofK { float floss, flR; };   // friction-loss row constants of dof (lane
 // per-env LDS workspace
 struct Work {
   float qpos[NQP], qvel[NV], qacc[NV], warm[NV], qlag[NQP], vlag[NV], action[NV];
-  float ctrl[NV], applied[NV], bias[NV], fsmooth[NV], asmooth[NV], fcon[NV];
 #ifdef HOIC_EXP_EULER
   float tv0[NV], tq0[NQP];
 #endif
-  // model constants used every pass (loaded once per launch)
-  float k_arm[NV], k_damp[NV], k_floss[NV], k_flR[NV], k_flB[NV]; int k_act[NV];
-  unsigned k_bpath[NB][3];
   // kinematics of the last forward pass
   float xpos[NB][3], xquat[NB][4];
-  float S[NV][6];                      // motion axes [angular; linear at the world origin]
-  float gxpos[NG][3], gxmat[NG][9];
+  float gxpos[NG][3];
   // scratch shared by phases that never overlap
   union {
     struct {
@@ -162,10 +158,8 @@ struct Work {
       float gvel[NG][3], gangvel[NG][3], obj_avg_acc[6];
     } post;
   } sc;
-  // contacts of the current forward pass
-  int ncon, nrow, solver_iter, fail;
-  float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
-  unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
+  // ---- from here to gxmat: not used by the post-step kernel before its reset path; its residual-force QP keeps
+  // its columns there (qp_cols(), QP_COL_FLOATS floats from col_lc on; layout asserted below)
   union {
     // ---- solver phase: derived per-contact data, contact rows, search direction.
     // Jacobian-free contacts: row (c,k) of the contact Jacobian is
@@ -186,6 +180,16 @@ struct Work {
     // (q, k) of lane l at col_lc[(q * 7 + k) * NT + l]; clipping scratch of the wave-cooperative box-box
     struct { float col_lc[4 * 7 * NT]; float col_poly[32]; };
   };
+  // contacts of the current forward pass
+  int ncon, nrow, solver_iter, fail;
+  float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
+  unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
+  // model constants used every pass (loaded once per launch)
+  float k_arm[NV], k_damp[NV], k_floss[NV], k_flR[NV], k_flB[NV]; int k_act[NV];
+  unsigned k_bpath[NB][3];
+  float ctrl[NV], applied[NV], bias[NV], fsmooth[NV], asmooth[NV], fcon[NV];
+  float S[NV][6];                      // motion axes [angular; linear at the world origin]
+  float gxmat[NG][9];
   // contact bookkeeping over the env step (record_contact)
   float rec_sum[NHG][12]; int rec_cnt[NHG];
 #ifdef HOIC_PHASE_TIMING
@@ -195,6 +199,11 @@ struct Work {
 #ifndef HOIC_PHASE_TIMING
 static_assert(sizeof(Work) <= 20480, "Work must stay under 20 KB: 8 environments per CU");
 #endif
+// residual-force QP columns (post-step kernel): up to 19 contacts x 5 points x 4 edges, 7 floats each, column c of
+// component k at qp_cols[k * QP_MAXCOL + c]
+#define QP_MAXCOL (NHG * 5 * 4)
+#define QP_COL_FLOATS (7 * QP_MAXCOL)
+static_assert(offsetof(Work, gxmat) + sizeof(((Work*)0)->gxmat) - offsetof(Work, col_lc) >= QP_COL_FLOATS * 4, "QP column overlay");
 
 #ifdef HOIC_PHASE_TIMING
 #define PT(i) do { long long t_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) { w.pt[i] += t_ - w.pt_last; w.pt_last = t_; } } while (0)
