@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __res
   float rfc_score = 0.f;
   if (ok) {
     dev_classify_contact(m, w);                                                                // :562
-    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt);                     // :631
+    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, st.qp_lam + (size_t)env * 8);   // :631
     if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
   }
   asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __res
     __syncthreads();
     dev_reset_state(m, w, ex, ns, nst);
     dev_kinematics(m, w, w.qpos);
+    if (tid == 6) st.qp_lam[(size_t)env * 8 + 6] = 0.0;
     ev.off = ex.seq_off[ns]; ev.len = ex.seq_len[ns]; ev.start = nst; ev.cur_t = 0;
     if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
     store_state(st, w, env);
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restri
   ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], start, 0};
   if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
   store_state(st, w, env);
-  if (tid == 0) { st.cur_t[env] = 0; st.start[env] = start; st.seq[env] = seq; st.rfc_score[env] = 0.f; }
+  if (tid == 0) { st.cur_t[env] = 0; st.start[env] = start; st.seq[env] = seq; st.rfc_score[env] = 0.f; st.qp_lam[(size_t)env * 8 + 6] = 0.0; }
 }
 
 __global__ __launch_bounds__(NT) void hoic_set_state_kernel(const DevModel* __restrict__ mp, DevState st,
@@ -653,7 +654,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
        hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess &&
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
-       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess;
+       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
   ok = hipMalloc(&s->d_ex, sizeof(DevExpert)) == hipSuccess && hipMalloc(&s->d_st, sizeof(DevState)) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
@@ -664,7 +665,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.vlag, 0, n * NV * 4); hipMemset(s->st.warm, 0, n * NV * 4); hipMemset(s->st.cur_t, 0, n * 4);
   hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
   hipMemset(s->st.overflow, 0, n * 4); hipMemset(s->st.phase, 0, n * 24 * 8);
-  hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4);
+  hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
   hipDeviceSynchronize();
   return s;
 }
@@ -674,7 +675,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   delete s;

@@ -193,7 +193,7 @@ HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (ov
 #undef HP
 }
 
-__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
+__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt, double* warm_lam) {
   const int tid = threadIdx.x;
   const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025, eps = 1e-7;
   if (!cfg.c.explain_force)
@@ -223,6 +223,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   tau[0] = Ioa[0] + ow[1] * Iw[2] - ow[2] * Iw[1];
   tau[1] = Ioa[1] + ow[2] * Iw[0] - ow[0] * Iw[2];
   tau[2] = Ioa[2] + ow[0] * Iw[1] - ow[1] * Iw[0];
+  if (w.sc.post.n_avg == 0) { if (tid == 6) warm_lam[6] = 0.0; }
   if (w.sc.post.n_avg == 0)
     return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + w_t * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
   const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.sc.post.n_avg * npt * 4;
@@ -276,8 +277,11 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   __syncthreads();
   const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
   const double ieps = 1.0 / eps;
+  // start from the previous env step's multipliers when it had contacts too (the optimum is unique, so the start only
+  // changes the iteration count: contact sets move slowly from step to step)
   double lam[6];
-  for (int i = 0; i < 6; i++) lam[i] = -2.0 * b[i];
+  const bool have_warm = warm_lam[6] != 0.0;
+  for (int i = 0; i < 6; i++) lam[i] = have_warm ? warm_lam[i] : -2.0 * b[i];
   for (int it = 0; it < 60; it++) {
     double g[6], H[21];
     for (int i = 0; i < 6; i++) g[i] = 0.0;
@@ -344,6 +348,8 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     for (int i = 0; i < 6; i++) { lam[i] += al * dir[i]; st += al * al * dir[i] * dir[i]; }
     if (sqrt(st) < 1e-15 * (1.0 + sqrt(ln))) break;
   }
+  if (tid < 6) warm_lam[tid] = lam[tid];
+  if (tid == 6) warm_lam[6] = 1.0;
   const double rf = 0.5 * sqrt(lam[0] * lam[0] + lam[1] * lam[1] + lam[2] * lam[2]);
   const double rt = 0.5 * sqrt(lam[3] * lam[3] + lam[4] * lam[4] + lam[5] * lam[5]);
   return (float)(rf + rt);   // |rest_force| + sqrt(w_t) |rest_torque| (:1083)

@@ -121,6 +121,7 @@ struct DevState {
   int* overflow; // [n] contact-cap overflow counter
   float* post;   // [n, PB_SIZE]
   float* oldg;   // [n, OG_SIZE]
+  double* qp_lam; // [n, 8] warm start of the residual-force QP: lambda[6], valid flag, pad
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
 };
 
