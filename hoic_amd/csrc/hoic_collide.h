@@ -516,6 +516,22 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         test = (p2[0] - p1[0]) * R1[2] + (p2[1] - p1[1]) * R1[5] + (p2[2] - p1[2]) * R1[8] <= bound;
       }
       isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
+      if (isbb) {
+        // per-lane pre-test on the six face axes: a pair separated by more than the margin along a face normal has no
+        // contact and does not take a turn in the (sequential) wave-cooperative routine below
+        const float mg = m.pair_margin[p] + 1e-6f;
+        float tw[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, Rab[3][3];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) Rab[i][j] = fabsf(R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j]) + 1e-6f;
+        const float* ha = m.pair_size1[p]; const float* hb = m.pair_size2[p];
+        for (int i = 0; i < 3; i++) {
+          const float ta = tw[0] * R1[i] + tw[1] * R1[3 + i] + tw[2] * R1[6 + i];
+          const float tb = tw[0] * R2[i] + tw[1] * R2[3 + i] + tw[2] * R2[6 + i];
+          const float pa_ = ha[i] + hb[0] * Rab[i][0] + hb[1] * Rab[i][1] + hb[2] * Rab[i][2] - fabsf(ta);
+          const float pb_ = hb[i] + ha[0] * Rab[0][i] + ha[1] * Rab[1][i] + ha[2] * Rab[2][i] - fabsf(tb);
+          if (pa_ < -mg || pb_ < -mg) isbb = false;
+        }
+      }
       if (test && !isbb) {
         const float s1[3] = {m.pair_size1[p][0], m.pair_size1[p][1], m.pair_size1[p][2]};
         const float s2[3] = {m.pair_size2[p][0], m.pair_size2[p][1], m.pair_size2[p][2]};
