@@ -300,6 +300,40 @@ class AgentHandMimic:
         m.update({n: float(info_m[i]) for i, n in enumerate(names)})
         return m
 
+    @torch.no_grad()
+    def eval_physics(self, epoch=0, seq_index=None, max_steps=10000):
+        """Physics metrics of a deterministic rollout against the expert sequence it tracks — the summary block of
+        scripts/eval_handmimic.py:274-303 (mimic / reference pairs): jitter, penetration depth, hand-object contact
+        count and the physically plausible frame ratio, computed by hoic_amd.metrics.PhysMetrics."""
+        from .metrics import PhysMetrics
+        env = self.env
+        si = self.seq_num - 1 if seq_index is None else int(seq_index)
+        env.set_mode("test")
+        N = self.n_envs
+        obs = env.reset(torch.full((N,), si, dtype=torch.int32), torch.zeros(N, dtype=torch.int32))
+        ex = self.expert_seqs[si]
+        T = ex["hand_dof_seq"].shape[0]
+        pred = []
+        for t in range(min(max_steps, T)):
+            q, _, _ = env.sim.get_state()
+            pred.append(q[0].double().cpu().numpy())
+            action = self.policy_net.select_action(self.running_state(obs, update=False), mean_action=True)
+            obs, _, done, _ = env.step(action)
+            if bool(done[0]):
+                break
+        env.set_mode("train")
+        self._obs = None
+        pred = np.array(pred)
+        ref = np.concatenate([ex["hand_dof_seq"], ex["obj_pose_seq"]], 1)[:len(pred)]
+        out = {}
+        for name, qs in (("mimic", pred), ("ref", ref)):
+            pm = PhysMetrics(env.sim.model, qs, sim=env.sim)
+            hand_acc, obj_acc, obj_ang_acc = pm.eval_jitter()
+            out[name] = {"hand_acc": hand_acc, "obj_acc": obj_acc, "obj_ang_acc": obj_ang_acc,
+                         "pene_mm": float(np.mean(pm.eval_penetration())), "cp_num": float(np.mean(pm.eval_contact_point())),
+                         "plausible_frame_ratio": float(100 - np.mean(pm.eval_stable()) * 100), "frames": int(len(qs))}
+        return out
+
     # ------------------------------------------------------------------ checkpoints (:175-186, :234-245)
     def save_checkpoint(self, epoch):
         os.makedirs(self.cfg.model_dir, exist_ok=True)

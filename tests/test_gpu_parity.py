@@ -378,3 +378,7 @@ def test_agent_iteration_runs_and_learns_something(box_blob, setup):
     assert any(not torch.equal(a, b) for a, b in zip(p0, agent.policy_net.parameters()))
     m = agent.eval_policy()
     assert 0 <= m["percent"] <= 1 and np.isfinite(m["avg_reward"])
+    ph = agent.eval_physics()
+    for side in ("mimic", "ref"):
+        assert all(np.isfinite(v) for v in ph[side].values()) and 0 <= ph[side]["plausible_frame_ratio"] <= 100
+    assert ph["ref"]["frames"] == ph["mimic"]["frames"] > 10

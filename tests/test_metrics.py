@@ -1,0 +1,78 @@
+"""Offline physics metrics (hoic_amd/metrics.py) against golden vectors produced by importing the reference's
+scripts/metrics.py (tests/golden/gen_golden_metrics.py), and on the GPU against the same metrics computed from the
+oracle's contacts."""
+import os
+
+import numpy as np
+import pytest
+
+from hoic_amd import metrics, mjcf
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "metrics.npz")
+
+
+def _pm_from_golden(box_model):
+    z = np.load(GOLD)
+    pm = metrics.PhysMetrics(box_model, z["qpos"], frames=(z["contacts"], z["body_xpos"]))
+    pm.hand_geom_range = z["hand_geom_range"].tolist(); pm.obj_geom_range = z["obj_geom_range"].tolist()
+    pm.box_size = z["box_size"]; pm.obj_mass = float(z["obj_mass"]); pm.obj_inertia = z["obj_inertia"]
+    pm.hand_body_idx = list(range(3, 24))
+    return z, pm
+
+
+def test_counts_and_penetration(box_model):
+    z, pm = _pm_from_golden(box_model)
+    assert np.array_equal(np.array(pm.eval_contact_point()), z["cp_num"].astype(int))
+    np.testing.assert_allclose(pm.eval_penetration2(), z["pene2"], rtol=1e-9, atol=1e-9)
+
+
+def test_jitter_and_target_wrench(box_model):
+    """The reference computes the rotational parts through float32 torch tensors: tolerance 1e-4 relative there."""
+    z, pm = _pm_from_golden(box_model)
+    j = pm.eval_jitter()
+    np.testing.assert_allclose(j[0], z["jitter"][0], rtol=1e-9)
+    np.testing.assert_allclose(j[1], z["jitter"][1], rtol=1e-9)
+    np.testing.assert_allclose(j[2], z["jitter"][2], rtol=2e-4)
+    F, tau = pm.obtain_target_ft()
+    np.testing.assert_allclose(F, z["target_force"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tau, z["target_torque"], rtol=1e-3, atol=1e-7 * np.abs(z["target_torque"]).max() * 100)
+
+
+def test_stability_qp(box_model):
+    z, pm = _pm_from_golden(box_model)
+    m = pm._ho_mask()
+    # feed the reference's own float32-derived targets so that only the QP is compared
+    rest = np.array([pm.solve_force(z["target_force"][t], z["target_torque"][t], pm.contacts[t][m[t]][:, 3:15], z["qpos"][t, 26:29])
+                     for t in range(z["qpos"].shape[0])])
+    np.testing.assert_allclose(rest, z["rest_ft"], rtol=1e-6, atol=1e-9)
+    st = pm.eval_stable()
+    ambiguous = np.abs(z["rest_ft"] / float(z["obj_mass"]) - 0.01) < 1e-4        # at the threshold float32 noise decides
+    assert np.array_equal(st[~ambiguous], z["stable"][~ambiguous])
+
+
+@pytest.mark.gpu
+def test_metrics_on_device_match_oracle_contacts(box_blob, box_model, oracle_lib):
+    """A recorded 60-frame qpos sequence: metrics from the probe kernel's contacts (one launch for all frames) equal
+    the metrics from the oracle's contacts frame by frame."""
+    import torch
+    from hoic_amd import lib, motions
+    from hoic_amd.config import Config
+    ex = motions.synthetic_expert(box_model, 2, 300)
+    s = ex[0]
+    T = 60
+    q = np.concatenate([s["hand_dof_seq"][120:120 + T], s["obj_pose_seq"][120:120 + T]], 1)
+    sim = lib.BatchedSim(box_blob, 4)
+    pm = metrics.PhysMetrics(box_model, q, sim=sim)
+    e = oracle_lib.OracleEnv(box_blob)
+    K = pm.contacts.shape[1]
+    c = np.zeros((T, K, 15)); xp = np.zeros((T, box_model.scalar("nbody"), 3))
+    for t in range(T):
+        e.set("qpos", q[t]); e.set("qvel", np.zeros(32)); e.forward()
+        oc = e.contacts()
+        c[t, :len(oc), 0] = 1; c[t, :len(oc), 1:3] = oc[:, 13:15]; c[t, :len(oc), 3:15] = oc[:, 1:13]
+        xp[t] = e.get("xpos")[:xp.shape[1]]
+    pr = metrics.PhysMetrics(box_model, q, frames=(c, xp))
+    assert pm.eval_contact_point() == pr.eval_contact_point() and sum(pm.eval_contact_point()) > 20
+    np.testing.assert_allclose(pm.eval_penetration(), pr.eval_penetration(), atol=2e-3)      # millimetres
+    np.testing.assert_allclose(pm.eval_jitter(), pr.eval_jitter(), rtol=1e-3)
+    assert np.mean(pm.eval_stable() == pr.eval_stable()) > 0.95
