@@ -214,6 +214,44 @@ def test_env_step_parity_short_horizon(obj, oracle_lib):
     assert diverged <= max(2, compared // (20 if obj == "box" else 10)), (diverged, compared)
 
 
+def test_ragged_sequences_and_window_clamping(box_blob, oracle_lib, setup):
+    """Sequences of different lengths in one expert table, episodes that start a few frames before the end (the
+    5-frame target window is clamped to the last frame, ho_im4.py:739-741), a single-env simulator and an env count
+    that is not a multiple of anything: observations, end flags and percent agree with the oracle."""
+    cfg, ex, thresh = setup
+    lens = [60, 213, 400, 9]
+    rag = [{k: (v[:L].copy() if isinstance(v, np.ndarray) else v) for k, v in ex[i % 4].items()} for i, L in enumerate(lens)]
+    N = 7
+    sim = _sim(box_blob, N, cfg, rag, thresh)
+    seqs = np.array([0, 0, 1, 1, 2, 3, 3]); starts = np.array([0, 50, 200, 100, 390, 0, 1])
+    obs = sim.reset(seqs, starts).cpu().numpy()
+    tape = motions.action_tape(6, N, seed=11)
+    oenvs = []
+    for i in range(N):
+        o = _oracle(oracle_lib, box_blob, cfg, thresh, rag[seqs[i]])
+        ob = o.reset(int(starts[i])); oenvs.append(o)
+        assert np.abs(ob - obs[i]).max() < 2e-5, i
+    alive = np.ones(N, bool)
+    n_end = 0
+    for t in range(6):
+        out = sim.step(torch.tensor(tape[t], dtype=torch.float32))
+        g_obs, g_flags, g_pct = out[0].cpu().numpy(), out[3].cpu().numpy(), out[4].cpu().numpy()
+        for i in range(N):
+            if not alive[i]:
+                continue
+            ob, info = oenvs[i].step(tape[t, i])
+            assert bool(g_flags[i, 1]) == info["end"] and bool(g_flags[i, 2]) == info["done"], (t, i, g_flags[i], info)
+            assert abs(g_pct[i] - info["percent"]) < 1e-6
+            assert np.abs(ob - g_obs[i]).max() < 5e-3, (t, i, np.abs(ob - g_obs[i]).max())
+            n_end += info["end"]
+            if info["done"]:
+                alive[i] = False
+    assert n_end >= 3            # the episodes that started next to the end of their sequence ended there
+    one = _sim(box_blob, 1, cfg, rag, thresh)                     # a one-env simulator behaves like env 0 of the batch
+    o1 = one.reset(np.array([0]), np.array([0])).cpu().numpy()
+    assert np.array_equal(o1[0], obs[0])
+
+
 def test_episode_reward_parity(box_blob, oracle_lib, setup):
     """North-star parity statement: the same (seeded, randomly initialised) deterministic policy driven through the
     float64 oracle and through the HIP simulator gives the same episode length and the same episode reward within
