@@ -241,8 +241,9 @@ class BatchedSim:
             raise HoicError("hoic_step_times failed")
         return list(a[:n]), list(b[:n])
 
-    def probe_forward(self, qpos, qvel, ctrl=None, applied=None, warm=None, do_step=False):
-        """mj_forward (+ Euler) at arbitrary states; returns a dict of numpy arrays."""
+    def probe_forward(self, qpos, qvel, ctrl=None, applied=None, warm=None, do_step=False, kinematics_only=False):
+        """mj_forward (+ Euler) at arbitrary states; returns a dict of numpy arrays.  ``kinematics_only``: return just
+        the body / geom poses and contacts (the other outputs are not copied back)."""
         t = self.torch
         f = dict(device=self.device, dtype=t.float32)
         qpos = t.as_tensor(np.asarray(qpos), **f).contiguous(); qvel = t.as_tensor(np.asarray(qvel), **f).contiguous()
@@ -261,4 +262,6 @@ class BatchedSim:
                                        _ptr(o["qacc"]), _ptr(o["qpos_out"]), _ptr(o["qvel_out"]), _ptr(o["iters"]),
                                        self._stream()), "hoic_probe_forward")
         t.cuda.synchronize(self.device)
+        if kinematics_only:
+            o = {k: o[k] for k in ("xpos", "xquat", "geom_xpos", "geom_xmat", "ncon", "contacts")}
         return {k: v.cpu().numpy() for k, v in o.items()}

@@ -117,8 +117,12 @@ def compute_vel_from_seq(hand_dof_seq, obj_pose_seq, motion_freq=30):
     return hv, ov, oav
 
 
-def preprocess_seq(model: mjcf.CompiledModel, seq: dict, motion_freq: int = 30) -> dict:
-    """One raw sequence -> the expert dict HandObjMimic4 consumes (see module docstring)."""
+def preprocess_seq(model: mjcf.CompiledModel, seq: dict, motion_freq: int = 30, sim=None) -> dict:
+    """One raw sequence -> the expert dict HandObjMimic4 consumes (see module docstring).
+
+    ``sim`` (a ``hoic_amd.lib.BatchedSim``): run the forward kinematics of every frame
+    (compute_body_pos_quat_from_seq, dataset_singledepth.py:222-237, one ``sim.forward()`` per frame in the
+    reference) as ONE launch of the probe kernel on the GPU (float32); without it, float64 NumPy FK on the host."""
     A = model.arrays
     nh = model.scalar("hand_nq")
     lo, hi = A["jnt_range"][:nh, 0], A["jnt_range"][:nh, 1]
@@ -129,7 +133,11 @@ def preprocess_seq(model: mjcf.CompiledModel, seq: dict, motion_freq: int = 30) 
     qpos = np.zeros((T, model.scalar("nq")))
     qpos[:, :nh] = hand
     qpos[:, nh:] = A["qpos0"][nh:]      # the reference's FK sim leaves the object at qpos0 (:228-230)
-    xpos, xquat = fk_batch(model, qpos)
+    if sim is not None:
+        out = sim.probe_forward(qpos, np.zeros((T, model.scalar("nv"))), kinematics_only=True)
+        xpos, xquat = out["xpos"].astype(np.float64), out["xquat"].astype(np.float64)
+    else:
+        xpos, xquat = fk_batch(model, qpos)
     hb0, nhb = model.scalar("hand_body0"), model.scalar("hand_nbody")
     return {"hand_dof_seq": hand, "hand_dof_vel_seq": hv, "obj_pose_seq": obj, "obj_vel_seq": ov,
             "obj_angle_vel_seq": oav, "body_pos_seq": xpos[:, hb0:hb0 + nhb].copy(),

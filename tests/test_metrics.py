@@ -76,3 +76,18 @@ def test_metrics_on_device_match_oracle_contacts(box_blob, box_model, oracle_lib
     np.testing.assert_allclose(pm.eval_penetration(), pr.eval_penetration(), atol=2e-3)      # millimetres
     np.testing.assert_allclose(pm.eval_jitter(), pr.eval_jitter(), rtol=1e-3)
     assert np.mean(pm.eval_stable() == pr.eval_stable()) > 0.95
+
+
+@pytest.mark.gpu
+def test_preprocess_seq_on_device(box_blob, box_model):
+    """Expert preprocessing: the FK of every frame through one probe-kernel launch
+    equals the float64 host FK."""
+    from hoic_amd import lib, motions
+    raw = motions.synthetic_sequences(box_model, 1, 300)[0]
+    sim = lib.BatchedSim(box_blob, 2)
+    a = motions.preprocess_seq(box_model, raw)
+    b = motions.preprocess_seq(box_model, raw, sim=sim)
+    for k in ("hand_dof_seq", "hand_dof_vel_seq", "obj_pose_seq", "obj_vel_seq", "obj_angle_vel_seq"):
+        assert np.array_equal(a[k], b[k])
+    np.testing.assert_allclose(b["body_pos_seq"], a["body_pos_seq"], atol=2e-6)
+    np.testing.assert_allclose(np.abs((b["body_quat_seq"] * a["body_quat_seq"]).sum(-1)), 1.0, atol=1e-6)
