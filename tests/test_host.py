@@ -171,3 +171,33 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(root, f)).read()
                 assert not pat.search(src), f
+
+
+def test_reference_checkpoint_loads():
+    """A checkpoint pickled by the reference's own PolicyGaussian / Value / ZFilter classes
+    (tests/golden/gen_golden_checkpoint.py; keys of agent_handmimic.py:175-186) loads through RefUnpickler into this
+    package's nets and filter, which then reproduce the reference's outputs."""
+    import pickle
+    import torch
+    from hoic_amd.agent import RefUnpickler
+    from hoic_amd.config import Config, release_cfg_dict
+    from hoic_amd.rl import MLP, BatchZFilter, PolicyGaussian, Value
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(g, "ref_checkpoint_small.npz"))
+    with open(os.path.join(g, "ref_checkpoint_small.p"), "rb") as f:
+        cp = RefUnpickler(f).load()
+    assert set(cp) == {"policy_dict", "value_dict", "running_state"}
+    d = release_cfg_dict("box"); d["policy_hsize"] = z["policy_hsize"].tolist(); d["value_hsize"] = z["value_hsize"].tolist()
+    cfg = Config("box_future5_light_add_geom", cfg_dict=d)
+    pol = PolicyGaussian(cfg, 32, 617).double(); val = Value(MLP(617, cfg.value_hsize, cfg.value_htype)).double()
+    pol.load_state_dict(cp["policy_dict"]); val.load_state_dict(cp["value_dict"])
+    filt = BatchZFilter.from_reference(cp["running_state"])
+    x = filt(torch.tensor(z["x_raw"]), update=False)
+    np.testing.assert_allclose(x.numpy(), z["x_norm"], rtol=1e-12, atol=1e-12)
+    with torch.no_grad():
+        np.testing.assert_allclose(pol.select_action(x, mean_action=True).numpy(), z["action_mean"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(val(x).numpy(), z["value"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(pol.get_log_prob(x, torch.tensor(z["action"])).numpy(), z["log_prob"], rtol=1e-12)
+    # and back: our checkpoint carries a reference-compatible running state
+    back = filt.to_reference()
+    assert back.rs._n == cp["running_state"].rs._n and np.allclose(back.rs._M, cp["running_state"].rs._M)
