@@ -62,6 +62,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HoicError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: it brings its own libamdhip64; loading ours before it would start a second HIP runtime in the
+    # process (the library then sees no device)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     L.hoic_create.restype = vp
