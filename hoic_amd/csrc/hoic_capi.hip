@@ -411,6 +411,8 @@ struct hoic_sim {
   hipEvent_t ev[NEV][3] = {};
   long long n_timed = 0, n_drained = 0;
   bool has_expert = false;
+  int expert_reserve = 0, expert_cap = 0;   // streaming: room for more frames behind the last sequence
+  std::vector<int> h_seq_len, h_seq_off;
 };
 
 namespace {
@@ -706,9 +708,9 @@ extern "C" int32_t hoic_set_mode(hoic_sim* s, int32_t train) {
   return HOIC_OK;
 }
 
-template <typename T> static T* upload(hoic_sim* s, const T* h, size_t n) {
+template <typename T> static T* upload(hoic_sim* s, const T* h, size_t n, size_t extra = 0) {
   T* d = nullptr;
-  if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+  if (hipMalloc(&d, (n + extra) * sizeof(T)) != hipSuccess) return nullptr;
   hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
   s->ex_allocs.push_back(d);
   return d;
@@ -725,19 +727,52 @@ extern "C" int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* se
   s->ex_allocs.clear();
   std::vector<int> off(n_seq);
   size_t T = 0;
-  for (int i = 0; i < n_seq; i++) { if (seq_len[i] < 8) { set_err("hoic_set_expert: sequence shorter than 8 frames"); return HOIC_ERR_ARG; } off[i] = (int)T; T += seq_len[i]; }
+  for (int i = 0; i < n_seq; i++) { if (seq_len[i] < 2) { set_err("hoic_set_expert: sequence shorter than 2 frames"); return HOIC_ERR_ARG; } off[i] = (int)T; T += seq_len[i]; }
   const int nh = s->hm.hand_nq;
   DevExpert& x = s->ex;
   x.n_seq = n_seq; x.total = (int)T;
   x.seq_off = upload(s, off.data(), n_seq); x.seq_len = upload(s, seq_len, n_seq);
-  x.hand_dof = upload(s, hand_dof, T * nh); x.hand_dof_vel = upload(s, hand_dof_vel, T * nh);
-  x.obj_pose = upload(s, obj_pose, T * 7); x.obj_vel = upload(s, obj_vel, T * 3); x.obj_angvel = upload(s, obj_angvel, T * 3);
-  x.body_pos = upload(s, body_pos, T * NHB * 3); x.body_quat = upload(s, body_quat, T * NHB * 4);
+  const size_t R = (size_t)s->expert_reserve;
+  x.hand_dof = upload(s, hand_dof, T * nh, R * nh); x.hand_dof_vel = upload(s, hand_dof_vel, T * nh, R * nh);
+  x.obj_pose = upload(s, obj_pose, T * 7, R * 7); x.obj_vel = upload(s, obj_vel, T * 3, R * 3); x.obj_angvel = upload(s, obj_angvel, T * 3, R * 3);
+  x.body_pos = upload(s, body_pos, T * NHB * 3, R * NHB * 3); x.body_quat = upload(s, body_quat, T * NHB * 4, R * NHB * 4);
+  s->expert_cap = (int)(T + R);
+  s->h_seq_off = off; s->h_seq_len.assign(seq_len, seq_len + n_seq);
   if (!x.seq_off || !x.seq_len || !x.hand_dof || !x.hand_dof_vel || !x.obj_pose || !x.obj_vel || !x.obj_angvel || !x.body_pos || !x.body_quat) {
     set_err("hoic_set_expert: hipMalloc failed"); return HOIC_ERR_DEVICE;
   }
   HIPCHK(hipMemcpy(s->d_ex, &s->ex, sizeof(DevExpert), hipMemcpyHostToDevice));
   s->has_expert = true;
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_set_expert_reserve(hoic_sim* s, int32_t frames) {
+  if (!s || frames < 0) { set_err("hoic_set_expert_reserve: bad arguments"); return HOIC_ERR_ARG; }
+  s->expert_reserve = frames;
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_append_expert_frame(hoic_sim* s, const float* hand_dof, const float* hand_dof_vel, const float* obj_pose,
+                                            const float* obj_vel, const float* obj_angvel, const float* body_pos,
+                                            const float* body_quat, void* stream) {
+  if (!s || !hand_dof || !hand_dof_vel || !obj_pose || !obj_vel || !obj_angvel || !body_pos || !body_quat) { set_err("hoic_append_expert_frame: null"); return HOIC_ERR_ARG; }
+  if (!s->has_expert) { set_err("hoic_append_expert_frame: set_expert has not been called"); return HOIC_ERR_STATE; }
+  DevExpert& x = s->ex;
+  if (x.total >= s->expert_cap) { set_err("hoic_append_expert_frame: reserve used up (hoic_set_expert_reserve)"); return HOIC_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nh = s->hm.hand_nq;
+  const size_t t = (size_t)x.total;
+  const int last = x.n_seq - 1;
+  HIPCHK(hipMemcpyAsync((float*)x.hand_dof + t * nh, hand_dof, nh * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((float*)x.hand_dof_vel + t * nh, hand_dof_vel, nh * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((float*)x.obj_pose + t * 7, obj_pose, 7 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((float*)x.obj_vel + t * 3, obj_vel, 3 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((float*)x.obj_angvel + t * 3, obj_angvel, 3 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((float*)x.body_pos + t * NHB * 3, body_pos, NHB * 3 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((float*)x.body_quat + t * NHB * 4, body_quat, NHB * 4 * 4, hipMemcpyHostToDevice, st));
+  s->h_seq_len[last] += 1; x.total += 1;
+  HIPCHK(hipMemcpyAsync((int*)x.seq_len + last, &s->h_seq_len[last], 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->d_ex, &s->ex, sizeof(DevExpert), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));      // the host staging values above must outlive the copies
   return HOIC_OK;
 }
 

@@ -53,7 +53,7 @@ __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, 
   const float dt = m.timestep;
   float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
   if (d < n) {
-    const float* ref = ev.ex->hand_dof + (size_t)ev.frame(0) * m.hand_nq;
+    const float* ref = ev.ex->hand_dof + (size_t)ev.frame(cfg.c.pd_ref_offset) * m.hand_nq;   // 0; 1 in the streaming env
     float target;
     const float a = w.action[d];
     if (d < 3) target = ref[d] + 0.1f * a;

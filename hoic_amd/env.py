@@ -207,6 +207,94 @@ class HandObjMimic4:
         return self.data.qvel[self.hand_qvel_dim:].copy()
 
 
+class HandObjMimicTest:
+    """Streaming environment of the real-time demo (uhc/envs/ho_im_test.py:26-91 + InferenceServer/RLTest.py:262-300):
+    the expert is a sliding window of ``w_size + 1`` frames fed one frame per control step; getters index the window.
+
+    Here the window is the tail of ONE growing sequence on the device (``hoic_append_expert_frame``); with the PD
+    reference offset of the streaming loop (the new frame is inserted before ``env.step``) the kernels' absolute frame
+    index ``cur_t + k`` is the reference's window index ``k``.  One environment, latency-bound by construction."""
+
+    def __init__(self, cfg, init_expert_seq, model_xml="box", data_specs=None, mode="test", device_index=0,
+                 max_frames=100000):
+        import torch
+        self.torch = torch
+        self.cc_cfg = cfg
+        self.w_size = cfg.future_w_size
+        assert len(init_expert_seq) == self.w_size + 1, "the window is w_size + 1 frames (ho_im_test.py:28-30)"
+        self.expert_window = [dict(f) for f in init_expert_seq]
+        self.expert_index = list(range(self.w_size + 1))
+        keys = ("hand_dof_seq", "hand_dof_vel_seq", "obj_pose_seq", "obj_vel_seq", "obj_angle_vel_seq",
+                "body_pos_seq", "body_quat_seq")
+        seq = {k: np.stack([np.asarray(f[k], dtype=np.float64) for f in init_expert_seq]) for k in keys}
+        if isinstance(model_xml, str):
+            blob = open(mjcf.packaged_model_path(model_xml), "rb").read()
+        else:
+            blob = model_xml.to_blob() if isinstance(model_xml, mjcf.CompiledModel) else bytes(model_xml)
+        self.sim = lib.BatchedSim(blob, 1, device_index)
+        self.model = self.sim.model
+        self.device = self.sim.device
+        self.sim.set_config(cfg.jkp, cfg.jkd, cfg.torque_lim,
+                            (cfg.pos_diff_thresh, cfg.rot_diff_thresh, cfg.jpos_diff_thresh, cfg.obj_pos_diff_thresh,
+                             cfg.obj_rot_diff_thresh), cfg.residual_force_scale, cfg.residual_torque_scale,
+                            sim_step=cfg.sim_step, residual_force=cfg.residual_force, explain_force=cfg.explain_force,
+                            surface_contact=cfg.surface_contact, pd_rel=(cfg.pd_type != "base"), pd_ref_offset=1)
+        self.sim.set_reward_params(cfg.reward_wk(), 0.0, False)
+        self.sim.set_expert_reserve(max_frames)
+        self.sim.set_expert([seq])
+        self.sim.set_mode(mode == "train")
+        self._t0 = 0                      # absolute index of window frame 0
+        self.hand_qpos_dim, self.hand_qvel_dim = self.model.scalar("hand_nq"), self.model.scalar("hand_nv")
+        self.observation_space, self.action_space = _Space(lib.OBS_DIM), _Space(lib.ACT_DIM)
+        self.data = SimpleNamespace()
+        self.reset()
+
+    # ---- ho_im_test.py:34-43
+    def insert_new_frame(self, frame):
+        expire = self.expert_index[0]
+        self.expert_window[expire] = dict(frame)
+        self.expert_index = [(i + 1) % (self.w_size + 1) for i in self.expert_index]
+        self.sim.append_expert_frame(frame)
+        self._t0 += 1
+
+    def get_expert_attr(self, attr, ind):
+        assert ind <= self.w_size
+        return np.array(self.expert_window[self.expert_index[ind]][attr], dtype=np.float64).copy()
+
+    def get_expert_hand_qpos(self, delta_t=0):
+        return self.get_expert_attr("hand_dof_seq", delta_t)
+
+    def get_expert_obj_pose(self, delta_t=0):
+        return self.get_expert_attr("obj_pose_seq", delta_t)
+
+    def _sync(self):
+        qpos, qvel, _ = self.sim.get_state()
+        self.data.qpos = qpos[0].double().cpu().numpy(); self.data.qvel = qvel[0].double().cpu().numpy()
+
+    def reset(self, tracking=False):
+        """reset_model (:77-91): state <- window frame 0"""
+        t = self.torch
+        obs = self.sim.reset(t.zeros(1, dtype=t.int32), t.full((1,), self._t0, dtype=t.int32))
+        self._sync()
+        return obs[0].double().cpu().numpy()
+
+    def get_obs(self):
+        return self.sim.obs[0].double().cpu().numpy()
+
+    def step(self, a):
+        t = self.torch
+        obs, rew, rinfo, flags, pct = self.sim.step(t.as_tensor(np.asarray(a, dtype=np.float32)[None], device=self.device))
+        self._sync()
+        return (obs[0].double().cpu().numpy(), 1.0, bool(flags[0, 2]),
+                {"fail": bool(flags[0, 0]), "end": bool(flags[0, 1]), "percent": float(pct[0])})
+
+    def get_hand_qpos(self):
+        return self.data.qpos[:self.hand_qpos_dim].copy()
+
+    def get_obj_qpos(self):
+        return self.data.qpos[self.hand_qpos_dim:].copy()
+
+
 def ho_mimic_reward_9(env, state, action, info):
     """Reference call shape (uhc/envs/ho_reward.py:943): the value was computed inside the fused step."""
     return env.c_reward, env.c_info

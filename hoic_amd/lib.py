@@ -31,7 +31,7 @@ class EnvConfig(C.Structure):
                 ("residual_force_scale", C.c_float), ("residual_torque_scale", C.c_float),
                 ("sim_step", C.c_int32), ("future_w_size", C.c_int32), ("residual_force", C.c_int32),
                 ("explain_force", C.c_int32), ("surface_contact", C.c_int32), ("pd_rel", C.c_int32),
-                ("solver_iterations", C.c_int32), ("reserved", C.c_int32)]
+                ("solver_iterations", C.c_int32), ("pd_ref_offset", C.c_int32)]
 
 
 class RewardParams(C.Structure):
@@ -41,7 +41,8 @@ class RewardParams(C.Structure):
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_enable_timing",
-           "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times"]
+           "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_set_expert_reserve",
+           "hoic_append_expert_frame"]
 
 
 def build(force: bool = False) -> str:
@@ -90,6 +91,8 @@ def load():
     L.hoic_last_step_ms.restype = f32
     L.hoic_last_poststep_ms.argtypes = [vp]
     L.hoic_step_times.argtypes = [vp, vp, vp, i32]
+    L.hoic_set_expert_reserve.argtypes = [vp, i32]
+    L.hoic_append_expert_frame.argtypes = [vp] * 9
     L.hoic_last_poststep_ms.restype = f32
     for n in EXPORTS:
         if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms", "hoic_last_poststep_ms"):
@@ -150,7 +153,7 @@ class BatchedSim:
     # ---- configuration
     def set_config(self, jkp, jkd, torque_lim, thresh=(0.1, 1.0, 0.1, 0.1, 1.0), rf_scale=2.5, rt_scale=0.125,
                    sim_step=15, residual_force=True, explain_force=True, surface_contact=True, pd_rel=True,
-                   solver_iterations=8):
+                   solver_iterations=8, pd_ref_offset=0):
         c = EnvConfig()
         for i in range(26):
             c.jkp[i], c.jkd[i], c.torque_lim[i] = float(jkp[i]), float(jkd[i]), float(torque_lim[i])
@@ -160,6 +163,7 @@ class BatchedSim:
         c.sim_step, c.future_w_size = int(sim_step), 5
         c.residual_force, c.explain_force, c.surface_contact = int(residual_force), int(explain_force), int(surface_contact)
         c.pd_rel, c.solver_iterations = int(pd_rel), int(solver_iterations)
+        c.pd_ref_offset = int(pd_ref_offset)
         self.torch.cuda.synchronize(self.device)
         _chk(self.L.hoic_set_config(self.h, C.byref(c)), "hoic_set_config")
 
@@ -185,6 +189,18 @@ class BatchedSim:
         _chk(self.L.hoic_set_expert(self.h, len(seqs), lens.ctypes.data_as(C.c_void_p),
                                     *[a.ctypes.data_as(C.c_void_p) for a in cat]), "hoic_set_expert")
         self.seq_len = lens
+
+    def set_expert_reserve(self, frames: int):
+        _chk(self.L.hoic_set_expert_reserve(self.h, int(frames)), "hoic_set_expert_reserve")
+
+    def append_expert_frame(self, frame: dict):
+        """streaming: one more frame (dict with the preprocess_seq keys, one time step each) behind the last sequence"""
+        keys = ("hand_dof_seq", "hand_dof_vel_seq", "obj_pose_seq", "obj_vel_seq", "obj_angle_vel_seq",
+                "body_pos_seq", "body_quat_seq")
+        arrs = [np.ascontiguousarray(np.asarray(frame[k], dtype=np.float32).reshape(-1)) for k in keys]
+        _chk(self.L.hoic_append_expert_frame(self.h, *[a.ctypes.data_as(C.c_void_p) for a in arrs], self._stream()),
+             "hoic_append_expert_frame")
+        self.seq_len[-1] += 1
 
     # ---- stepping
     def reset(self, seq, start, env_ids=None):

@@ -39,7 +39,8 @@ typedef struct hoic_env_config {
   int32_t residual_force, explain_force, surface_contact;
   int32_t pd_rel;          /* pd_type == "rel" */
   int32_t solver_iterations; /* Newton iteration cap per substep (fp32) */
-  int32_t reserved;
+  int32_t pd_ref_offset;     /* 0: training env; 1: streaming env (uhc/envs/ho_im_test.py: the new frame is inserted before
+                              * env.step, InferenceServer/RLTest.py:298-299, so the PD target is expert frame t+1) */
 } hoic_env_config;
 
 /* Reward parameters of ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-967); refreshed every epoch by
@@ -71,6 +72,17 @@ int32_t hoic_set_mode(hoic_sim* s, int32_t train); /* set_mode('train'|'test'), 
 int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* seq_len, const float* hand_dof,
                         const float* hand_dof_vel, const float* obj_pose, const float* obj_vel,
                         const float* obj_angvel, const float* body_pos, const float* body_quat);
+
+/* ---- streaming (HandObjMimicTest.insert_new_frame, uhc/envs/ho_im_test.py:34-38): the LAST sequence of the expert
+ * table may grow at run time.  hoic_set_expert_reserve (before hoic_set_expert) reserves room for `frames` more
+ * frames; hoic_append_expert_frame appends one frame — host float32 arrays hand_dof[26], hand_dof_vel[26],
+ * obj_pose[7], obj_vel[3], obj_angvel[3], body_pos[21*3], body_quat[21*4] — to the last sequence (asynchronous on
+ * `stream`; HOIC_ERR_STATE when the reserve is used up).  With an ever-growing sequence and pd_ref_offset = 1 the
+ * absolute frame index cur_t + k of the kernels equals the reference's sliding-window index k. */
+int32_t hoic_set_expert_reserve(hoic_sim* s, int32_t frames);
+int32_t hoic_append_expert_frame(hoic_sim* s, const float* hand_dof, const float* hand_dof_vel, const float* obj_pose,
+                                 const float* obj_vel, const float* obj_angvel, const float* body_pos,
+                                 const float* body_quat, void* stream);
 
 /* ---- reset: MujocoEnv.reset + HandObjMimic4.reset_model (mujoco_env.py:95-114, ho_im4.py:690-716) for the
  * envs listed in d_env_ids (n entries, int32; NULL = all envs in order).  d_seq / d_start: per listed env,

@@ -20,6 +20,7 @@ typedef struct ho_cfg {
   double pos_diff_thresh, rot_diff_thresh, jpos_diff_thresh, obj_pos_diff_thresh, obj_rot_diff_thresh;
   double residual_force_scale, residual_torque_scale;
   int sim_step, w_size, residual_force, explain_force, surface_contact, mode_train, pd_rel;
+  int pd_ref_offset;   /* 1: streaming env (uhc/envs/ho_im_test.py: the frame is inserted before step, so delta_t = 0 is frame t+1) */
 } ho_cfg;
 
 typedef struct ho_expert {
@@ -112,6 +113,7 @@ static void free_expert(ho_expert* x) {
   free(x->body_pos); free(x->body_quat);
   memset(x, 0, sizeof(*x));
 }
+void hoo_env_set_pd_ref_offset(ho_env* e, int off) { e->cfg.pd_ref_offset = off; }
 void hoo_env_destroy(ho_env* e) { if (e) { free_expert(&e->e); free(e); } }
 
 void hoo_env_set_cfg(ho_env* e, const double* jkp, const double* jkd, const double* torque_lim,
@@ -201,7 +203,7 @@ void hoo_env_compute_torque(const ho_env* e, const double* ctrl, double* torque)
   const ho_model* m = &e->m; const ho_data* d = &e->d;
   int n = m->hand_nv;
   double dt = m->timestep, target[NU], err[NU], rhs[NU], A[NU * NU];
-  const double* ref = e->e.hand_dof + (size_t)eidx(e, 0) * m->hand_nq;
+  const double* ref = e->e.hand_dof + (size_t)eidx(e, e->cfg.pd_ref_offset) * m->hand_nq;
   for (int i = 0; i < 3; i++) target[i] = ref[i] + 0.1 * ctrl[i];
   for (int i = 3; i < 6; i++) target[i] = ref[i] + 0.3 * ctrl[i];
   for (int i = 6; i < n; i++) target[i] = (e->cfg.pd_rel ? ref[i] : e->base_pose[i]) + e->ctrl_scale[i] * ctrl[i];

@@ -44,6 +44,7 @@ def lib():
         L.hoo_get_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hoo_env_set_cfg.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p]
         L.hoo_env_set_expert.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        L.hoo_env_set_pd_ref_offset.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hoo_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hoo_env_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -118,6 +119,10 @@ class OracleEnv:
         flags = np.array([sim_step, w_size, residual_force, explain_force, surface_contact, mode_train, pd_rel], np.int32)
         a, b, c, t = _f64(jkp), _f64(jkd), _f64(torque_lim), _f64(thresh)
         self.L.hoo_env_set_cfg(self.h, _p(a), _p(b), _p(c), _p(t), float(rf_scale), float(rt_scale), _p(flags))
+
+    def set_pd_ref_offset(self, off: int):
+        """1 = streaming env semantics (uhc/envs/ho_im_test.py + InferenceServer/RLTest.py:289-300)"""
+        self.L.hoo_env_set_pd_ref_offset(self.h, int(off))
 
     def set_expert(self, ex: dict):
         T = ex["hand_dof_seq"].shape[0]
