@@ -11,6 +11,10 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#ifdef HOIC_TRACE_DISPATCH
+__device__ int g_trace_bb[1 << 16];     // development aid: box-box turns per workgroup
+__device__ int g_trace_qp[4 << 16];     // QP iterations / line-search steps / columns / warm per workgroup
+#endif
 #include "hoic_env.h"
 
 static thread_local std::string g_err;
@@ -115,7 +119,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
-  const int env = blockIdx.x, tid = threadIdx.x;
+  const int env = st.order[blockIdx.x], tid = threadIdx.x;
+  const long long clk0 = (long long)__builtin_readcyclecounter();
+#ifdef HOIC_TRACE_DISPATCH
+  const long long trace_t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  int trace_ncon = 0, trace_iter = 0, trace_ncon_max = 0, trace_late = 0, trace_last = 0;
+  if (tid == 0) g_trace_bb[blockIdx.x] = 0;
+#endif
   load_state(m, st, w, env);
   dev_load_constants(m, w);
   MReg M;
@@ -181,6 +191,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     if (mode == 2) break;
     ok = dev_forward_dyn(ml, cl, w, M);       // :545 mj_step = forward ...
+#ifdef HOIC_TRACE_DISPATCH
+    trace_ncon += w.ncon; trace_iter += w.solver_iter; trace_ncon_max = max(trace_ncon_max, w.ncon);
+    if (done_sub >= nsub - 5) trace_late += w.solver_iter;
+    if (done_sub >= nsub - 1) trace_last = w.solver_iter * 100 + w.ncon;
+#endif
     if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
       if (tid < NQP) w.qpos[tid] = w.qlag[tid];
       if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
@@ -220,6 +235,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
   if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
   store_state(st, w, env);
+  if (tid == 0) st.cost[env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
+#ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock
+  if (tid == 0) {
+    long long* tr = st.phase + (size_t)env * 24;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tr[0] = trace_t0; tr[1] = (long long)__builtin_amdgcn_s_memrealtime(); tr[2] = hw; tr[3] = xcc; tr[4] = blockIdx.x;
+    tr[5] = trace_ncon; tr[6] = trace_iter; tr[7] = g_trace_bb[blockIdx.x]; tr[8] = trace_ncon_max; tr[9] = trace_late; tr[10] = trace_last;
+  }
+#endif
   PT(13);
 #ifdef HOIC_PHASE_TIMING
   if (tid < 24) st.phase[(size_t)env * 24 + tid] = w.pt[tid];
@@ -236,7 +262,12 @@ __global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __res
                                                            const int* __restrict__ next_start) {
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
-  const int env = blockIdx.x, tid = threadIdx.x;
+  const int n_envs = gridDim.x;
+  const int env = st.order[n_envs + blockIdx.x], tid = threadIdx.x;
+  const long long clk0 = (long long)__builtin_readcyclecounter();
+#ifdef HOIC_TRACE_DISPATCH
+  if (tid == 0) for (int i = 0; i < 4; i++) g_trace_qp[blockIdx.x * 4 + i] = 0;
+#endif
   const float* post = st.post + (size_t)env * PB_SIZE;
   if (tid < NQP) w.qpos[tid] = st.qpos[(size_t)env * NQP + tid];
   if (tid < NV) {
@@ -299,7 +330,58 @@ __global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __res
     store_state(st, w, env);
   }
   dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
-  if (tid == 0) st.cur_t[env] = ev.cur_t;
+  if (tid == 0) {
+    st.cur_t[env] = ev.cur_t;
+    st.cost[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
+#ifdef HOIC_TRACE_DISPATCH
+    long long* tr = st.phase + (size_t)env * 24;
+    for (int i = 0; i < 4; i++) tr[12 + i] = g_trace_qp[blockIdx.x * 4 + i];
+#endif
+  }
+}
+
+// ---- launch order of the next step (optional, HOIC_REORDER=1).  An env's pass takes between ~0.7x and ~1.8x the
+// mean (contacts, Newton and QP iterations), and 4096 envs are only two rounds of the 2048 resident wavefronts, so
+// the last round ends with a tail of half-empty CUs (27 % of the wave slots idle, tools/dispatch_trace.py).
+// Longest-first dispatch by the measured duration of the previous pass shortens that tail when durations persist from
+// step to step: a counting sort on 1024 duration bins, one workgroup per kernel (blockIdx 0: substep order, 1:
+// post-step order).  The order only changes which CU runs an env, never a result.
+#define ORDER_NT 1024
+__global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __restrict__ cost_all, int* __restrict__ order_all, int n) {
+  __shared__ unsigned hist[ORDER_NT], scan[ORDER_NT];
+  __shared__ unsigned lo, hi;
+  const unsigned* cost = cost_all + (size_t)blockIdx.x * n;
+  int* order = order_all + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  if (tid == 0) { lo = 0xFFFFFFFFu; hi = 0u; }
+  hist[tid] = 0u;
+  __syncthreads();
+  unsigned mn = 0xFFFFFFFFu, mx = 0u;
+  for (int i = tid; i < n; i += ORDER_NT) { const unsigned c = cost[i]; mn = min(mn, c); mx = max(mx, c); }
+  atomicMin(&lo, mn); atomicMax(&hi, mx);
+  __syncthreads();
+  const unsigned base = lo, span = max(hi - lo, 1u);
+  for (int i = tid; i < n; i += ORDER_NT) {
+    const unsigned b = (ORDER_NT - 1) - (unsigned)(((unsigned long long)(cost[i] - base) * (ORDER_NT - 1)) / span);   // bin 0 = longest
+    atomicAdd(&hist[b], 1u);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the bins
+  unsigned v = hist[tid];
+  scan[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < ORDER_NT; off <<= 1) {
+    const unsigned a = tid >= off ? scan[tid - off] : 0u;
+    __syncthreads();
+    scan[tid] += a;
+    __syncthreads();
+  }
+  hist[tid] = scan[tid] - v;
+  __syncthreads();
+  for (int i = tid; i < n; i += ORDER_NT) {
+    const unsigned b = (ORDER_NT - 1) - (unsigned)(((unsigned long long)(cost[i] - base) * (ORDER_NT - 1)) / span);
+    order[atomicAdd(&hist[b], 1u)] = i;
+  }
 }
 
 __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restrict__ mp, DevExpert ex, DevState st,
@@ -395,6 +477,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
 
 // ------------------------------------------------------------------------------------------------ host side
 struct hoic_sim {
+  bool reorder = false;
   int n_envs = 0, device = 0;
   DevModel hm;            // host copy
   DevModel* d_model = nullptr;
@@ -656,7 +739,8 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
        hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess &&
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
-       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess;
+       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess &&
+       hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
   ok = hipMalloc(&s->d_ex, sizeof(DevExpert)) == hipSuccess && hipMalloc(&s->d_st, sizeof(DevState)) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
@@ -668,6 +752,11 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
   hipMemset(s->st.overflow, 0, n * 4); hipMemset(s->st.phase, 0, n * 24 * 8);
   hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
+  hipMemset(s->st.cost, 0, 2 * n * 4);
+  hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, 0, s->st.cost, s->st.order, n_envs);   // a valid permutation from the start
+  // Off unless HOIC_REORDER=1: at the random-policy start of training the previous step's duration predicts the next
+  // one only weakly (correlation 0.1-0.4, tools/dispatch_trace.py) and the measured kernel time is unchanged.
+  s->reorder = getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '1';
   hipDeviceSynchronize();
   return s;
 }
@@ -677,7 +766,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   delete s;
@@ -793,6 +882,7 @@ extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, f
   if (!s->has_expert) { set_err("hoic_step: set_expert has not been called"); return HOIC_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t* e = s->timing ? s->ev[s->n_timed % hoic_sim::NEV] : nullptr;
+  if (s->reorder) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
   if (e) hipEventRecord(e[0], st);
   hipLaunchKernelGGL(hoic_substep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action);
   if (e) hipEventRecord(e[1], st);
@@ -859,6 +949,13 @@ extern "C" float hoic_last_poststep_ms(hoic_sim* s) {
   hipEvent_t* e = s->ev[(s->n_timed - 1) % hoic_sim::NEV];
   return ev_ms(e[1], e[2]);
 }
+extern "C" int32_t hoic_env_durations(hoic_sim* s, uint32_t* h_substep, uint32_t* h_poststep) {
+  if (!s || !h_substep || !h_poststep) return HOIC_ERR_ARG;
+  hipSetDevice(s->device);
+  HIPCHK(hipMemcpy(h_substep, s->st.cost, (size_t)s->n_envs * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h_poststep, s->st.cost + s->n_envs, (size_t)s->n_envs * 4, hipMemcpyDeviceToHost));
+  return HOIC_OK;
+}
 extern "C" int32_t hoic_step_times(hoic_sim* s, float* substep_ms, float* poststep_ms, int32_t max_n) {
   if (!s || !substep_ms || !poststep_ms || max_n <= 0) return HOIC_ERR_ARG;
   if (!s->ev[0][0]) return 0;
@@ -873,6 +970,12 @@ extern "C" int32_t hoic_step_times(hoic_sim* s, float* substep_ms, float* postst
   return n;
 }
 
+extern "C" int32_t hoicdbg_phase_raw(hoic_sim* s, long long* out) {     // development aid: the raw [n_envs, 24] counters
+  if (!s || !out) return HOIC_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, s->st.phase, (size_t)s->n_envs * 24 * 8, hipMemcpyDeviceToHost));
+  return HOIC_OK;
+}
 // development aid (not part of include/hoic.h): per-phase shader-cycle counters of the last step, averaged over
 // envs; all zeros unless the library was built with -DHOIC_PHASE_TIMING
 extern "C" int32_t hoicdbg_phase_cycles(hoic_sim* s, double* out24, int32_t* overflow_total) {

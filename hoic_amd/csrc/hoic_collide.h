@@ -550,6 +550,9 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
     // box-box pairs: one after the other, the whole wave on each (col_box_box_wave)
     {
       unsigned long long bbmask = __ballot(isbb);
+#ifdef HOIC_TRACE_DISPATCH
+      if (tid == 0) g_trace_bb[blockIdx.x] += __popcll(bbmask);
+#endif
       while (bbmask) {
         const int L = __ffsll((long long)bbmask) - 1;
         bbmask &= bbmask - 1;

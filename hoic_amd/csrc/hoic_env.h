@@ -282,7 +282,13 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   double lam[6];
   const bool have_warm = warm_lam[6] != 0.0;
   for (int i = 0; i < 6; i++) lam[i] = have_warm ? warm_lam[i] : -2.0 * b[i];
+#ifdef HOIC_TRACE_DISPATCH
+  int trace_it = 0, trace_ls = 0;
+#endif
   for (int it = 0; it < 60; it++) {
+#ifdef HOIC_TRACE_DISPATCH
+    trace_it++;
+#endif
     double g[6], H[21];
     for (int i = 0; i < 6; i++) g[i] = 0.0;
     for (int i = 0; i < 21; i++) H[i] = 0.0;
@@ -320,6 +326,9 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     for (int i = 0; i < 6; i++) { gl += lam[i] * dir[i]; dd += dir[i] * dir[i]; bd += b[i] * dir[i]; }
     double al = 1.0, lo = 0.0, hi = -1.0;
     for (int ls = 0; ls < 60; ls++) {
+#ifdef HOIC_TRACE_DISPATCH
+      trace_ls++;
+#endif
       double dphi = 0, ddphi = 0;
       for (int jj = 0; jj < nslot; jj++) {
         const int col = tid + jj * NT;
@@ -348,6 +357,9 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     for (int i = 0; i < 6; i++) { lam[i] += al * dir[i]; st += al * al * dir[i] * dir[i]; }
     if (sqrt(st) < 1e-15 * (1.0 + sqrt(ln))) break;
   }
+#ifdef HOIC_TRACE_DISPATCH
+  if (tid == 0) { g_trace_qp[blockIdx.x * 4] = trace_it; g_trace_qp[blockIdx.x * 4 + 1] = trace_ls; g_trace_qp[blockIdx.x * 4 + 2] = ncol; g_trace_qp[blockIdx.x * 4 + 3] = have_warm; }
+#endif
   if (tid < 6) warm_lam[tid] = lam[tid];
   if (tid == 6) warm_lam[6] = 1.0;
   const double rf = 0.5 * sqrt(lam[0] * lam[0] + lam[1] * lam[1] + lam[2] * lam[2]);

@@ -26,62 +26,73 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
-template <int J> HD float hs_row_bcast(const f32x16& acc) {
-  constexpr int reg = (J & 3) + 4 * (J >> 3);
-  constexpr int half = (J >> 2) & 1;
-  const unsigned v = __float_as_uint(acc[reg]);
-  const u32x2v r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // .x = low half on both, .y = high half on both
-  return __uint_as_float(half ? r.y : r.x);
+template <int LANE> HD void hs_writelane(float& dst, float uniform_val) {     // uniform_val must be wave-uniform (SGPR)
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(uniform_val), "n"(LANE));
 }
-
-template <int LANE> HD void hs_writelane(float& dst, float uniform_val) {
-  const int sv = __builtin_amdgcn_readfirstlane(__float_as_int(uniform_val));
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "n"(LANE));
+// 1 / max(d, 1e-30) of a wave-uniform pivot: the clamp runs on the scalar unit (positive floats order like integers,
+// negative ones are negative integers), the reciprocal is one VALU op
+HD float hs_pivot_ninv(float d_uniform, float& d_clamped) {
+  const int di = max(__float_as_int(d_uniform), 0x0DA24260);      // bits of 1e-30f
+  d_clamped = __int_as_float(di);
+  return -__builtin_amdgcn_rcpf(d_clamped);
 }
-// `col` is made opaque at every step so that the lane masks (col > J ...) are recomputed on the spot (one v_cmp)
-// instead of being hoisted out of the substep loop as ~100 loop-invariant SGPR pairs, which spill.
+// One pivot pair (J, J+1).  Rows J and J+1 of the running matrix sit in two registers of the same half-wave: one
+// permlane32_swap puts row J on the low lanes and row J+1 on the high lanes, a second one spreads each over both
+// halves.  nl = -L[.][J] doubles as the MFMA A operand, the forward-substitution multiplier and the value stored in
+// T.  No lane masks anywhere: entries of nl at lanes <= J are rounding residue and only touch entries of y that have
+// already been extracted (y_J goes to lane J of yv, the pivot d_J to lane J of dv).
 template <int J> struct HsFactor {
-  static HD void run(f32x16& acc, float& y, float& dinv, int col, int hi, float* T) {
-#ifndef HOIC_NO_OPAQUE
-    asm volatile("" : "+v"(col));
-#endif
-    const float u0 = hs_row_bcast<J>(acc);           // u0[lane&31] = A[J][.] = L[.][J] * d_J
-    const float r1 = hs_row_bcast<J + 1>(acc);
-    const float inv0 = __builtin_amdgcn_rcpf(fmaxf(rl(u0, J), 1e-30f));
-    const float l0 = u0 * inv0;
-    const float u1 = r1 - rl(l0, J + 1) * u0;        // row J+1 after eliminating pivot J
-    const float inv1 = __builtin_amdgcn_rcpf(fmaxf(rl(u1, J + 1), 1e-30f));
-    const float l1 = u1 * inv1;
-    if (J < 30) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? -l1 : -l0, hi ? u1 : u0, acc, 0, 0, 0);
-    // 1/d_J lands in lane J (only the low half-wave carries the solution)
-#ifndef HOIC_NO_WRITELANE
-    hs_writelane<J>(dinv, inv0);
-    hs_writelane<J + 1>(dinv, inv1);
-#else
-    dinv = (col == J) ? inv0 : ((col == J + 1) ? inv1 : dinv);
-#endif
+  static HD void run(f32x16& acc, float& y, float& yv, float& dv, int hi, float* Tcol) {
+    constexpr int reg0 = (J & 3) + 4 * (J >> 3), reg1 = ((J + 1) & 3) + 4 * ((J + 1) >> 3), half = (J >> 2) & 1;
+    const u32x2v p = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[reg0]), __float_as_uint(acc[reg1]), false, false);
+    const unsigned q = half ? p.y : p.x;                      // low lanes: row J, high lanes: row J+1
+    const u32x2v sp = __builtin_amdgcn_permlane32_swap(q, q, false, false);
+    const float u0 = __uint_as_float(sp.x), r1 = __uint_as_float(sp.y);   // u0[c] = A[J][c] = L[c][J] d_J
+    float d0, d1;
+    const float ninv0 = hs_pivot_ninv(rl(u0, J), d0);
+    const float nl0 = u0 * ninv0;
+    const float u1 = fmaf(rl(nl0, J + 1), u0, r1);            // row J+1 after eliminating pivot J
+    const float ninv1 = hs_pivot_ninv(rl(u1, J + 1), d1);
+    const float nl1 = u1 * ninv1;
+    const float A = hi ? nl1 : nl0;
+    if (J < 30) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A, hi ? u1 : u0, acc, 0, 0, 0);
+    Tcol[J * LD] = A;                                         // T[J + hi][c] = -L[c][J + hi]
     const float y0 = rl(y, J);
-    y = (col > J) ? fmaf(-l0, y0, y) : y;
+    y = fmaf(nl0, y0, y);
     const float y1 = rl(y, J + 1);
-    y = (col > J + 1) ? fmaf(-l1, y1, y) : y;
-    T[(J + hi) * LD + col] = hi ? l1 : l0;           // T[k][c] = L[c][k]
-    HsFactor<J + 2>::run(acc, y, dinv, col, hi, T);
+    y = fmaf(nl1, y1, y);
+    hs_writelane<J>(yv, y0); hs_writelane<J + 1>(yv, y1);
+    hs_writelane<J>(dv, d0); hs_writelane<J + 1>(dv, d1);
+    HsFactor<J + 2>::run(acc, y, yv, dv, hi, Tcol);
   }
 };
-template <> struct HsFactor<32> { static HD void run(f32x16&, float&, float&, int, int, float*) {} };
+template <> struct HsFactor<32> { static HD void run(f32x16&, float&, float&, float&, int, float*) {} };
+// backward substitution, 16 columns of L in flight at a time; x_k goes to lane k of xv as soon as it is final
+template <int K> struct HsBack {
+  static HD void run(const float (&lc)[16], float& x, float& xv) {
+    constexpr int kk = K, k = K & 15;
+    const float xk = rl(x, kk);
+    hs_writelane<kk>(xv, xk);
+    if constexpr (kk > 0) x = fmaf(lc[k], xk, x);
+    if constexpr ((K & 15) != 0) HsBack<K - 1>::run(lc, x, xv);
+  }
+};
 
 // diag: per-lane diagonal increment of row/col (lane & 31); use_rows: add the active contact rows through the
-// MFMA; rhs: per-lane right-hand side (lane & 31).  Returns x[lane & 31] (both half-waves hold the solution).
+// MFMA; rhs: per-lane right-hand side (lane & 31).  Returns x[lane & 31] on the low half-wave lanes AND the high ones.
 __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MReg& M, float dg, int nact, bool use_rows, float rhs) {
   const int lane = opaque(threadIdx.x), col = lane & 31, hi = lane >> 5;
   f32x16 acc;
+  // this lane holds the diagonal entry (col, col) in register dreg if its half-wave owns row col
+  const int dreg = (((col >> 2) & 1) == hi) ? (col & 3) + 4 * (col >> 3) : -1;
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int r = MREG_ROW(reg, hi);
-    float v = M.r[reg];
-    if (r == col) v += dg;
-    if (r >= nact || col >= nact) v = (r == col) ? 1.f : 0.f;
-    acc[reg] = v;
+  for (int reg = 0; reg < 16; reg++) acc[reg] = M.r[reg] + (dreg == reg ? dg : 0.f);
+  if (nact < NV) {           // leading nact x nact block, identity elsewhere (the PD solve on the hand dofs)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int r = MREG_ROW(reg, hi);
+      if (r >= nact || col >= nact) acc[reg] = (r == col) ? 1.f : 0.f;
+    }
   }
   if (use_rows) {
     float Sc[6];
@@ -107,34 +118,28 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
     }
   }
   PT(15);
-  float y = rhs, dinv = 1.f;
+  float y = rhs, yv = 0.f, dv = 1.f;
   float* T = w.sc.T;
-  HsFactor<0>::run(acc, y, dinv, col, hi, T);
+  HsFactor<0>::run(acc, y, yv, dv, hi, T + hi * LD + col);
   PT(16);
-  y *= dinv;
+  float x = yv * __builtin_amdgcn_rcpf(dv);       // D^-1 L^-1 rhs
   __syncthreads();
-  // backward substitution in two halves (16 columns of L in flight at a time keeps the register peak down)
-  float x = y;
-  int colx = col;
-#pragma unroll
-  for (int h = 1; h >= 0; h--) {
+  float xv = 0.f;
+  {
     float lc[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + 16 * h + k];        // L[16h+k][col], valid for 16h+k > col
-#ifndef HOIC_NO_OPAQUE
-    asm volatile("" : "+v"(colx));     // keep the lane masks from being hoisted (see HsFactor)
-#endif
+    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + 16 + k];        // -L[16+k][col]
+    HsBack<31>::run(lc, x, xv);
 #pragma unroll
-    for (int k = 15; k >= 0; k--) {
-      const int kk = 16 * h + k;
-      if (kk == 0) continue;
-      const float xk = rl(x, kk);
-      x = (colx < kk) ? fmaf(-lc[k], xk, x) : x;
-    }
+    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + k];
+    HsBack<15>::run(lc, x, xv);
   }
   __syncthreads();
   PT(18);
-  return x;
+  // lanes 0..31 of xv hold the solution; the high half-wave gets a copy
+  const unsigned xb = __float_as_uint(xv);
+  const u32x2v xs = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+  return __uint_as_float(xs.x);
 }
 
 // impedance d(r) from solimp [MJ-doc: getimpedance]
@@ -145,10 +150,15 @@ HD float dev_impedance(const float* s_in, float pos, float margin) {
   float x = fabsf((pos - margin) / wdt);
   if (x >= 1.f) return s1;
   if (x <= 0.f) return s0;
-  float y;
-  if (pw == 1.f) y = x;
-  else if (x <= mid) y = powf(x, pw) / powf(mid, pw - 1.f);
-  else y = 1.f - powf(1.f - x, pw) / powf(1.f - mid, pw - 1.f);
+  // both branches of the power sigmoid are base^pw / bm^(pw-1) of a mirrored argument; base and bm lie in (0, 1],
+  // so the hardware log2/exp2 (1 ulp) replace the ~300-instruction library powf
+  const bool lo = x <= mid;
+  const float base = lo ? x : 1.f - x, bm = lo ? mid : 1.f - mid;
+  float r;
+  if (pw == 1.f) r = base;
+  else if (pw == 2.f) r = base * base * __builtin_amdgcn_rcpf(bm);
+  else r = __builtin_amdgcn_exp2f(pw * __builtin_amdgcn_logf(base) - (pw - 1.f) * __builtin_amdgcn_logf(bm));
+  const float y = lo ? r : 1.f - r;
   return s0 + y * (s1 - s0);
 }
 

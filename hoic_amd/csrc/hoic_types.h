@@ -123,6 +123,8 @@ struct DevState {
   float* oldg;   // [n, OG_SIZE]
   double* qp_lam; // [n, 8] warm start of the residual-force QP: lambda[6], valid flag, pad
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
+  unsigned* cost;    // [2, n] shader-clock duration (>> 6) of the env's last substep / post-step pass
+  int* order;        // [2, n] launch order of the next step: workgroup b runs env order[b], longest first
 };
 
 // joint-space inertia matrix in the layout of a v_mfma_f32_32x32x2_f32 accumulator: lane (col + 32*hi) holds, in

@@ -41,7 +41,7 @@ class RewardParams(C.Structure):
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_enable_timing",
-           "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_set_expert_reserve",
+           "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame"]
 
 
@@ -91,6 +91,7 @@ def load():
     L.hoic_last_step_ms.restype = f32
     L.hoic_last_poststep_ms.argtypes = [vp]
     L.hoic_step_times.argtypes = [vp, vp, vp, i32]
+    L.hoic_env_durations.argtypes = [vp, vp, vp]
     L.hoic_set_expert_reserve.argtypes = [vp, i32]
     L.hoic_append_expert_frame.argtypes = [vp] * 9
     L.hoic_last_poststep_ms.restype = f32
@@ -259,6 +260,12 @@ class BatchedSim:
         if n < 0:
             raise HoicError("hoic_step_times failed")
         return list(a[:n]), list(b[:n])
+
+    def env_durations(self):
+        """per-env duration (units of 64 shader clocks) of the last step's substep / post-step pass (numpy uint32)"""
+        a = np.zeros(self.n, dtype=np.uint32); b = np.zeros(self.n, dtype=np.uint32)
+        _chk(self.L.hoic_env_durations(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "hoic_env_durations")
+        return a, b
 
     def probe_forward(self, qpos, qvel, ctrl=None, applied=None, warm=None, do_step=False, kinematics_only=False):
         """mj_forward (+ Euler) at arbitrary states; returns a dict of numpy arrays.  ``kinematics_only``: return just

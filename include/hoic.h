@@ -130,6 +130,10 @@ float hoic_last_poststep_ms(hoic_sim* s);
  * without one host synchronisation per step); blocks until the last of them has finished.  Returns the number of
  * entries written (<= max_n), or a negative hoic_status. */
 int32_t hoic_step_times(hoic_sim* s, float* substep_ms, float* poststep_ms, int32_t max_n);
+/* Per-env duration of the last step's two passes in units of 64 shader clocks (HOST arrays of n_envs entries each).
+ * These are the keys of the longest-first launch order of the next step (the order never changes a result);
+ * synchronises the device. */
+int32_t hoic_env_durations(hoic_sim* s, uint32_t* h_substep, uint32_t* h_poststep);
 
 #ifdef __cplusplus
 }

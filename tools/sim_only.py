@@ -32,3 +32,9 @@ for t in range(STEPS):
 torch.cuda.synchronize()
 print('kernel ms', np.round(ms, 3), 'median', np.median(ms[2:]), 'dones', done, 'iters', np.round(np.mean(it), 3),
       'reward mean', float(out[1].mean()))
+if os.environ.get("HOIC_SHOW_DUR"):
+    a, b = sim.env_durations()
+    clk = 64 / 2.4e6     # ms per unit at 2.4 GHz (approximate: the shader clock is not fixed)
+    q = lambda x: np.round(np.percentile(x * clk, [0, 10, 50, 90, 99, 100]), 3)
+    print('substep duration ms pct[0,10,50,90,99,100]', q(a.astype(np.float64)), 'mean', round(float(a.mean() * clk), 3))
+    print('poststep duration ms', q(b.astype(np.float64)), 'mean', round(float(b.mean() * clk), 3))
