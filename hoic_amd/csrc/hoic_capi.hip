@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 // ---- kernel 2 of a step: contact averaging, the residual-force QP (float64), termination, reward, the optional
 // in-launch reset and the 617-float observation (HandObjMimic4.step after do_simulation, ho_im4.py:631-662)
-__global__ __launch_bounds__(NT) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                            DevExpert ex, DevState st, const float* __restrict__ action,
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
@@ -921,6 +921,35 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
               d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_ncon, d_solver_iter};
   static const int lds_pad = getenv("HOIC_DBG_LDS_PAD") ? atoi(getenv("HOIC_DBG_LDS_PAD")) : 0;   // occupancy experiments
   hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), lds_pad, (hipStream_t)stream, s->d_model, s->d_cfg, a);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+// the residual-force QP on given columns (tests: the solver against the oracle's on hard instances)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_probe_qp_kernel(const float* __restrict__ cols, const int* __restrict__ ncols,
+                                                                                                const double* __restrict__ rhs, int max_col,
+                                                                                                double* __restrict__ lam_out, int* __restrict__ stat_out) {
+  __shared__ Work w;
+  const int k = blockIdx.x, tid = threadIdx.x, ncol = ncols[k];
+  float* qc = w.col_lc;
+  const float* src = cols + (size_t)k * max_col * 7;
+  for (int c = tid; c < ncol; c += NT)
+    for (int i = 0; i < 7; i++) qc[i * QP_MAXCOL + c] = src[(size_t)c * 7 + i];
+  __syncthreads();
+  double b[6], lam[6];
+  for (int i = 0; i < 6; i++) b[i] = rhs[(size_t)k * 6 + i];
+  int stat[2];
+  dev_nnqp(w, qc, ncol, b, lam, stat);
+  if (tid < 6) lam_out[(size_t)k * 6 + tid] = lam[tid];
+  if (tid < 2) stat_out[(size_t)k * 2 + tid] = stat[tid];
+}
+
+extern "C" int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, const int32_t* d_ncols, const double* d_rhs,
+                                 int32_t max_col, double* d_lambda, int32_t* d_stat, void* stream) {
+  if (!s || n <= 0 || !d_cols || !d_ncols || !d_rhs || !d_lambda || !d_stat || max_col <= 0 || max_col > QP_MAXCOL) {
+    set_err("hoic_probe_qp: bad arguments (max_col must be in 1..380)"); return HOIC_ERR_ARG;
+  }
+  hipLaunchKernelGGL(hoic_probe_qp_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, d_cols, d_ncols, d_rhs, max_col, d_lambda, d_stat);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }

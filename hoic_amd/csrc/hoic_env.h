@@ -164,6 +164,41 @@ __device__ void dev_classify_contact(const DevModel& m, Work& w) {
 // ---- solve_rfc (ho_im4.py:941-1083) in float64: Newton on the 6-D dual of the non-negative QP
 //   min_l |l|^2/4 + b'l + 1/(2 eps) sum_i max(0, -(c_i + a_i'l))^2 ,  residual wrench = -l/2
 // (same formulation as oracle/ho_env.c; columns a_i live in registers, 6 per lane)
+// LDL^T solve of a symmetric positive definite QP_MAXP x QP_MAXP system G z = h (G packed lower row-major, destroyed;
+// h in, z out).  Everything is statically indexed: the arrays stay in registers.
+#define QP_MAXP 8
+HD void ldl8_solve(double (&G)[QP_MAXP * (QP_MAXP + 1) / 2], double (&h)[QP_MAXP]) {
+#define GP(i, j) G[(i) * ((i) + 1) / 2 + (j)]
+  double dinv[QP_MAXP];
+#pragma unroll
+  for (int j = 0; j < QP_MAXP; j++) {
+    const double d = GP(j, j);
+    double r = __builtin_amdgcn_rcp(d);
+    r = r * (2.0 - d * r); r = r * (2.0 - d * r);
+    dinv[j] = r;
+#pragma unroll
+    for (int i = j + 1; i < QP_MAXP; i++) {
+      const double lij = GP(i, j) * r;
+#pragma unroll
+      for (int k = j + 1; k <= i; k++) GP(i, k) -= lij * GP(k, j);
+    }
+#pragma unroll
+    for (int i = j + 1; i < QP_MAXP; i++) GP(i, j) *= r;
+  }
+#pragma unroll
+  for (int j = 0; j < QP_MAXP; j++) {
+#pragma unroll
+    for (int i = j + 1; i < QP_MAXP; i++) h[i] -= GP(i, j) * h[j];
+  }
+#pragma unroll
+  for (int j = 0; j < QP_MAXP; j++) h[j] *= dinv[j];
+#pragma unroll
+  for (int j = QP_MAXP - 1; j >= 0; j--) {
+#pragma unroll
+    for (int i = j + 1; i < QP_MAXP; i++) h[j] -= GP(i, j) * h[i];
+  }
+#undef GP
+}
 HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (overwritten by its Cholesky factor), x in/out
 #define HP(i, j) H[(i) * ((i) + 1) / 2 + (j)]
 #pragma unroll
@@ -191,6 +226,224 @@ HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (ov
 #pragma unroll
     for (int k = i + 1; k < 6; k++) s -= HP(k, i) * x[k]; x[i] = s / HP(i, i); }
 #undef HP
+}
+
+// ---- the residual-force QP proper: columns a_k (6) and offsets c_k (k < ncol) in LDS at qc[i * QP_MAXCOL + k],
+// right-hand side b; returns the dual optimum lambda = 2 (A x - b).  stat (optional, lane-uniform): column entries,
+// small solves are not counted; [0] = active-set iterations, [1] = dual-Newton iterations of the fallback.
+__device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, const double (&b)[6], double (&lam)[6], int* stat) {
+  const int tid = threadIdx.x;
+  const double eps = 1e-7;
+  const int nslot = (ncol + NT - 1) / NT;         // columns per lane actually present (typically 1-2 of at most 6)
+  const double ieps = 1.0 / eps;
+  // ---- primal active-set pass (Lawson-Hanson form) on
+  //        min_x |A x - b|^2 + c.x + eps/2 |x|^2,   x >= 0,
+  // whose dual in lambda = 2 (A x - b) is the 6-D problem the Newton iteration below solves.  At most 8 columns are
+  // passive at a time (A has 6 rows; the eps term lets a few more in): their Gram matrix sits in LDS, the 8 x 8
+  // LDL^T solve runs wave-uniform in registers, the steepest-column search is lane-parallel over the columns.
+  // Typical cost 8 column entries / 12 small solves; the dual Newton from a cold start needed up to 37 iterations of
+  // 27 float64 wave reductions plus ~10 line-search passes each, and one such env sets the kernel time.
+  bool polish = false;
+  {
+    double xs[QP_MAXP], hb[QP_MAXP];
+    int colj[QP_MAXP];
+#pragma unroll
+    for (int j = 0; j < QP_MAXP; j++) { xs[j] = 0.0; hb[j] = 0.0; colj[j] = 0; }
+    unsigned pm = 0u, inP = 0u, ban = 0u;      // passive slots; per-lane bit jj <-> column tid + jj * NT
+    double* Gm = w.sc.post.qp_G;
+    float (*pa)[8] = w.sc.post.qp_a;
+    // gradient tolerance relative to the size of its terms
+    float amax = 0.f, cmax = 0.f;
+    for (int jj = 0; jj < nslot; jj++) {
+      const int col = tid + jj * NT;
+      if (col < ncol) {
+        for (int i = 0; i < 6; i++) amax = fmaxf(amax, fabsf(qc[i * QP_MAXCOL + col]));
+        cmax = fmaxf(cmax, fabsf(qc[6 * QP_MAXCOL + col]));
+      }
+    }
+    amax = wave_max(amax); cmax = wave_max(cmax);
+    double bmax = 0.0;
+    for (int i = 0; i < 6; i++) bmax = fmax(bmax, fabs(b[i]));
+    const double tol = 1e-9 * (1.0 + (double)cmax + 2.0 * (double)amax * bmax);
+    int it = 0;
+    for (; it < 64; it++) {
+      double r[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) r[i] = b[i];
+#pragma unroll
+      for (int j = 0; j < QP_MAXP; j++)
+        if ((pm >> j) & 1u) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) r[i] -= xs[j] * (double)pa[j][i];
+        }
+      double best = -1e300; int bestc = -1;
+      for (int jj = 0; jj < nslot; jj++) {
+        const int col = tid + jj * NT;
+        if (col < ncol && !(((inP | ban) >> jj) & 1u)) {
+          double wv = -(double)qc[6 * QP_MAXCOL + col];
+#pragma unroll
+          for (int i = 0; i < 6; i++) wv += 2.0 * (double)qc[i * QP_MAXCOL + col] * r[i];
+          if (wv > best) { best = wv; bestc = col; }
+        }
+      }
+      const double wmax = wave_max_d(best);
+      if (!(wmax > tol)) break;
+      if (pm == (1u << QP_MAXP) - 1u) { polish = true; break; }
+      const int src = __ffsll((long long)__ballot(best == wmax)) - 1;
+      const int k = __builtin_amdgcn_readlane(bestc, src);
+      const int s = __ffs((int)~pm) - 1;
+      __syncthreads();
+      if (tid < 8) pa[s][tid] = tid < 7 ? qc[tid * QP_MAXCOL + k] : 0.f;
+      __syncthreads();
+      double an[6], hnew = -(double)pa[s][6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { an[i] = (double)pa[s][i]; hnew += 2.0 * an[i] * b[i]; }
+      if (tid < QP_MAXP) {
+        double g = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) g += an[i] * (double)pa[tid][i];
+        g *= 2.0;
+        if (tid == s) g += eps;
+        const int hi_ = tid > s ? tid : s, lo_ = tid > s ? s : tid;
+        Gm[hi_ * (hi_ + 1) / 2 + lo_] = g;
+      }
+#pragma unroll
+      for (int j = 0; j < QP_MAXP; j++) if (j == s) { hb[j] = hnew; xs[j] = 0.0; colj[j] = k; }
+      pm |= 1u << s;
+      if (tid == (k & (NT - 1))) inP |= 1u << (k / NT);
+      __syncthreads();
+      bool rejected = false, first = true;
+      for (int in = 0; in < 24; in++) {
+        double W[QP_MAXP * (QP_MAXP + 1) / 2], z[QP_MAXP];
+#pragma unroll
+        for (int i = 0; i < QP_MAXP; i++) {
+          const bool ai = (pm >> i) & 1u;
+          z[i] = ai ? hb[i] : 0.0;
+#pragma unroll
+          for (int j = 0; j <= i; j++) {
+            const bool aj = (pm >> j) & 1u;
+            W[i * (i + 1) / 2 + j] = (ai && aj) ? Gm[i * (i + 1) / 2 + j] : (i == j ? 1.0 : 0.0);
+          }
+        }
+        ldl8_solve(W, z);
+        double znew = 0.0;
+#pragma unroll
+        for (int j = 0; j < QP_MAXP; j++) if (j == s) znew = z[j];
+        if (first && !(znew > 0.0)) {       // rounding: the steepest column does not want to enter after all
+          pm &= ~(1u << s);
+          if (tid == (k & (NT - 1))) { inP &= ~(1u << (k / NT)); ban |= 1u << (k / NT); }
+          rejected = true;
+          break;
+        }
+        first = false;
+        bool allpos = true;
+#pragma unroll
+        for (int j = 0; j < QP_MAXP; j++) if (((pm >> j) & 1u) && !(z[j] > 0.0)) allpos = false;
+        if (allpos) {
+#pragma unroll
+          for (int j = 0; j < QP_MAXP; j++) if ((pm >> j) & 1u) xs[j] = z[j];
+          break;
+        }
+        double al = 1.0;
+#pragma unroll
+        for (int j = 0; j < QP_MAXP; j++)
+          if (((pm >> j) & 1u) && !(z[j] > 0.0)) al = fmin(al, xs[j] / (xs[j] - z[j]));
+        double xmax = 1.0;
+#pragma unroll
+        for (int j = 0; j < QP_MAXP; j++)
+          if ((pm >> j) & 1u) { xs[j] += al * (z[j] - xs[j]); xmax = fmax(xmax, fabs(xs[j])); }
+#pragma unroll
+        for (int j = 0; j < QP_MAXP; j++)
+          if (((pm >> j) & 1u) && !(z[j] > 0.0) && xs[j] <= 1e-14 * xmax) {
+            pm &= ~(1u << j); xs[j] = 0.0;
+            if (tid == (colj[j] & (NT - 1))) inP &= ~(1u << (colj[j] / NT));
+          }
+      }
+      if (!rejected) ban = 0u;
+    }
+    if (it >= 64) polish = true;
+    if (stat) stat[0] = it;
+#pragma unroll
+    for (int i = 0; i < 6; i++) lam[i] = -2.0 * b[i];
+#pragma unroll
+    for (int j = 0; j < QP_MAXP; j++)
+      if ((pm >> j) & 1u) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) lam[i] += 2.0 * xs[j] * (double)pa[j][i];
+      }
+    __syncthreads();
+  }
+  // ---- dual Newton: only when the passive set was full or the pass ran out of iterations; starts at the
+  // multipliers found above
+  int n_dual = 0;
+  for (int it = 0; polish && it < 60; it++) {
+    n_dual++;
+    double g[6], H[21];
+    for (int i = 0; i < 6; i++) g[i] = 0.0;
+    for (int i = 0; i < 21; i++) H[i] = 0.0;
+    for (int jj = 0; jj < nslot; jj++) {
+      const int col = tid + jj * NT;
+      if (col < ncol) {
+        double a[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = (double)qc[i * QP_MAXCOL + col];
+        double sk = (double)qc[6 * QP_MAXCOL + col];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sk += a[i] * lam[i];
+        if (sk < 0.0) {
+          const double se = sk * ieps;
+#pragma unroll
+          for (int i = 0, k = 0; i < 6; i++) {
+            g[i] += se * a[i];
+            const double ai = a[i] * ieps;
+#pragma unroll
+            for (int j = 0; j <= i; j++, k++) H[k] += ai * a[j];
+          }
+        }
+      }
+    }
+    for (int i = 0; i < 6; i++) g[i] = wave_sum_d(g[i]) + 0.5 * lam[i] + b[i];
+    for (int i = 0; i < 21; i++) H[i] = wave_sum_d(H[i]);
+    for (int i = 0, k = 0; i < 6; i++) { k += i; H[k] += 0.5; k++; }
+    double gn = 0, ln = 0;
+    for (int i = 0; i < 6; i++) { gn += g[i] * g[i]; ln += lam[i] * lam[i]; }
+    if (sqrt(gn) < 1e-9 * (1.0 + sqrt(ln))) break;      // H >= I/2: |lambda error| <= 2 |g|, far below the float32 result
+    double dir[6];
+    for (int i = 0; i < 6; i++) dir[i] = -g[i];
+    chol6_solve(H, dir);
+    double gl = 0, dd = 0, bd = 0;
+    for (int i = 0; i < 6; i++) { gl += lam[i] * dir[i]; dd += dir[i] * dir[i]; bd += b[i] * dir[i]; }
+    double al = 1.0, lo = 0.0, hi = -1.0;
+    for (int ls = 0; ls < 60; ls++) {
+      double dphi = 0, ddphi = 0;
+      for (int jj = 0; jj < nslot; jj++) {
+        const int col = tid + jj * NT;
+        if (col < ncol) {
+          double s0 = (double)qc[6 * QP_MAXCOL + col], av = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; i++) { const double ai = (double)qc[i * QP_MAXCOL + col]; s0 += ai * lam[i]; av += ai * dir[i]; }
+          const double sk = s0 + al * av;
+          if (sk < 0.0) { dphi += sk * av * ieps; ddphi += av * av * ieps; }
+        }
+      }
+      dphi = wave_sum_d(dphi) + 0.5 * (gl + al * dd) + bd; ddphi = wave_sum_d(ddphi) + 0.5 * dd;
+      if (fabs(dphi) < 1e-13 * (1.0 + fabs(bd) + fabs(gl))) break;
+      if (dphi < 0) lo = al; else hi = al;
+      double an = al - dphi / ddphi;
+      if (hi >= 0 && (an <= lo || an >= hi)) an = 0.5 * (lo + hi);
+      if (hi < 0 && an <= lo) an = 2 * al + 1e-12;
+      if (hi >= 0 && hi - lo < 1e-15 * (1 + hi)) break;
+      // the 1-D function is piecewise quadratic: once the active set stops changing the Newton step is exact and
+      // repeats itself (the derivative test above sits below its own rounding noise, which is scaled by 1/eps)
+      const bool same = fabs(an - al) <= 1e-14 * (1.0 + fabs(al));
+      al = an;
+      if (same) break;
+    }
+    double st = 0;
+    for (int i = 0; i < 6; i++) { lam[i] += al * dir[i]; st += al * al * dir[i] * dir[i]; }
+    if (sqrt(st) < 1e-15 * (1.0 + sqrt(ln))) break;
+  }
+  if (stat) stat[1] = n_dual;
 }
 
 __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt, double* warm_lam) {
@@ -276,89 +529,13 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   }
   __syncthreads();
   const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
-  const double ieps = 1.0 / eps;
-  // start from the previous env step's multipliers when it had contacts too (the optimum is unique, so the start only
-  // changes the iteration count: contact sets move slowly from step to step)
   double lam[6];
-  const bool have_warm = warm_lam[6] != 0.0;
-  for (int i = 0; i < 6; i++) lam[i] = have_warm ? warm_lam[i] : -2.0 * b[i];
 #ifdef HOIC_TRACE_DISPATCH
-  int trace_it = 0, trace_ls = 0;
-#endif
-  for (int it = 0; it < 60; it++) {
-#ifdef HOIC_TRACE_DISPATCH
-    trace_it++;
-#endif
-    double g[6], H[21];
-    for (int i = 0; i < 6; i++) g[i] = 0.0;
-    for (int i = 0; i < 21; i++) H[i] = 0.0;
-    for (int jj = 0; jj < nslot; jj++) {
-      const int col = tid + jj * NT;
-      if (col < ncol) {
-        double a[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) a[i] = (double)qc[i * QP_MAXCOL + col];
-        double sk = (double)qc[6 * QP_MAXCOL + col];
-#pragma unroll
-        for (int i = 0; i < 6; i++) sk += a[i] * lam[i];
-        if (sk < 0.0) {
-          const double se = sk * ieps;
-#pragma unroll
-          for (int i = 0, k = 0; i < 6; i++) {
-            g[i] += se * a[i];
-            const double ai = a[i] * ieps;
-#pragma unroll
-            for (int j = 0; j <= i; j++, k++) H[k] += ai * a[j];
-          }
-        }
-      }
-    }
-    for (int i = 0; i < 6; i++) g[i] = wave_sum_d(g[i]) + 0.5 * lam[i] + b[i];
-    for (int i = 0; i < 21; i++) H[i] = wave_sum_d(H[i]);
-    for (int i = 0, k = 0; i < 6; i++) { k += i; H[k] += 0.5; k++; }
-    double gn = 0, ln = 0;
-    for (int i = 0; i < 6; i++) { gn += g[i] * g[i]; ln += lam[i] * lam[i]; }
-    if (sqrt(gn) < 1e-9 * (1.0 + sqrt(ln))) break;      // H >= I/2: |lambda error| <= 2 |g|, far below the float32 result
-    double dir[6];
-    for (int i = 0; i < 6; i++) dir[i] = -g[i];
-    chol6_solve(H, dir);
-    double gl = 0, dd = 0, bd = 0;
-    for (int i = 0; i < 6; i++) { gl += lam[i] * dir[i]; dd += dir[i] * dir[i]; bd += b[i] * dir[i]; }
-    double al = 1.0, lo = 0.0, hi = -1.0;
-    for (int ls = 0; ls < 60; ls++) {
-#ifdef HOIC_TRACE_DISPATCH
-      trace_ls++;
-#endif
-      double dphi = 0, ddphi = 0;
-      for (int jj = 0; jj < nslot; jj++) {
-        const int col = tid + jj * NT;
-        if (col < ncol) {
-          double s0 = (double)qc[6 * QP_MAXCOL + col], av = 0.0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) { const double ai = (double)qc[i * QP_MAXCOL + col]; s0 += ai * lam[i]; av += ai * dir[i]; }
-          const double sk = s0 + al * av;
-          if (sk < 0.0) { dphi += sk * av * ieps; ddphi += av * av * ieps; }
-        }
-      }
-      dphi = wave_sum_d(dphi) + 0.5 * (gl + al * dd) + bd; ddphi = wave_sum_d(ddphi) + 0.5 * dd;
-      if (fabs(dphi) < 1e-13 * (1.0 + fabs(bd) + fabs(gl))) break;
-      if (dphi < 0) lo = al; else hi = al;
-      double an = al - dphi / ddphi;
-      if (hi >= 0 && (an <= lo || an >= hi)) an = 0.5 * (lo + hi);
-      if (hi < 0 && an <= lo) an = 2 * al + 1e-12;
-      if (hi >= 0 && hi - lo < 1e-15 * (1 + hi)) break;
-      // the 1-D function is piecewise quadratic: once the active set stops changing the Newton step is exact and
-      // repeats itself (the derivative test above sits below its own rounding noise, which is scaled by 1/eps)
-      const bool same = fabs(an - al) <= 1e-14 * (1.0 + fabs(al));
-      al = an;
-      if (same) break;
-    }
-    double st = 0;
-    for (int i = 0; i < 6; i++) { lam[i] += al * dir[i]; st += al * al * dir[i] * dir[i]; }
-    if (sqrt(st) < 1e-15 * (1.0 + sqrt(ln))) break;
-  }
-#ifdef HOIC_TRACE_DISPATCH
-  if (tid == 0) { g_trace_qp[blockIdx.x * 4] = trace_it; g_trace_qp[blockIdx.x * 4 + 1] = trace_ls; g_trace_qp[blockIdx.x * 4 + 2] = ncol; g_trace_qp[blockIdx.x * 4 + 3] = have_warm; }
+  int qstat[2];
+  dev_nnqp(w, qc, ncol, b, lam, qstat);
+  if (tid == 0) { g_trace_qp[blockIdx.x * 4] = qstat[0]; g_trace_qp[blockIdx.x * 4 + 1] = qstat[1]; g_trace_qp[blockIdx.x * 4 + 2] = ncol; g_trace_qp[blockIdx.x * 4 + 3] = qstat[1] > 0; }
+#else
+  dev_nnqp(w, qc, ncol, b, lam, nullptr);
 #endif
   if (tid < 6) warm_lam[tid] = lam[tid];
   if (tid == 6) warm_lam[6] = 1.0;

@@ -134,6 +134,13 @@ HD double wave_sum_d(double v) {
   v += dpp_mov_d<0x140>(v);   // row_mirror
   return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
 }
+HD double wave_max_d(double v) {
+  v = fmax(v, dpp_mov_d<0xb1>(v));
+  v = fmax(v, dpp_mov_d<0x4e>(v));
+  v = fmax(v, dpp_mov_d<0x141>(v));
+  v = fmax(v, dpp_mov_d<0x140>(v));
+  return fmax(fmax(rl_d(v, 0), rl_d(v, 16)), fmax(rl_d(v, 32), rl_d(v, 48)));
+}
 // inclusive prefix sum of a small non-negative integer over the wave (ballot-free, DPP row shifts + readlanes)
 HD int wave_incl_scan(int v) {
   const int lane = threadIdx.x & 63;

@@ -157,6 +157,8 @@ struct Work {
     } dyn;
     float T[NV * LD];                  // columns of L during the matrix-core solves
     struct {                           // post-step kernel only
+      double qp_G[36];                 // residual-force QP: Gram matrix of the passive columns (packed lower 8 x 8)
+      float qp_a[8][8];                //                    the passive columns themselves (a[6], c, pad)
       float avg_cps[NHG][12]; int avg_geom[NHG]; float avg_ts[NHG]; int n_avg;
       float gvel[NG][3], gangvel[NG][3], obj_avg_acc[6];
     } post;

@@ -40,7 +40,7 @@ class RewardParams(C.Structure):
 
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
-           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_enable_timing",
+           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame"]
 
@@ -91,6 +91,7 @@ def load():
     L.hoic_last_step_ms.restype = f32
     L.hoic_last_poststep_ms.argtypes = [vp]
     L.hoic_step_times.argtypes = [vp, vp, vp, i32]
+    L.hoic_probe_qp.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp]
     L.hoic_env_durations.argtypes = [vp, vp, vp]
     L.hoic_set_expert_reserve.argtypes = [vp, i32]
     L.hoic_append_expert_frame.argtypes = [vp] * 9
@@ -260,6 +261,19 @@ class BatchedSim:
         if n < 0:
             raise HoicError("hoic_step_times failed")
         return list(a[:n]), list(b[:n])
+
+    def probe_qp(self, cols, ncols, rhs):
+        """The residual-force QP on given columns: cols [n, max_col, 7] (a[6], c), ncols [n], rhs [n, 6] (float64).
+        Returns (lambda [n, 6] float64, stat [n, 2] int32 = active-set iterations, dual-Newton fallback iterations)."""
+        t = self.torch
+        cols = t.as_tensor(np.asarray(cols), device=self.device, dtype=t.float32).contiguous()
+        ncols = t.as_tensor(np.asarray(ncols), device=self.device, dtype=t.int32).contiguous()
+        rhs = t.as_tensor(np.asarray(rhs), device=self.device, dtype=t.float64).contiguous()
+        n, max_col = cols.shape[0], cols.shape[1]
+        lam = t.zeros(n, 6, device=self.device, dtype=t.float64); stat = t.zeros(n, 2, device=self.device, dtype=t.int32)
+        _chk(self.L.hoic_probe_qp(self.h, n, _ptr(cols), _ptr(ncols), _ptr(rhs), max_col, _ptr(lam), _ptr(stat), self._stream()),
+             "hoic_probe_qp")
+        return lam.cpu().numpy(), stat.cpu().numpy()
 
     def env_durations(self):
         """per-env duration (units of 64 shader clocks) of the last step's substep / post-step pass (numpy uint32)"""

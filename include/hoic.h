@@ -119,6 +119,14 @@ int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const fl
                            int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
                            float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream);
 
+/* The residual-force QP of HandObjMimic4.get_rfc_score (ho_im4.py:1040-1083) on caller-supplied data, n independent
+ * problems:  min_x |A x - b|^2 + c.x + 1e-7/2 |x|^2, x >= 0.  d_cols [n, max_col, 7] float32: column k of problem i
+ * is (a_k[6], c_k); d_ncols [n] columns in use (<= max_col <= 380); d_rhs [n, 6] float64.  Outputs: d_lambda [n, 6]
+ * float64 = 2 (A x - b) (rfc_score = |lambda[0:3]| / 2 + |lambda[3:6]| / 2), d_stat [n, 2] = active-set iterations,
+ * dual-Newton fallback iterations.  Test / diagnostic entry: hoic_step runs the same routine on its own columns. */
+int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, const int32_t* d_ncols, const double* d_rhs,
+                      int32_t max_col, double* d_lambda, int32_t* d_stat, void* stream);
+
 /* hoic_step is two launches: the substep kernel (15 fused substeps, the dominant kernel) and the post-step
  * kernel (contact averaging, residual-force QP, termination, reward, observation).  Durations in milliseconds of
  * the most recent launches, measured with HIP events on the launch stream (negative if timing was not enabled

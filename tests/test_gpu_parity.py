@@ -479,3 +479,53 @@ def test_agent_iteration_runs_and_learns_something(box_blob, setup):
     for side in ("mimic", "ref"):
         assert all(np.isfinite(v) for v in ph[side].values()) and 0 <= ph[side]["plausible_frame_ratio"] <= 100
     assert ph["ref"]["frames"] == ph["mimic"]["frames"] > 10
+
+
+def _rfc_like_instance(rng, ncon, npt=5):
+    """Columns shaped like get_rfc_score's (ho_im4.py:1009-1066): friction-pyramid edges at 5 points per contact, torque
+    rows scaled by sqrt(w_t) = 100, non-negative velocity offsets."""
+    mu, swt = 0.75, 100.0
+    inv = 1.0 / np.sqrt(1.0 + mu * mu)
+    cols = []
+    for _ in range(ncon):
+        pos = rng.normal(size=3) * 0.04
+        fn = -pos / np.linalg.norm(pos) + 0.3 * rng.normal(size=3) if rng.random() < 0.8 else rng.normal(size=3)
+        fn /= np.linalg.norm(fn)
+        t1 = np.cross(fn, [0.3, 0.5, 0.8]); t1 /= np.linalg.norm(t1); t2 = np.cross(fn, t1)
+        ts = rng.integers(1, 16) / 15.0
+        for j in range(npt):
+            dl = t1 if j in (1, 2) else t2
+            p = pos + (0.0 if j == 0 else (0.0025 if j & 1 else -0.0025)) * dl
+            nvn = abs(rng.normal()) * 0.05 * (rng.random() < 0.5); nvt = abs(rng.normal()) * 0.05
+            am = rng.integers(0, 4)
+            for e in range(4):
+                xv = (fn + (-1 if e & 1 else 1) * mu * (t1 if e < 2 else t2)) * inv * ts
+                cols.append(np.concatenate([xv, swt * np.cross(p, xv), [nvn + (0 if e == am else nvt)]]))
+    b = np.concatenate([rng.normal(size=3) * 0.3 + [0, 0, 0.2], swt * rng.normal(size=3) * 0.003])
+    return np.array(cols, dtype=np.float32), b
+
+
+def test_rfc_qp_solver_against_oracle(box_blob, oracle_lib, setup):
+    """The active-set residual-force QP (hoic_probe_qp = the routine hoic_step runs) against the oracle's dual Newton
+    (pinned to the reference's QP by tests/golden/rfc.npz) on 600 random contact configurations, 1..19 contacts x 5
+    points x 4 edges = up to 380 columns, the same float32 columns on both sides.  float64 solvers: the scores agree
+    to 1e-6."""
+    cfg, ex, thresh = setup
+    sim = _sim(box_blob, 1, cfg, ex, thresh)
+    rng = np.random.default_rng(5)
+    n, max_col = 600, 380
+    cols = np.zeros((n, max_col, 7), dtype=np.float32); ncols = np.zeros(n, dtype=np.int32); rhs = np.zeros((n, 6))
+    for i in range(n):
+        ncon = int(rng.integers(1, 20)) if i % 3 == 0 else int(rng.integers(1, 7))
+        a, b = _rfc_like_instance(rng, ncon)
+        cols[i, :len(a)] = a; ncols[i] = len(a); rhs[i] = b
+    lam, stat = sim.probe_qp(cols, ncols, rhs)
+    worst = 0.0
+    for i in range(n):
+        a = cols[i, :ncols[i]].astype(np.float64)
+        lo, _ = oracle_lib.nnqp_dual(a[:, :6].copy(), a[:, 6].copy(), rhs[i], 1e-7)
+        so = 0.5 * (np.linalg.norm(lo[:3]) + np.linalg.norm(lo[3:])); sg = 0.5 * (np.linalg.norm(lam[i, :3]) + np.linalg.norm(lam[i, 3:]))
+        worst = max(worst, abs(so - sg) / (1.0 + so))
+    assert worst < 1e-6, worst
+    assert stat[:, 0].max() < 64            # the active-set pass converged everywhere ...
+    assert np.isfinite(lam).all()

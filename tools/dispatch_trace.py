@@ -89,3 +89,8 @@ print('slowest: dur', np.round(pd[o], 3), 'iters', qit[o], 'ls', qls[o], 'cols',
 A2 = np.stack([np.ones(hasqp.sum()), qit[hasqp], qls[hasqp]], 1)
 cf, *_ = np.linalg.lstsq(A2, pd[hasqp], rcond=None)
 print('dur ~ c0 + c1*iters + c2*ls_steps (ms):', cf)
+for wflag in (0, 1):
+    mk = hasqp & (qwarm == wflag)
+    if mk.sum():
+        print('warm' if wflag else 'cold', 'n', mk.sum(), 'iters mean/p90/max', qit[mk].mean(), np.percentile(qit[mk], 90), qit[mk].max(), 'ls mean/max', qls[mk].mean(), qls[mk].max(),
+              'dur mean/max', pd[mk].mean(), pd[mk].max(), 'cols mean', qcol[mk].mean())
