@@ -17,6 +17,7 @@ every env) with a value bootstrap at the cut instead of whole episodes; float32 
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import pickle
@@ -135,8 +136,11 @@ class PPOLearner:
 class AgentHandMimic:
     def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
-                 strict_reference=True, solver_iterations=8):
+                 strict_reference=True, solver_iterations=8, n_groups=None):
         self.cfg = self.cc_cfg = cfg
+        # rollout pipelining: 2 half-batches once a half still fills the GPU's 2048 wavefront slots
+        self.n_groups = int(n_groups) if n_groups is not None else (2 if n_envs >= 4096 and n_envs % 2 == 0 else 1)
+        self._streams = None
         self.dtype = dtype
         self.training = training
         self.distributed = distributed
@@ -175,6 +179,14 @@ class AgentHandMimic:
             self.load_checkpoint(checkpoint_epoch)
             self.epoch = checkpoint_epoch
 
+    def _groups(self):
+        """env ranges stepped independently during the rollout ((first, count) pairs)"""
+        G = self.n_groups if (self.device.type == "cuda" and self.n_envs % max(self.n_groups, 1) == 0) else 1
+        if G > 1 and self._streams is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(G)]
+        c = self.n_envs // G
+        return [(g * c, c) for g in range(G)]
+
     # ------------------------------------------------------------------ episode draws (:444-448)
     def _draw_episodes(self, n):
         hi = max(self.seq_num - 1, 1)                        # never the last (held-out) sequence
@@ -202,16 +214,45 @@ class AgentHandMimic:
             seq, start = self._draw_episodes(N)
             self._obs = self.env.reset(seq, start)
         obs = self._obs
+        # The batch is stepped as n_groups independent env ranges, each on its own stream: the physics launch of one
+        # range ends with a tail of a few long-running envs (contacts), during which the GPU runs the other range's
+        # policy forward and physics.  The reference's sampler is asynchronous in the same way (one worker per
+        # thread, each with its own env).  The running observation filter is shared: its updates are chained
+        # range after range with events, so every state is normalised with the statistics of all earlier ranges.
+        groups = self._groups()
+        G = len(groups)
+        use_streams = G > 1
+        c_info_g = [torch.zeros(9, device=dev, dtype=torch.float64) for _ in range(G)]
+        n_done_g = [torch.zeros((), device=dev, dtype=torch.float64) for _ in range(G)]
+        if use_streams:
+            main = torch.cuda.current_stream(dev)
+            for st_ in self._streams:
+                st_.wait_stream(main)
+        zf_event = None
         for t in range(T):
-            state = self.running_state(obs)
-            action = self.policy_net.select_action(state)
-            nseq, nstart = self._draw_episodes(N)
-            obs, _, done, info = self.env.step(action, nseq, nstart)
-            states[t] = state; actions[t] = action
-            rewards[t] = self.env.c_reward
-            masks[t] = (~done).to(dt)
-            c_info += self.env.c_info.sum(0, dtype=torch.float64)
-            n_done += done.sum()
+            for gi, (first, count) in enumerate(groups):
+                sl = slice(first, first + count)
+                ctx = torch.cuda.stream(self._streams[gi]) if use_streams else contextlib.nullcontext()
+                with ctx:
+                    if use_streams and zf_event is not None:
+                        self._streams[gi].wait_event(zf_event)
+                    state = self.running_state(obs[sl])
+                    if use_streams:
+                        zf_event = torch.cuda.Event(); zf_event.record(self._streams[gi])
+                    action = self.policy_net.select_action(state)
+                    nseq, nstart = self._draw_episodes(count)
+                    _, _, done, info = self.env.step(action, nseq, nstart, first, count)
+                    states[t, sl] = state; actions[t, sl] = action
+                    rewards[t, sl] = self.env.c_reward
+                    masks[t, sl] = (~done).to(dt)
+                    c_info_g[gi] += self.env.c_info.sum(0, dtype=torch.float64)
+                    n_done_g[gi] += done.sum()
+        if use_streams:
+            for st_ in self._streams:
+                main.wait_stream(st_)
+        obs = self.env.get_obs()
+        for gi in range(G):
+            c_info += c_info_g[gi]; n_done += n_done_g[gi]
         self._obs = obs
         next_state = self.running_state(obs, update=False)
         next_values = self.value_net(next_state).squeeze(1)

@@ -115,11 +115,12 @@ __device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
 // differences) for the post-step kernel.
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                           const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
-                                                          const float* __restrict__ action) {
+                                                          const float* __restrict__ action, int first, int use_order) {
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
-  const int env = st.order[blockIdx.x], tid = threadIdx.x;
+  // workgroup b runs env first + b (I/O row b), or env order[b] of a whole-batch step in longest-first order
+  const int env = use_order ? st.order[blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
 #ifdef HOIC_TRACE_DISPATCH
   const long long trace_t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
   __syncthreads();
 #endif
-  if (tid < NV) w.action[tid] = fminf(fmaxf(action[(size_t)env * HOIC_ACT_DIM + tid], -1.f), 1.f);   // ho_im4.py:613
+  if (tid < NV) w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);   // ho_im4.py:613
   __syncthreads();
   const int seq = st.seq[env];
   ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], st.start[env], st.cur_t[env]};
@@ -259,11 +260,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
                                                            float* __restrict__ percent, const int* __restrict__ next_seq,
-                                                           const int* __restrict__ next_start) {
+                                                           const int* __restrict__ next_start, int first, int use_order, int n_envs) {
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
-  const int n_envs = gridDim.x;
-  const int env = st.order[n_envs + blockIdx.x], tid = threadIdx.x;
+  const int env = use_order ? st.order[n_envs + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
 #ifdef HOIC_TRACE_DISPATCH
   if (tid == 0) for (int i = 0; i < 4; i++) g_trace_qp[blockIdx.x * 4 + i] = 0;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (tid < NQP) w.qpos[tid] = st.qpos[(size_t)env * NQP + tid];
   if (tid < NV) {
     w.qvel[tid] = st.qvel[(size_t)env * NV + tid];
-    w.action[tid] = fminf(fmaxf(action[(size_t)env * HOIC_ACT_DIM + tid], -1.f), 1.f);
+    w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);
   }
   for (int k = tid; k < m.nbody * 3; k += NT) w.xpos[k / 3][k % 3] = post[PB_XPOS + k];
   for (int k = tid; k < m.nbody * 4; k += NT) w.xquat[k / 4][k % 4] = post[PB_XQUAT + k];
@@ -313,14 +313,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float r = rw[0];
   if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                     // agent_handmimic.py:479-480
   if (tid == 0) {
-    reward[env] = r;
-    flags[4 * env] = fail; flags[4 * env + 1] = end; flags[4 * env + 2] = done; flags[4 * env + 3] = solver_iter;
-    percent[env] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
+    reward[io] = r;
+    flags[4 * io] = fail; flags[4 * io + 1] = end; flags[4 * io + 2] = done; flags[4 * io + 3] = solver_iter;
+    percent[io] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
     st.rfc_score[env] = rfc_score;
   }
-  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)env * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
+  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
   if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
-    const int ns = next_seq[env], nst = next_start[env];
+    const int ns = next_seq[io], nst = next_start[io];
     __syncthreads();
     dev_reset_state(m, w, ex, ns, nst);
     dev_kinematics(m, w, w.qpos);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
     store_state(st, w, env);
   }
-  dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
+  dev_write_obs(m, w, ev, obs + (size_t)io * HOIC_OBS_DIM);
   if (tid == 0) {
     st.cur_t[env] = ev.cur_t;
     st.cost[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
@@ -874,23 +874,38 @@ extern "C" int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, 
   return HOIC_OK;
 }
 
-extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, float* d_reward, float* d_reward_info,
-                             int32_t* d_flags, float* d_percent, const int32_t* d_next_seq, const int32_t* d_next_start,
-                             void* stream) {
-  if (!s || !d_action || !d_obs || !d_reward || !d_reward_info || !d_flags || !d_percent) { set_err("hoic_step: null pointer"); return HOIC_ERR_ARG; }
-  if ((d_next_seq == nullptr) != (d_next_start == nullptr)) { set_err("hoic_step: next_seq/next_start must come together"); return HOIC_ERR_ARG; }
-  if (!s->has_expert) { set_err("hoic_step: set_expert has not been called"); return HOIC_ERR_STATE; }
+static int32_t step_range(hoic_sim* s, int first, int count, const float* d_action, float* d_obs, float* d_reward, float* d_reward_info,
+                          int32_t* d_flags, float* d_percent, const int32_t* d_next_seq, const int32_t* d_next_start, void* stream,
+                          const char* who) {
+  if (!s || !d_action || !d_obs || !d_reward || !d_reward_info || !d_flags || !d_percent) { set_err(std::string(who) + ": null pointer"); return HOIC_ERR_ARG; }
+  if ((d_next_seq == nullptr) != (d_next_start == nullptr)) { set_err(std::string(who) + ": next_seq/next_start must come together"); return HOIC_ERR_ARG; }
+  if (first < 0 || count <= 0 || first + count > s->n_envs) { set_err(std::string(who) + ": env range outside [0, n_envs)"); return HOIC_ERR_ARG; }
+  if (!s->has_expert) { set_err(std::string(who) + ": set_expert has not been called"); return HOIC_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t* e = s->timing ? s->ev[s->n_timed % hoic_sim::NEV] : nullptr;
-  if (s->reorder) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
+  const int use_order = s->reorder && first == 0 && count == s->n_envs;
+  if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
   if (e) hipEventRecord(e[0], st);
-  hipLaunchKernelGGL(hoic_substep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action);
+  hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order);
   if (e) hipEventRecord(e[1], st);
-  hipLaunchKernelGGL(hoic_poststep_kernel, dim3(s->n_envs), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start);
+  hipLaunchKernelGGL(hoic_poststep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs);
   if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());
   return HOIC_OK;
+}
+
+extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, float* d_reward, float* d_reward_info,
+                             int32_t* d_flags, float* d_percent, const int32_t* d_next_seq, const int32_t* d_next_start,
+                             void* stream) {
+  if (!s) { set_err("hoic_step: null handle"); return HOIC_ERR_ARG; }
+  return step_range(s, 0, s->n_envs, d_action, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, stream, "hoic_step");
+}
+
+extern "C" int32_t hoic_step_range(hoic_sim* s, int32_t first, int32_t count, const float* d_action, float* d_obs, float* d_reward,
+                                   float* d_reward_info, int32_t* d_flags, float* d_percent, const int32_t* d_next_seq,
+                                   const int32_t* d_next_start, void* stream) {
+  return step_range(s, first, count, d_action, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, stream, "hoic_step_range");
 }
 
 extern "C" int32_t hoic_get_state(hoic_sim* s, float* d_qpos, float* d_qvel, int32_t* d_cur_t, void* stream) {

@@ -39,7 +39,7 @@ class RewardParams(C.Structure):
 
 
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
-           "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step",
+           "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame"]
@@ -91,6 +91,7 @@ def load():
     L.hoic_last_step_ms.restype = f32
     L.hoic_last_poststep_ms.argtypes = [vp]
     L.hoic_step_times.argtypes = [vp, vp, vp, i32]
+    L.hoic_step_range.argtypes = [vp, i32, i32] + [vp] * 9
     L.hoic_probe_qp.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp]
     L.hoic_env_durations.argtypes = [vp, vp, vp]
     L.hoic_set_expert_reserve.argtypes = [vp, i32]
@@ -214,17 +215,26 @@ class BatchedSim:
         _chk(self.L.hoic_reset(self.h, _ptr(ids), n, _ptr(seq), _ptr(start), _ptr(self.obs), self._stream()), "hoic_reset")
         return self.obs
 
-    def step(self, action, next_seq=None, next_start=None):
+    def step(self, action, next_seq=None, next_start=None, first=0, count=None):
+        """One env step of all envs, or of the envs [first, first + count) (``action`` / ``next_*`` then hold ``count``
+        rows and the returned tensors are the matching row views); launched on the current torch stream."""
         t = self.torch
+        count = self.n - first if count is None else int(count)
         a = action.to(device=self.device, dtype=t.float32).contiguous()
-        assert a.shape == (self.n, ACT_DIM)
+        assert a.shape == (count, ACT_DIM)
         if next_seq is not None:
             next_seq = next_seq.to(device=self.device, dtype=t.int32).contiguous()
             next_start = next_start.to(device=self.device, dtype=t.int32).contiguous()
-        _chk(self.L.hoic_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.reward), _ptr(self.reward_info),
-                              _ptr(self.flags), _ptr(self.percent), _ptr(next_seq), _ptr(next_start), self._stream()),
-             "hoic_step")
-        return self.obs, self.reward, self.reward_info, self.flags, self.percent
+            assert next_seq.shape == (count,) and next_start.shape == (count,)
+        sl = slice(first, first + count)
+        out = (self.obs[sl], self.reward[sl], self.reward_info[sl], self.flags[sl], self.percent[sl])
+        if first == 0 and count == self.n:
+            _chk(self.L.hoic_step(self.h, _ptr(a), *[_ptr(x) for x in out], _ptr(next_seq), _ptr(next_start), self._stream()),
+                 "hoic_step")
+        else:
+            _chk(self.L.hoic_step_range(self.h, int(first), count, _ptr(a), *[_ptr(x) for x in out], _ptr(next_seq),
+                                        _ptr(next_start), self._stream()), "hoic_step_range")
+        return out
 
     def get_state(self):
         t = self.torch

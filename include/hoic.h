@@ -99,6 +99,14 @@ int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, const int32
 int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, float* d_reward, float* d_reward_info,
                   int32_t* d_flags, float* d_percent, const int32_t* d_next_seq, const int32_t* d_next_start,
                   void* stream);
+/* The same env step for the envs [first, first + count) only; every device array holds `count` rows, row b belongs to
+ * env first + b.  Ranges are independent: stepping disjoint ranges on different streams lets the tail of one range's
+ * launch (few long-running envs) overlap the other range's work; the host mirror's rollout pipelines two half-batches
+ * this way (hoic_amd/agent.py).  State, outputs and results are identical to hoic_step on the whole batch. */
+int32_t hoic_step_range(hoic_sim* s, int32_t first, int32_t count, const float* d_action, float* d_obs, float* d_reward,
+                        float* d_reward_info, int32_t* d_flags, float* d_percent, const int32_t* d_next_seq,
+                        const int32_t* d_next_start, void* stream);
+
 
 /* ---- state access: MjSim.get_state / set_state (mujoco_env.py:109-113) and the data.* reads of the env.
  * d_qpos [n_envs,33], d_qvel [n_envs,32]; set_state also clears warm start and makes lagged == current. */

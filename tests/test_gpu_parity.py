@@ -529,3 +529,32 @@ def test_rfc_qp_solver_against_oracle(box_blob, oracle_lib, setup):
     assert worst < 1e-6, worst
     assert stat[:, 0].max() < 64            # the active-set pass converged everywhere ...
     assert np.isfinite(lam).all()
+
+
+def test_step_range_matches_whole_batch(box_blob, setup):
+    """hoic_step_range on two env ranges launched on two streams = hoic_step on the whole batch, bit for bit (the
+    rollout pipelines half-batches this way), including the in-launch resets."""
+    cfg, ex, thresh = setup
+    N = 256
+    a_sim = _sim(box_blob, N, cfg, ex, thresh); b_sim = _sim(box_blob, N, cfg, ex, thresh)
+    g = torch.Generator().manual_seed(3)
+    seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(0, 100, (N,), generator=g, dtype=torch.int32)
+    a_sim.reset(seq, start); b_sim.reset(seq, start)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for t in range(6):
+        act = (torch.randn(N, 32, generator=g) * 0.3).cuda()
+        ns = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32).cuda(); nst = torch.randint(0, 100, (N,), generator=g, dtype=torch.int32).cuda()
+        ref = [x.clone() for x in a_sim.step(act, ns, nst)]
+        torch.cuda.synchronize()
+        for k, (first, count) in enumerate(((0, 96), (96, 160))):
+            with torch.cuda.stream(streams[k]):
+                out = b_sim.step(act[first:first + count], ns[first:first + count], nst[first:first + count], first, count)
+                assert out[0].shape == (count, 617)
+        torch.cuda.synchronize()
+        got = (b_sim.obs, b_sim.reward, b_sim.reward_info, b_sim.flags, b_sim.percent)
+        for r, o in zip(ref, got):
+            assert torch.equal(r, o)
+    qa, va, ta = a_sim.get_state(); qb, vb, tb = b_sim.get_state()
+    assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(ta, tb)
+    with pytest.raises(lib.HoicError):
+        b_sim.step(act[:8], ns[:8], nst[:8], N - 4, 8)      # range past the last env
