@@ -254,6 +254,8 @@ class AgentHandMimic:
         for gi in range(G):
             c_info += c_info_g[gi]; n_done += n_done_g[gi]
         self._obs = obs
+        if self.distributed:
+            self.running_state.sync()          # one observation filter for all ranks from here on
         next_state = self.running_state(obs, update=False)
         next_values = self.value_net(next_state).squeeze(1)
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,

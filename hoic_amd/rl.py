@@ -169,6 +169,7 @@ class BatchZFilter:
         self.n = torch.zeros((), dtype=torch.float64, device=device)
         self.mean = torch.zeros(dim, dtype=torch.float64, device=device)
         self.S = torch.zeros(dim, dtype=torch.float64, device=device)
+        self._base = (self.n.clone(), self.mean.clone(), self.S.clone())     # state at the last sync()
 
     def push(self, x):
         x = x.to(torch.float64)
@@ -190,14 +191,22 @@ class BatchZFilter:
         return torch.clamp(y, -self.clip, self.clip).to(x.dtype)
 
     def sync(self, group=None):
-        """All-reduce the moments over ranks (replicas then share one filter; the reference keeps worker 0's)."""
+        """Merge the moments over ranks: afterwards every rank holds the filter of ALL samples seen by any rank (the
+        reference keeps worker 0's copy and drops the others', agent.py:64-120).  Safe to call every iteration: only
+        what a rank pushed since the previous sync is exchanged (as count, sum and sum of squares in float64)."""
         import torch.distributed as dist
-        n, mean, S = self.n.clone(), self.mean.clone(), self.S.clone()
-        tot = n.clone(); dist.all_reduce(tot, group=group)
-        wmean = mean * n; dist.all_reduce(wmean, group=group)
-        gmean = wmean / tot
-        gS = S + n * (mean - gmean) ** 2; dist.all_reduce(gS, group=group)
-        self.n, self.mean, self.S = tot, gmean, gS
+        n0, m0, S0 = self._base
+        q0 = S0 + n0 * m0 * m0
+        dn = self.n - n0
+        dsum = self.n * self.mean - n0 * m0
+        dq = (self.S + self.n * self.mean * self.mean) - q0
+        dn = dn.clone(); dsum = dsum.clone(); dq = dq.clone()
+        dist.all_reduce(dn, group=group); dist.all_reduce(dsum, group=group); dist.all_reduce(dq, group=group)
+        n = n0 + dn
+        mean = (n0 * m0 + dsum) / torch.clamp(n, min=1.0)
+        S = torch.clamp(q0 + dq - n * mean * mean, min=0.0)
+        self.n, self.mean, self.S = n, mean, S
+        self._base = (n.clone(), mean.clone(), S.clone())
 
     def to_reference(self):
         z = ZFilter(tuple(self.mean.shape), clip=self.clip)
@@ -210,4 +219,5 @@ class BatchZFilter:
         f.n = torch.tensor(float(z.rs._n), dtype=torch.float64, device=device)
         f.mean = torch.as_tensor(z.rs._M, dtype=torch.float64, device=device).clone()
         f.S = torch.as_tensor(z.rs._S, dtype=torch.float64, device=device).clone()
+        f._base = (f.n.clone(), f.mean.clone(), f.S.clone())       # a loaded filter is common to all ranks
         return f

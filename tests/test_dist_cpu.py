@@ -44,7 +44,9 @@ def _worker(rank, world, port, q):
     from types import SimpleNamespace
     part = SimpleNamespace(**{k: (v[:, sl] if v.dim() >= 2 else v[sl]) for k, v in vars(full).items()})
     learner.update_params(part)
-    zf = BatchZFilter(24); zf.push(full.states[:, sl].reshape(-1, 24)); zf.sync()
+    # two sampling rounds, a sync after each (agent.sample does one per iteration)
+    zf = BatchZFilter(24); zf.push(full.states[:3, sl].reshape(-1, 24)); zf.sync()
+    zf.push(full.states[3:, sl].reshape(-1, 24)); zf.sync()
     if rank == 0:
         q.put(({k: v.numpy() for k, v in learner.policy_net.state_dict().items()},
                {k: v.numpy() for k, v in learner.value_net.state_dict().items()}, zf.mean.numpy(), zf.S.numpy(), float(zf.n)))
@@ -75,5 +77,5 @@ def test_two_ranks_equal_one_process():
         np.testing.assert_allclose(v.numpy(), val2[k], atol=1e-12, err_msg=k)
     zf = BatchZFilter(24); zf.push(full.states.reshape(-1, 24))
     np.testing.assert_allclose(zf.mean.numpy(), zmean, atol=1e-12)
-    np.testing.assert_allclose(zf.S.numpy(), zS, atol=1e-10)
+    np.testing.assert_allclose(zf.S.numpy(), zS, rtol=1e-10, atol=1e-10)
     assert zn == float(zf.n)
