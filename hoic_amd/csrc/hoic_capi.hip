@@ -26,22 +26,22 @@ extern "C" const char* hoic_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------------ kernels
 __device__ void load_state(const DevModel& m, const DevState& st, Work& w, int env) {
   const int tid = threadIdx.x;
-  if (tid < NQP) { w.qpos[tid] = st.qpos[(size_t)env * NQP + tid]; w.qlag[tid] = st.qlag[(size_t)env * NQP + tid]; }
+  if (tid < NQP) { w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid]; w.qlag[tid] = as_global(st.qlag)[(size_t)env * NQP + tid]; }
   if (tid < NV) {
-    w.qvel[tid] = st.qvel[(size_t)env * NV + tid]; w.vlag[tid] = st.vlag[(size_t)env * NV + tid];
-    w.warm[tid] = st.warm[(size_t)env * NV + tid];
+    w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid]; w.vlag[tid] = as_global(st.vlag)[(size_t)env * NV + tid];
+    w.warm[tid] = as_global(st.warm)[(size_t)env * NV + tid];
     w.ctrl[tid] = 0.f; w.applied[tid] = 0.f; w.qacc[tid] = 0.f;
   }
   if (tid < NHG) { for (int i = 0; i < 12; i++) w.rec_sum[tid][i] = 0.f; w.rec_cnt[tid] = 0; }
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; }
-  __syncthreads();
+  wsync();
 }
 __device__ void store_state(const DevState& st, const Work& w, int env) {
   const int tid = threadIdx.x;
-  if (tid < NQP) { st.qpos[(size_t)env * NQP + tid] = w.qpos[tid]; st.qlag[(size_t)env * NQP + tid] = w.qlag[tid]; }
+  if (tid < NQP) { as_global(st.qpos)[(size_t)env * NQP + tid] = w.qpos[tid]; as_global(st.qlag)[(size_t)env * NQP + tid] = w.qlag[tid]; }
   if (tid < NV) {
-    st.qvel[(size_t)env * NV + tid] = w.qvel[tid]; st.vlag[(size_t)env * NV + tid] = w.vlag[tid];
-    st.warm[(size_t)env * NV + tid] = w.warm[tid];
+    as_global(st.qvel)[(size_t)env * NV + tid] = w.qvel[tid]; as_global(st.vlag)[(size_t)env * NV + tid] = w.vlag[tid];
+    as_global(st.warm)[(size_t)env * NV + tid] = w.warm[tid];
   }
 }
 
@@ -62,7 +62,7 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   for (int rep = 0; rep < HOIC_EXP_EXTRA_HSOLVE; rep++) a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs + 1e-30f * a0);
 #endif
   if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
-  __syncthreads();
+  wsync();
   RowK rk;
   dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
 #ifdef HOIC_EXP_CONS
@@ -88,9 +88,9 @@ __device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
   const float acc = dev_hsolve(m, w, M, h * w.k_damp[d], m.nv, false, rhs);
   if (tid < NQP) w.qlag[tid] = w.qpos[tid];
   if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
-  __syncthreads();
+  wsync();
   if (tid < m.nv) w.qvel[tid] += h * acc;
-  __syncthreads();
+  wsync();
   if (tid < m.njnt) {
     const int qa = m.jnt_qposadr[tid], da = m.jnt_dofadr[tid];
     if (m.jnt_type[tid] == HOIC_JNT_FREE) {
@@ -107,7 +107,7 @@ __device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
       }
     } else w.qpos[qa] += h * w.qvel[da];
   }
-  __syncthreads();
+  wsync();
 }
 
 // ---- kernel 1 of a step: the 15 substeps (control glue + dynamics + contact solve + integration), f32.
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
   // workgroup b runs env first + b (I/O row b), or env order[b] of a whole-batch step in longest-first order
-  const int env = use_order ? st.order[blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
+  const int env = use_order ? as_global(st.order)[blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
 #ifdef HOIC_TRACE_DISPATCH
   const long long trace_t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -132,20 +132,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   MReg M;
 #ifdef HOIC_PHASE_TIMING
   if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
-  __syncthreads();
+  wsync();
 #endif
   if (tid < NV) w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);   // ho_im4.py:613
-  __syncthreads();
-  const int seq = st.seq[env];
-  ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], st.start[env], st.cur_t[env]};
+  wsync();
+  const int seq = as_global(st.seq)[env];
+  ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], as_global(st.start)[env], as_global(st.cur_t)[env]};
   float vf[3], vt[3];
   for (int i = 0; i < 3; i++) {
     vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
     vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
   }
-  int* ovf = &st.overflow[env];
-  float* post = st.post + (size_t)env * PB_SIZE;
-  float* oldg = st.oldg + (size_t)env * OG_SIZE;
+  int* ovf = (int*)&as_global(st.overflow)[env];
+  GPTR(float) post = as_global(st.post) + (size_t)env * PB_SIZE;
+  GPTR(float) oldg = as_global(st.oldg) + (size_t)env * OG_SIZE;
   // One loop, three modes, so that every stage has a single (inlined) call site:
   //   mode 0  the forward pass on the lagged state: quantities of the previous forward pass (one-substep lag,
   //           SURVEY.md row Q1) are recomputed instead of being persisted
@@ -162,9 +162,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   while (true) {
     // the model / config pointers are laundered every pass: otherwise the compiler hoists the (loop-invariant)
     // model-constant loads out of the loop and pins them in registers
-    const DevModel* mq = mp; const DevConfig* cq = cp;
+    // (the laundered pointers keep their global address space: a generic pointer would turn every model read into a
+    // flat_load, which counts on the LDS counter as well and forces s_waitcnt vmcnt(0) lgkmcnt(0) drains)
+    GPTR(const DevModel) mq = (GPTR(const DevModel))mp; GPTR(const DevConfig) cq = (GPTR(const DevConfig))cp;
     asm volatile("" : "+s"(mq), "+s"(cq));
-    const DevModel& ml = *mq; const DevConfig& cl = *cq;
+    const DevModel& ml = *(const DevModel*)mq; const DevConfig& cl = *(const DevConfig*)cq;
     PT(0);
     if (mode == 1) {
       dev_record_contact(ml, w); PT(2);           // :543 (contacts of the previous forward pass)
@@ -200,13 +202,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
       if (tid < NQP) w.qpos[tid] = w.qlag[tid];
       if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
-      __syncthreads();
+      wsync();
       mode = 2;
       continue;
     }
 #ifdef HOIC_EXP_EULER
-    { if (tid < NV) w.tv0[tid] = w.qvel[tid]; if (tid < NQP) w.tq0[tid] = w.qpos[tid]; __syncthreads(); dev_euler(ml, w, M);
-      if (tid < NV) w.qvel[tid] = w.tv0[tid]; if (tid < NQP) w.qpos[tid] = w.tq0[tid]; __syncthreads(); }
+    { if (tid < NV) w.tv0[tid] = w.qvel[tid]; if (tid < NQP) w.tq0[tid] = w.qpos[tid]; wsync(); dev_euler(ml, w, M);
+      if (tid < NV) w.qvel[tid] = w.tv0[tid]; if (tid < NQP) w.qpos[tid] = w.tq0[tid]; wsync(); }
 #endif
     dev_euler(ml, w, M); PT(10);              //              ... + Euler
     if (++done_sub >= nsub) break;
@@ -236,10 +238,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
   if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
   store_state(st, w, env);
-  if (tid == 0) st.cost[env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
+  if (tid == 0) as_global(st.cost)[env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
 #ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock
   if (tid == 0) {
-    long long* tr = st.phase + (size_t)env * 24;
+    GPTR(long long) tr = as_global(st.phase) + (size_t)env * 24;
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
   PT(13);
 #ifdef HOIC_PHASE_TIMING
-  if (tid < 24) st.phase[(size_t)env * 24 + tid] = w.pt[tid];
+  if (tid < 24) as_global(st.phase)[(size_t)env * 24 + tid] = w.pt[tid];
 #endif
 }
 
@@ -263,15 +265,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            const int* __restrict__ next_start, int first, int use_order, int n_envs) {
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
-  const int env = use_order ? st.order[n_envs + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
+  const int env = use_order ? as_global(st.order)[n_envs + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
 #ifdef HOIC_TRACE_DISPATCH
   if (tid == 0) for (int i = 0; i < 4; i++) g_trace_qp[blockIdx.x * 4 + i] = 0;
 #endif
-  const float* post = st.post + (size_t)env * PB_SIZE;
-  if (tid < NQP) w.qpos[tid] = st.qpos[(size_t)env * NQP + tid];
+  GPTR(const float) post = as_global((const float*)st.post) + (size_t)env * PB_SIZE;
+  if (tid < NQP) w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
   if (tid < NV) {
-    w.qvel[tid] = st.qvel[(size_t)env * NV + tid];
+    w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid];
     w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);
   }
   for (int k = tid; k < m.nbody * 3; k += NT) w.xpos[k / 3][k % 3] = post[PB_XPOS + k];
@@ -283,9 +285,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (tid < 6) w.sc.post.obj_avg_acc[tid] = post[PB_OBJACC + tid];
   bool ok = post[PB_OK] != 0.f;
   const int solver_iter = (int)post[PB_ITER];
-  __syncthreads();
-  const int seq = st.seq[env];
-  ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], st.start[env], st.cur_t[env]};
+  wsync();
+  const int seq = as_global(st.seq)[env];
+  ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], as_global(st.start)[env], as_global(st.cur_t)[env]};
   float vf[3], vt[3];
   for (int i = 0; i < 3; i++) {
     vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float rfc_score = 0.f;
   if (ok) {
     dev_classify_contact(m, w);                                                                // :562
-    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, st.qp_lam + (size_t)env * 8);   // :631
+    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
     if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
   }
   asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
@@ -316,25 +318,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     reward[io] = r;
     flags[4 * io] = fail; flags[4 * io + 1] = end; flags[4 * io + 2] = done; flags[4 * io + 3] = solver_iter;
     percent[io] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
-    st.rfc_score[env] = rfc_score;
+    as_global(st.rfc_score)[env] = rfc_score;
   }
   if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
   if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
     const int ns = next_seq[io], nst = next_start[io];
-    __syncthreads();
+    wsync();
     dev_reset_state(m, w, ex, ns, nst);
     dev_kinematics(m, w, w.qpos);
-    if (tid == 6) st.qp_lam[(size_t)env * 8 + 6] = 0.0;
-    ev.off = ex.seq_off[ns]; ev.len = ex.seq_len[ns]; ev.start = nst; ev.cur_t = 0;
-    if (tid == 0) { st.seq[env] = ns; st.start[env] = nst; }
+    if (tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
+    ev.off = as_global(ex.seq_off)[ns]; ev.len = as_global(ex.seq_len)[ns]; ev.start = nst; ev.cur_t = 0;
+    if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; }
     store_state(st, w, env);
   }
   dev_write_obs(m, w, ev, obs + (size_t)io * HOIC_OBS_DIM);
   if (tid == 0) {
-    st.cur_t[env] = ev.cur_t;
-    st.cost[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
+    as_global(st.cur_t)[env] = ev.cur_t;
+    as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
 #ifdef HOIC_TRACE_DISPATCH
-    long long* tr = st.phase + (size_t)env * 24;
+    GPTR(long long) tr = as_global(st.phase) + (size_t)env * 24;
     for (int i = 0; i < 4; i++) tr[12 + i] = g_trace_qp[blockIdx.x * 4 + i];
 #endif
   }
@@ -393,30 +395,30 @@ __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restri
   const int env = env_ids ? env_ids[k] : k;
   const int seq = seqs[k], start = starts[k];
   if (tid < NQP) w.qpos[tid] = 0.f;
-  __syncthreads();
+  wsync();
   dev_reset_state(m, w, ex, seq, start);
   dev_kinematics(m, w, w.qpos);
-  ExpertView ev{&ex, ex.seq_off[seq], ex.seq_len[seq], start, 0};
+  ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], start, 0};
   if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
   store_state(st, w, env);
-  if (tid == 0) { st.cur_t[env] = 0; st.start[env] = start; st.seq[env] = seq; st.rfc_score[env] = 0.f; st.qp_lam[(size_t)env * 8 + 6] = 0.0; }
+  if (tid == 0) { as_global(st.cur_t)[env] = 0; as_global(st.start)[env] = start; as_global(st.seq)[env] = seq; as_global(st.rfc_score)[env] = 0.f; as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0; }
 }
 
 __global__ __launch_bounds__(NT) void hoic_set_state_kernel(const DevModel* __restrict__ mp, DevState st,
                                                             const float* __restrict__ qpos, const float* __restrict__ qvel) {
   const int env = blockIdx.x, tid = threadIdx.x, nq = mp->nq, nv = mp->nv;
-  if (tid < NQP) { const float v = tid < nq ? qpos[(size_t)env * nq + tid] : 0.f; st.qpos[(size_t)env * NQP + tid] = v; st.qlag[(size_t)env * NQP + tid] = v; }
+  if (tid < NQP) { const float v = tid < nq ? qpos[(size_t)env * nq + tid] : 0.f; as_global(st.qpos)[(size_t)env * NQP + tid] = v; as_global(st.qlag)[(size_t)env * NQP + tid] = v; }
   if (tid < NV) {
     const float v = tid < nv ? qvel[(size_t)env * nv + tid] : 0.f;
-    st.qvel[(size_t)env * NV + tid] = v; st.vlag[(size_t)env * NV + tid] = v; st.warm[(size_t)env * NV + tid] = 0.f;
+    as_global(st.qvel)[(size_t)env * NV + tid] = v; as_global(st.vlag)[(size_t)env * NV + tid] = v; as_global(st.warm)[(size_t)env * NV + tid] = 0.f;
   }
 }
 __global__ __launch_bounds__(NT) void hoic_get_state_kernel(const DevModel* __restrict__ mp, DevState st, float* __restrict__ qpos,
                                                             float* __restrict__ qvel, int* __restrict__ cur_t) {
   const int env = blockIdx.x, tid = threadIdx.x, nq = mp->nq, nv = mp->nv;
-  if (qpos && tid < nq) qpos[(size_t)env * nq + tid] = st.qpos[(size_t)env * NQP + tid];
-  if (qvel && tid < nv) qvel[(size_t)env * nv + tid] = st.qvel[(size_t)env * NV + tid];
-  if (cur_t && tid == 0) cur_t[env] = st.cur_t[env];
+  if (qpos && tid < nq) qpos[(size_t)env * nq + tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
+  if (qvel && tid < nv) qvel[(size_t)env * nv + tid] = as_global(st.qvel)[(size_t)env * NV + tid];
+  if (cur_t && tid == 0) cur_t[env] = as_global(st.cur_t)[env];
 }
 
 struct ProbeArgs {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
     w.warm[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;
   }
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; }
-  __syncthreads();
+  wsync();
   dev_load_constants(m, w);
   MReg M;
   dev_forward_kin(m, w, M, w.qpos, w.qvel, nullptr);
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const float* src = cols + (size_t)k * max_col * 7;
   for (int c = tid; c < ncol; c += NT)
     for (int i = 0; i < 7; i++) qc[i * QP_MAXCOL + c] = src[(size_t)c * 7 + i];
-  __syncthreads();
+  wsync();
   double b[6], lam[6];
   for (int i = 0; i < 6; i++) b[i] = rhs[(size_t)k * 6 + i];
   int stat[2];

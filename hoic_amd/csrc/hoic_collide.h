@@ -312,9 +312,9 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
       const float tt = da / (da - db);
       polybuf[2 * (pos + (e1 ? 1 : 0))] = px + tt * (bx - px); polybuf[2 * (pos + (e1 ? 1 : 0)) + 1] = py + tt * (by - py);
     }
-    __syncthreads();
+    wsync();
     if (lane < n) { px = polybuf[2 * lane]; py = polybuf[2 * lane + 1]; }
-    __syncthreads();
+    wsync();
   }
   // depths, keep the penetrating vertices (polygon order), at most four of them
   const float depth = hrax - (z0 + gx * px + gy * py);
@@ -496,7 +496,7 @@ HD void make_frame(float* f) {
 __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
   const int tid = opaque(threadIdx.x);
   if (tid == 0) w.ncon = 0;
-  __syncthreads();
+  wsync();
   for (int ps = 0; ps * NT < m.npair; ps++) {
     const int p = ps * NT + tid;
     LaneContacts lc{0, &w.col_lc[tid]};
@@ -564,7 +564,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         const int nn = col_box_box_wave(Pa, RA, Ha, Pb, RB, Hb, owner, w.col_poly);
         if (tid == L) lc.n = nn;
       }
-      __syncthreads();
+      wsync();
     }
     // margin filter, then the survivors go from the staging column to their positions in the contact list
     int cnt = 0;
@@ -588,12 +588,12 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         c++;
       }
     }
-    __syncthreads();
+    wsync();
     if (tid == 0) {
       int nn = w.ncon + total;
       if (nn > MAXCON) { if (overflow) *overflow += 1; nn = MAXCON; }
       w.ncon = nn;
     }
-    __syncthreads();
+    wsync();
   }
 }

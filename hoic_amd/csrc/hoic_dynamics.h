@@ -25,7 +25,7 @@ __device__ __forceinline__ void dev_load_constants(const DevModel& m, Work& w) {
     w.k_flR[t] = v ? m.dof_flR[t] : 1.f; w.k_flB[t] = v ? m.dof_flB[t] : 0.f; w.k_act[t] = v ? m.dof_actid[t] : -1;
   }
   if (t < NB) for (int i = 0; i < 3; i++) w.k_bpath[t][i] = t < m.nbody ? m.body_path[t][i] : 0xFFFFFFFFu;
-  __syncthreads();
+  wsync();
 }
 
 // sum_{d on the packed path} S[d] * x[d]  (+ optional extra[d]) as straight-line code: all LDS reads are issued
@@ -70,7 +70,7 @@ __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const
     r[6] = (ty == HOIC_JNT_SLIDE) ? qq : cs; r[7] = sn * r[0]; r[8] = sn * r[1]; r[9] = sn * r[2];
     r[10] = __int_as_float(ty); r[11] = __int_as_float(qa);
   }
-  __syncthreads();
+  wsync();
   // 1. transform of each body relative to its parent, with the joint axes / anchors in the parent frame
   if (isb) {
     const int b = tid, ja = m.body_jntadr[b], jn = m.body_jntnum[b];
@@ -105,7 +105,7 @@ __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const
     for (int i = 0; i < 3; i++) w.xpos[b][i] = P[i];
     for (int i = 0; i < 4; i++) w.xquat[b][i] = Q[i];
   }
-  __syncthreads();
+  wsync();
   // 2. pointer jumping: after round r a body's transform is relative to its ancestor 2^(r+1) levels up
   for (int r = 0; r < m.nround; r++) {
     const int src = isb ? m.body_jump[r][tid] : -1;
@@ -118,18 +118,18 @@ __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const
       mulquat(Qs, Q, qn);
       for (int i = 0; i < 4; i++) Q[i] = qn[i];
     }
-    __syncthreads();
+    wsync();
     if (src >= 0) {
       for (int i = 0; i < 3; i++) w.xpos[tid][i] = P[i];
       for (int i = 0; i < 4; i++) w.xquat[tid][i] = Q[i];
     }
-    __syncthreads();
+    wsync();
   }
   if (isb) {
     normquat(Q);
     for (int i = 0; i < 4; i++) w.xquat[tid][i] = Q[i];
   }
-  __syncthreads();
+  wsync();
   PT(21);
   // 3a. per body: spatial inertia about the world origin (m, h = m c, Io: xx yy zz xy xz yz)
   if (isb) {
@@ -200,7 +200,7 @@ __device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const
       quat2mat(qg, w.gxmat[g]);
     }
   }
-  __syncthreads();
+  wsync();
 }
 
 HD void inert_mul(const float* I, const float* v, float* f) {
@@ -225,14 +225,14 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
       for (int i = 0; i < 10; i++) acc[i] += w.sc.dyn.I10[b][i];
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
-  __syncthreads();   // (also: the joint frames in sc.dyn.u.j are dead from here on, u.f takes their place)
+  wsync();   // (also: the joint frames in sc.dyn.u.j are dead from here on, u.f takes their place)
   const int d = opaque(tid & 31);
   const bool vd = d < m.nv;
   float Si[6], fSi[6];
   for (int i = 0; i < 6; i++) { Si[i] = vd ? w.S[d][i] : 0.f; fSi[i] = 0.f; }
   if (vd) inert_mul(w.sc.dyn.Ic[m.dof_bodyid[d]], Si, fSi);
   if (tid < 32) for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[d][i] = fSi[i];
-  __syncthreads();
+  wsync();
   const unsigned am = vd ? (m.dof_amask[d] | (1u << d)) : 0u, dm = vd ? m.dof_dmask[d] : 0u;
   const int hi = tid >> 5;
 #pragma unroll
@@ -243,7 +243,7 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
     if (j == d) v += w.k_arm[d];
     M.r[reg] = v;
   }
-  __syncthreads();
+  wsync();
 }
 
 // (M x)[lane & 31] on every lane, x in LDS: each half-wave sums its 16 columns, one cross-half add
@@ -287,7 +287,7 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     const float qd = qvel[tid];
     for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[tid][i] = sd[i] * qd;
   }
-  __syncthreads();
+  wsync();
   if (tid < m.nbody) {
     float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
@@ -300,7 +300,7 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     }
     for (int i = 0; i < 6; i++) w.sc.dyn.u.f.cfrc[tid][i] = f[i];
   }
-  __syncthreads();
+  wsync();
   if (tid < m.nbody) {   // subtree force sums (range sums again), kept in the Ic slots
     float sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (m.body_dofnum[tid] > 0) {
@@ -310,9 +310,9 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     }
     for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
   }
-  __syncthreads();
+  wsync();
   if (tid < NV) w.bias[tid] = (tid < m.nv) ? dot6(w.S[tid], w.sc.dyn.Ic[m.dof_bodyid[tid]]) : 0.f;
-  __syncthreads();
+  wsync();
 }
 
 // J^T (f at point, torque) of a body into qfrc, with the kinematics currently in the workspace (mj_applyFT,

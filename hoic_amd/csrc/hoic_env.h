@@ -53,7 +53,7 @@ __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, 
   const float dt = m.timestep;
   float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
   if (d < n) {
-    const float* ref = ev.ex->hand_dof + (size_t)ev.frame(cfg.c.pd_ref_offset) * m.hand_nq;   // 0; 1 in the streaming env
+    GPTR(const float) ref = as_global(ev.ex->hand_dof) + (size_t)ev.frame(cfg.c.pd_ref_offset) * m.hand_nq;   // 0; 1 in the streaming env
     float target;
     const float a = w.action[d];
     if (d < 3) target = ref[d] + 0.1f * a;
@@ -79,7 +79,7 @@ __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, 
     }
     w.ctrl[tid] = tq;
   }
-  __syncthreads();
+  wsync();
 }
 
 // ---- generalized applied forces: gravity compensation + residual object wrench, lagged Jacobians
@@ -94,7 +94,7 @@ __device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, co
     }
     w.applied[tid] = s;
   }
-  __syncthreads();
+  wsync();
 }
 
 // ---- record_contact (ho_im4.py:883-889): lane = hand geom, deterministic accumulation order
@@ -111,7 +111,7 @@ __device__ void dev_record_contact(const DevModel& m, Work& w) {
       }
     }
   }
-  __syncthreads();
+  wsync();
 }
 
 // uhc/utils/transforms.py:414 matrix_to_axis_angle
@@ -158,7 +158,7 @@ __device__ void dev_classify_contact(const DevModel& m, Work& w) {
     w.sc.post.avg_geom[idx] = tid + m.hand_geom0;
     w.sc.post.avg_ts[idx] = (float)w.rec_cnt[tid];
   }
-  __syncthreads();
+  wsync();
 }
 
 // ---- solve_rfc (ho_im4.py:941-1083) in float64: Newton on the 6-D dual of the non-negative QP
@@ -292,9 +292,9 @@ __device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, con
       const int src = __ffsll((long long)__ballot(best == wmax)) - 1;
       const int k = __builtin_amdgcn_readlane(bestc, src);
       const int s = __ffs((int)~pm) - 1;
-      __syncthreads();
+      wsync();
       if (tid < 8) pa[s][tid] = tid < 7 ? qc[tid * QP_MAXCOL + k] : 0.f;
-      __syncthreads();
+      wsync();
       double an[6], hnew = -(double)pa[s][6];
 #pragma unroll
       for (int i = 0; i < 6; i++) { an[i] = (double)pa[s][i]; hnew += 2.0 * an[i] * b[i]; }
@@ -311,7 +311,7 @@ __device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, con
       for (int j = 0; j < QP_MAXP; j++) if (j == s) { hb[j] = hnew; xs[j] = 0.0; colj[j] = k; }
       pm |= 1u << s;
       if (tid == (k & (NT - 1))) inP |= 1u << (k / NT);
-      __syncthreads();
+      wsync();
       bool rejected = false, first = true;
       for (int in = 0; in < 24; in++) {
         double W[QP_MAXP * (QP_MAXP + 1) / 2], z[QP_MAXP];
@@ -371,7 +371,7 @@ __device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, con
 #pragma unroll
         for (int i = 0; i < 6; i++) lam[i] += 2.0 * xs[j] * (double)pa[j][i];
       }
-    __syncthreads();
+    wsync();
   }
   // ---- dual Newton: only when the passive set was full or the pass ran out of iterations; starts at the
   // multipliers found above
@@ -527,7 +527,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
     qc[5 * QP_MAXCOL + col] = (float)(swt * (cro[0] * xv[1] - cro[1] * xv[0]));
     qc[6 * QP_MAXCOL + col] = (float)(((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt));
   }
-  __syncthreads();
+  wsync();
   const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
   double lam[6];
 #ifdef HOIC_TRACE_DISPATCH
@@ -547,7 +547,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
 // ---- termination diffs (calc_ho_diff, ho_im4.py:664-688); out: pos, rot, jpos, obj, obj_rot(=0)
 __device__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& ev, float* out) {
   const int tid = threadIdx.x, hb0 = m.hand_body0, fr = ev.frame(0);
-  const float* ep = ev.ex->body_pos + (size_t)fr * NHB * 3; const float* eq = ev.ex->body_quat + (size_t)fr * NHB * 4;
+  GPTR(const float) ep = as_global(ev.ex->body_pos) + (size_t)fr * NHB * 3; GPTR(const float) eq = as_global(ev.ex->body_quat) + (size_t)fr * NHB * 4;
   float s = 0.f;
   if (tid < NHB) { float dv[3]; for (int i = 0; i < 3; i++) dv[i] = w.xpos[hb0 + tid][i] - ep[3 * tid + i]; s = sqrtf(dot3(dv, dv)); }
   const float root = rl(s, 0);
@@ -556,7 +556,7 @@ __device__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& 
   float qi[4], qd[4], e4[4] = {eq[0], eq[1], eq[2], eq[3]};
   quat_inv(w.xquat[hb0], qi); mulquat(e4, qi, qd);
   out[1] = 2.f * asinf(fminf(fmaxf(sqrtf(qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]), 0.f), 1.f));
-  const float* eo = ev.ex->obj_pose + (size_t)fr * 7;
+  GPTR(const float) eo = as_global(ev.ex->obj_pose) + (size_t)fr * 7;
   float dv[3];
   for (int i = 0; i < 3; i++) dv[i] = w.qpos[m.hand_nq + i] - eo[i];
   out[3] = sqrtf(dot3(dv, dv));
@@ -569,8 +569,8 @@ __device__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& 
 __device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& w, const ExpertView& ev, float rfc_score, float* out) {
   const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0, fr = ev.frame(0);
   const float* wk = cfg.rp.wk;
-  const float* eq = ev.ex->hand_dof + (size_t)fr * nh; const float* evel = ev.ex->hand_dof_vel + (size_t)fr * nh;
-  const float* ebq = ev.ex->body_quat + (size_t)fr * NHB * 4; const float* ebp = ev.ex->body_pos + (size_t)fr * NHB * 3;
+  GPTR(const float) eq = as_global(ev.ex->hand_dof) + (size_t)fr * nh; GPTR(const float) evel = as_global(ev.ex->hand_dof_vel) + (size_t)fr * nh;
+  GPTR(const float) ebq = as_global(ev.ex->body_quat) + (size_t)fr * NHB * 4; GPTR(const float) ebp = as_global(ev.ex->body_pos) + (size_t)fr * NHB * 3;
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
   if (tid >= 6 && tid < nh) a = fabsf(w.qpos[tid] - eq[tid]);
   if (tid < m.hand_nv) c = fabsf(w.qvel[tid] - evel[tid]);
@@ -586,7 +586,7 @@ __device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& 
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
   const float pose_r = expf(-wk[8] * a / (float)(nh - 6)), wpose_r = expf(-wk[9] * b / (float)NHB);
   const float vel_r = expf(-wk[10] * c / (float)m.hand_nv), jpos_r = expf(-wk[11] * d / (float)NHB);
-  const float* eo = ev.ex->obj_pose + (size_t)fr * 7;
+  GPTR(const float) eo = as_global(ev.ex->obj_pose) + (size_t)fr * 7;
   float dv[3];
   for (int i = 0; i < 3; i++) dv[i] = w.qpos[nh + i] - eo[i];
   const float opos_r = expf(-wk[12] * sqrtf(dot3(dv, dv)));
@@ -595,8 +595,8 @@ __device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& 
   const float w0 = fabsf(qd[0]) - 1.f;
   const float orot_r = expf(-wk[13] * sqrtf(w0 * w0 + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]));
   float s = 0.f;
-  for (int i = 0; i < 3; i++) s += fabsf(w.qvel[m.hand_nv + i] - ev.ex->obj_vel[(size_t)fr * 3 + i]) +
-                                   fabsf(w.qvel[m.hand_nv + 3 + i] - ev.ex->obj_angvel[(size_t)fr * 3 + i]);
+  for (int i = 0; i < 3; i++) s += fabsf(w.qvel[m.hand_nv + i] - as_global(ev.ex->obj_vel)[(size_t)fr * 3 + i]) +
+                                   fabsf(w.qvel[m.hand_nv + 3 + i] - as_global(ev.ex->obj_angvel)[(size_t)fr * 3 + i]);
   const float ovel_r = expf(-wk[14] * s / 6.f);
   const float orfc_r = cfg.c.residual_force ? expf(-wk[15] * rfc_score) : 1.f;
   const float hand = (wk[0] * pose_r + wk[1] * wpose_r + wk[3] * jpos_r + wk[2] * vel_r) / (wk[0] + wk[1] + wk[3] + wk[2]);
@@ -669,8 +669,8 @@ __device__ void dev_reset_state(const DevModel& m, Work& w, const DevExpert& x, 
   if (tid < nh) { w.qpos[tid] = x.hand_dof[(size_t)fr * nh + tid]; w.qvel[tid] = x.hand_dof_vel[(size_t)fr * nh + tid]; }
   if (tid < 7) w.qpos[nh + tid] = x.obj_pose[(size_t)fr * 7 + tid];
   if (tid < 3) { w.qvel[m.hand_nv + tid] = x.obj_vel[(size_t)fr * 3 + tid]; w.qvel[m.hand_nv + 3 + tid] = x.obj_angvel[(size_t)fr * 3 + tid]; }
-  __syncthreads();
+  wsync();
   if (tid < NQP) w.qlag[tid] = tid < m.nq ? w.qpos[tid] : 0.f;
   if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = 0.f; w.qacc[tid] = 0.f; }
-  __syncthreads();
+  wsync();
 }

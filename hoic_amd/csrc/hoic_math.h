@@ -3,6 +3,20 @@
 #include <hip/hip_runtime.h>
 
 #define HD __device__ __forceinline__
+// pointer to global memory as such (address space 1), and the cast that tells the compiler a pointer it cannot trace
+// (loaded from a table in memory) is one: accesses become global_load/store instead of flat ones
+#define GPTR(T) T __attribute__((address_space(1)))*
+template <class T> HD GPTR(T) as_global(T* p) { return (GPTR(T))p; }
+// Ordering point between lanes of ONE wavefront that talk through LDS (every workgroup of the simulator kernels is a
+// single wavefront).  The LDS pipeline executes a wave's instructions in order, so a ds_read issued after a ds_write
+// sees it without any wait; all that is needed is that the compiler keeps the order.  __syncthreads() drains every
+// outstanding LDS / global access (s_waitcnt 0) at each of the ~60 hand-over points of a pass.
+// -DHOIC_FULL_BARRIER restores it (development aid).
+#ifdef HOIC_FULL_BARRIER
+#define wsync() __syncthreads()
+#else
+#define wsync() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 #define MINVALF 1e-15f
 
 // hides a lane-varying loop-invariant value from the optimiser so that the lane masks derived from it are

@@ -123,7 +123,7 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
   HsFactor<0>::run(acc, y, yv, dv, hi, T + hi * LD + col);
   PT(16);
   float x = yv * __builtin_amdgcn_rcpf(dv);       // D^-1 L^-1 rhs
-  __syncthreads();
+  wsync();
   float xv = 0.f;
   {
     float lc[16];
@@ -134,7 +134,7 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
     for (int k = 0; k < 16; k++) lc[k] = T[col * LD + k];
     HsBack<15>::run(lc, x, xv);
   }
-  __syncthreads();
+  wsync();
   PT(18);
   // lanes 0..31 of xv hold the solution; the high half-wave gets a copy
   const unsigned xb = __float_as_uint(xv);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const 
 #pragma unroll
     for (int i = 0; i < 6; i++) w.bV[tid][i] = V[i];
   }
-  __syncthreads();
+  wsync();
   const int nb = w.ncon * 4;
   for (int t = tid; t < nb; t += NT) {
     const int c = t >> 2, k = t & 3;
@@ -189,7 +189,7 @@ __device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const 
     for (int i = 0; i < 6; i++) dV[i] = w.bV[b2][i] - w.bV[b1][i];
     w.u[t] = (k < 3) ? dot3(w.c_pxf[c][k], dV) + dot3(w.c_frame[c] + 3 * k, dV + 3) : dot3(w.c_frame[c], dV);
   }
-  __syncthreads();
+  wsync();
 }
 
 // J_r . x for contact row r (u must hold dev_basis_dot(x))
@@ -269,14 +269,14 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
     const int total = __builtin_amdgcn_readlane(incl_sum, NT - 1);
     if (tid == 0) w.nrow = total;
   }
-  __syncthreads();
+  wsync();
   // reference accelerations of the contact rows
   dev_basis_dot(m, w, qvel);
   for (int r = tid; r < w.nrow; r += NT) {
     const int c = w.cr_con[r];
     w.cr_aref[r] = -w.c_B[c] * dev_crow_times(w, r) + w.c_aref0[c];
   }
-  __syncthreads();
+  wsync();
 }
 
 // ---- row state.  jar = J x - aref of every row: per-dof rows in the registers of lane & 31 = dof (both
@@ -320,7 +320,7 @@ __device__ __forceinline__ float dev_rows_cost(const DevModel& m, Work& w, const
       }
     }
   }
-  __syncthreads();
+  wsync();
   return wave_sum(cost);
 }
 
@@ -345,7 +345,7 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
     }
     for (int i = 0; i < 6; i++) w.c_G[c][i] = G[i];   // zero padding up to a multiple of 4 contacts
   }
-  __syncthreads();
+  wsync();
   float s = ev.force_f + rk.l_sign * ev.force_l;
   if (ncon > 0) {
     float G[6] = {0, 0, 0, 0, 0, 0};
@@ -360,7 +360,7 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
     }
     s += dot6(w.S[d], G);
   }
-  __syncthreads();
+  wsync();
   return s;
 }
 
@@ -401,7 +401,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
     const float sd = dev_hsolve(m, w, M, ev.curv_f + ev.curv_l, m.nv, true, -g);
     if (tid < NV) w.search[tid] = vd ? sd : 0.f;
-    __syncthreads();
+    wsync();
     // line-search quantities
     const float Ms = vd ? dev_Mx(M, w.search) : 0.f;
     float gq = 0.f, hh = 0.f, g0 = 0.f;
@@ -442,5 +442,5 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);
   if (tid < NV) { w.fcon[tid] = vd ? jtf : 0.f; w.qacc[tid] = qacc; }
   if (tid == 0) w.solver_iter = it;
-  __syncthreads();
+  wsync();
 }
