@@ -185,7 +185,9 @@ def main():
                                    f"+ PyTorch-ROCm PPO (whole loop: rollout + GAE + {cfg.num_optim_epoch} full-batch epochs)",
                        "envs_per_gpu": args.envs, "steps_per_iteration": steps_per_iter,
                        "samples_per_iteration": steps_per_iter * args.envs * world, "parallelism": f"env-dp{world}",
-                       "rollout_env_ranges": n_groups},
+                       "rollout_env_ranges": n_groups,
+                       "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
+                                                if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,
             "update_s_per_iteration": t_update / n_it,
             "avg_episode_len": float(last_log.avg_episode_len), "avg_c_reward": float(last_log.avg_c_reward),

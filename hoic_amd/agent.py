@@ -162,6 +162,8 @@ class AgentHandMimic:
         self.n_envs = n_envs
         self.state_dim, self.action_dim = self.env.observation_space.shape[0], self.env.action_space.shape[0]
         # nets + optimizers (:125-169)
+        from . import tuning
+        self.tuned_gemms = tuning.enable_tuned_gemms()      # recorded hipBLASLt kernel selections for the MLP shapes
         self.learner = PPOLearner(cfg, self.state_dim, self.action_dim, self.device, dtype, distributed, update_dtype,
                                   strict_reference)
         self.policy_net, self.value_net = self.learner.policy_net, self.learner.value_net

@@ -201,3 +201,18 @@ def test_reference_checkpoint_loads():
     # and back: our checkpoint carries a reference-compatible running state
     back = filt.to_reference()
     assert back.rs._n == cp["running_state"].rs._n and np.allclose(back.rs._M, cp["running_state"].rs._M)
+
+
+def test_tuned_gemm_selection_file():
+    """The committed TunableOp selections: validators + one line per GEMM shape of the Box loop; without a GPU the
+    loader leaves the library defaults in place."""
+    from hoic_amd import tuning
+    lines = [l.strip().split(",") for l in open(tuning.DEFAULT_FILE) if l.strip()]
+    vals = {l[1]: l[2] for l in lines if l[0] == "Validator"}
+    assert vals["GCN_ARCH_NAME"].startswith("gfx950")
+    shapes = [l for l in lines if l[0] != "Validator"]
+    assert len(shapes) >= 20 and all(len(l) >= 3 for l in shapes)
+    assert any("53248" in l[1] for l in shapes) and any("_2048_617" in l[1] for l in shapes)
+    import torch
+    if not torch.cuda.is_available():
+        assert tuning.enable_tuned_gemms() is False
