@@ -341,144 +341,186 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
   return ns;
 }
 
-// ---- convex mesh (hull vertices + face planes in the geom frame) vs plane / capsule / box.
-// Plain loops over the hull tables, one pair per lane; see oracle/ho_collide.c for the formulation.
-struct HullRef { const float (*v)[3]; int nv; const float (*pl)[4]; int np; };
-HD HullRef get_hull(const DevModel& m, int mesh) {
-  HullRef h;
-  h.v = &m.mesh_vert[m.mesh_vertadr[mesh]]; h.nv = m.mesh_vertnum[mesh];
-  h.pl = &m.mesh_plane[m.mesh_planeadr[mesh]]; h.np = m.mesh_planenum[mesh];
-  return h;
-}
-HD float hull_line_max(const HullRef& h, const float* a, const float* d, float t, int& face) {
-  const float x = a[0] + t * d[0], y = a[1] + t * d[1], z = a[2] + t * d[2];
-  float best = -1e30f; int bf = 0;
-  for (int f = 0; f < h.np; f++) {
-    const float v = h.pl[f][0] * x + h.pl[f][1] * y + h.pl[f][2] * z - h.pl[f][3];
-    if (v > best) { best = v; bf = f; }
+// ---- convex mesh (hull vertices + face planes in the geom frame) vs plane / capsule / box, wave-cooperative: the
+// whole wave works on one pair at a time (like box-box).  Lane l keeps face planes l and l + 64 and vertex l of the hull
+// in registers (hulls have at most 64 vertices and 128 faces: checked at model load), so "the face of largest signed
+// distance at a point" - the kernel of all three routines - is two plane evaluations per lane and one wave maximum
+// instead of a 120-trip loop over tables in global memory, and the vertex loops run one vertex per lane.  The logic
+// around it is the sequential formulation of oracle/ho_collide.c, evaluated uniformly by all lanes; results that
+// depend on an order (first maximum, keep-the-deepest-four, three-lowest) are produced in that order.
+struct HullLane { float p0[4], p1[4], v[3]; int np, nv; };
+HD void hull_lane_load(const DevModel& m, int mesh, HullLane& h) {
+  const int lane = threadIdx.x;
+  h.np = m.mesh_planenum[mesh]; h.nv = m.mesh_vertnum[mesh];
+  const float (*pl)[4] = &m.mesh_plane[m.mesh_planeadr[mesh]];
+  const float (*vv)[3] = &m.mesh_vert[m.mesh_vertadr[mesh]];
+  const bool a0 = lane < h.np, a1 = lane + 64 < h.np, av = lane < h.nv;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {       // a face that does not exist evaluates to -1e30 everywhere
+    h.p0[i] = a0 ? pl[lane][i] : (i == 3 ? 1e30f : 0.f);
+    h.p1[i] = a1 ? pl[lane + 64][i] : (i == 3 ? 1e30f : 0.f);
   }
-  face = bf;
-  return best;
+#pragma unroll
+  for (int i = 0; i < 3; i++) h.v[i] = av ? vv[lane][i] : 0.f;
 }
-HD void lc_keep_deepest(LaneContacts& o, float dist, const float* pos, const float* n) {
+// max over the faces of n.x - d at the point (x, y, z) (hull frame); pl = that face (the first one in face order on ties)
+HD float hull_max_wave(const HullLane& h, float x, float y, float z, float* pl) {
+  const int lane = threadIdx.x;
+  const float v0 = h.p0[0] * x + h.p0[1] * y + h.p0[2] * z - h.p0[3];
+  const float v1 = h.p1[0] * x + h.p1[1] * y + h.p1[2] * z - h.p1[3];
+  const bool second = v1 > v0;
+  const float bv = second ? v1 : v0;
+  const int bi = second ? lane + 64 : lane;
+  const float mx = wave_max(bv);
+  const unsigned long long tied = __ballot(bv == mx);
+  int idx = 0;
+  if (__popcll(tied) > 1) idx = (int)wave_min(bv == mx ? (float)bi : 1e9f);
+  else if (tied) idx = __builtin_amdgcn_readlane(bi, __ffsll((long long)tied) - 1);
+  const int wl = idx & 63;
+#pragma unroll
+  for (int i = 0; i < 4; i++) pl[i] = rl(second ? h.p1[i] : h.p0[i], wl);
+  return mx;
+}
+// the sequential "keep the four deepest" of one pair's contact list, state held uniformly: n, the four distances
+struct Deep4 { int n; float d0, d1, d2, d3; };
+HD void deep4_add(Deep4& k, const LaneContacts& owner, float dist, const float* pos, const float* nrm) {
   int slot = -1;
-  if (o.n < 4) slot = o.n++;
+  if (k.n < 4) slot = k.n++;
   else {
-    int wst = 0;
-    float wd = lc_at(o, 0, 0);
-    for (int q = 1; q < 4; q++) { const float dq = lc_at(o, q, 0); if (dq > wd) { wd = dq; wst = q; } }
+    int wst = 0; float wd = k.d0;
+    if (k.d1 > wd) { wd = k.d1; wst = 1; }
+    if (k.d2 > wd) { wd = k.d2; wst = 2; }
+    if (k.d3 > wd) { wd = k.d3; wst = 3; }
     if (dist < wd) slot = wst;
   }
-  lc_put(o, slot, dist, pos, n);
+  if (slot < 0) return;
+  k.d0 = slot == 0 ? dist : k.d0; k.d1 = slot == 1 ? dist : k.d1; k.d2 = slot == 2 ? dist : k.d2; k.d3 = slot == 3 ? dist : k.d3;
+  if (threadIdx.x == 0) { LaneContacts o = owner; lc_put(o, slot, dist, pos, nrm); }
 }
-__device__ __forceinline__ void col_plane_mesh(const DevModel& m, const float* pp, const float* pR, const float* mp,
-                                            const float* mR, int mesh, LaneContacts& o) {
-  const HullRef h = get_hull(m, mesh);
-  float n[3];
+__device__ __forceinline__ int col_plane_mesh_wave(const HullLane& h, const float* pp, const float* pR, const float* mp,
+                                                const float* mR, const LaneContacts& owner) {
+  const int lane = threadIdx.x;
+  float n[3], wv[3];
   matcol(pR, 2, n);
+  matvec(mR, h.v, wv);
+  for (int i = 0; i < 3; i++) wv[i] += mp[i];
+  const float dist = (wv[0] - pp[0]) * n[0] + (wv[1] - pp[1]) * n[1] + (wv[2] - pp[2]) * n[2];
+  unsigned long long neg = __ballot(lane < h.nv && dist < 0.f);
   float best[3] = {0.f, 0.f, 0.f}; int bi[3] = {-1, -1, -1};
-  for (int v = 0; v < h.nv; v++) {
-    float wv[3];
-    matvec(mR, h.v[v], wv);
-    const float dist = (wv[0] + mp[0] - pp[0]) * n[0] + (wv[1] + mp[1] - pp[1]) * n[1] + (wv[2] + mp[2] - pp[2]) * n[2];
-    if (dist >= 0.f) continue;
-    if (bi[0] < 0 || dist < best[0]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = best[0]; bi[1] = bi[0]; best[0] = dist; bi[0] = v; }
-    else if (bi[1] < 0 || dist < best[1]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = dist; bi[1] = v; }
-    else if (bi[2] < 0 || dist < best[2]) { best[2] = dist; bi[2] = v; }
+  while (neg) {                       // the three lowest vertices, inserted in vertex order
+    const int v = __ffsll((long long)neg) - 1;
+    neg &= neg - 1;
+    const float dv = rl(dist, v);
+    if (bi[0] < 0 || dv < best[0]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = best[0]; bi[1] = bi[0]; best[0] = dv; bi[0] = v; }
+    else if (bi[1] < 0 || dv < best[1]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = dv; bi[1] = v; }
+    else if (bi[2] < 0 || dv < best[2]) { best[2] = dv; bi[2] = v; }
   }
+  int cnt = 0;
+#pragma unroll
   for (int s = 0; s < 3; s++) {
     if (bi[s] < 0) continue;
-    float wv[3], pos[3];
-    matvec(mR, h.v[bi[s]], wv);
-    for (int i = 0; i < 3; i++) pos[i] = wv[i] + mp[i] - 0.5f * best[s] * n[i];
-    lc_push(o, best[s], pos, n);
+    float pos[3];
+    for (int i = 0; i < 3; i++) pos[i] = rl(wv[i], bi[s]) - 0.5f * best[s] * n[i];
+    if (lane == 0) { LaneContacts o = owner; lc_put(o, cnt, best[s], pos, n); }
+    cnt++;
   }
+  return cnt;
 }
-__device__ __forceinline__ void col_capsule_mesh(const DevModel& m, const float* cp, const float* cR, const float* cs,
-                                              const float* mp, const float* mR, int mesh, LaneContacts& o) {
-  const HullRef h = get_hull(m, mesh);
+__device__ __forceinline__ int col_capsule_mesh_wave(const HullLane& h, const float* cp, const float* cR, const float* cs,
+                                                  const float* mp, const float* mR, const LaneContacts& owner) {
   float ax[3], rel[3], pc[3], al[3], a[3], d[3];
   matcol(cR, 2, ax);
   for (int i = 0; i < 3; i++) rel[i] = cp[i] - mp[i];
   mattvec(mR, rel, pc); mattvec(mR, ax, al);
   for (int i = 0; i < 3; i++) { a[i] = pc[i] - cs[1] * al[i]; d[i] = 2.f * cs[1] * al[i]; }
   const float r = cs[0];
-  int f0, f1, fm;
-  const float v0 = hull_line_max(h, a, d, 0.f, f0), v1 = hull_line_max(h, a, d, 1.f, f1);
-  const float s0 = h.pl[f0][0] * d[0] + h.pl[f0][1] * d[1] + h.pl[f0][2] * d[2];
-  const float s1 = h.pl[f1][0] * d[0] + h.pl[f1][1] * d[1] + h.pl[f1][2] * d[2];
+  float p0[4], p1[4], pm[4], pl_[4], pr_[4];
+  const float v0 = hull_max_wave(h, a[0], a[1], a[2], p0);
+  const float v1 = hull_max_wave(h, a[0] + d[0], a[1] + d[1], a[2] + d[2], p1);
+  const float s0 = p0[0] * d[0] + p0[1] * d[1] + p0[2] * d[2];
+  const float s1 = p1[0] * d[0] + p1[1] * d[1] + p1[2] * d[2];
   float ts, vs, nmin[3];
-  if (s0 >= 0.f) { ts = 0.f; vs = v0; for (int i = 0; i < 3; i++) nmin[i] = h.pl[f0][i]; }
-  else if (s1 <= 0.f) { ts = 1.f; vs = v1; for (int i = 0; i < 3; i++) nmin[i] = h.pl[f1][i]; }
+  if (s0 >= 0.f) { ts = 0.f; vs = v0; for (int i = 0; i < 3; i++) nmin[i] = p0[i]; }
+  else if (s1 <= 0.f) { ts = 1.f; vs = v1; for (int i = 0; i < 3; i++) nmin[i] = p1[i]; }
   else {
-    float tl = 0.f, vl = v0, sl = s0, tr = 1.f, vr = v1, sr = s1; int fl = f0, fr = f1;
+    float tl = 0.f, vl = v0, sl = s0, tr = 1.f, vr = v1, sr = s1;
+    for (int i = 0; i < 4; i++) { pl_[i] = p0[i]; pr_[i] = p1[i]; }
     ts = 0.f; vs = v0;
     for (int it = 0; it < 8; it++) {
       float t = ((vr - sr * tr) - (vl - sl * tl)) / (sl - sr);
       t = fminf(fmaxf(t, tl), tr);
-      const float v = hull_line_max(h, a, d, t, fm);
+      const float v = hull_max_wave(h, a[0] + t * d[0], a[1] + t * d[1], a[2] + t * d[2], pm);
       const float lineval = vl + sl * (t - tl);
       ts = t; vs = v;
       if (v <= lineval + 1e-7f) break;
-      const float sm = h.pl[fm][0] * d[0] + h.pl[fm][1] * d[1] + h.pl[fm][2] * d[2];
-      if (sm < 0.f) { tl = t; vl = v; sl = sm; fl = fm; } else { tr = t; vr = v; sr = sm; fr = fm; }
+      const float sm = pm[0] * d[0] + pm[1] * d[1] + pm[2] * d[2];
+      if (sm < 0.f) { tl = t; vl = v; sl = sm; for (int i = 0; i < 4; i++) pl_[i] = pm[i]; }
+      else { tr = t; vr = v; sr = sm; for (int i = 0; i < 4; i++) pr_[i] = pm[i]; }
     }
     const float lam = sr / (sr - sl);   // zero sub-gradient combination of the two tied faces
-    for (int i = 0; i < 3; i++) nmin[i] = lam * h.pl[fl][i] + (1.f - lam) * h.pl[fr][i];
+    for (int i = 0; i < 3; i++) nmin[i] = lam * pl_[i] + (1.f - lam) * pr_[i];
     normalize3(nmin);
   }
   // candidates in the order of the sequential list (end 0, end 1, interior minimum), at most two contacts
-  float tc[3] = {0.f, 1.f, ts}, vc[3] = {v0, v1, vs}, nc3[3][3];
-  for (int i = 0; i < 3; i++) { nc3[0][i] = h.pl[f0][i]; nc3[1][i] = h.pl[f1][i]; nc3[2][i] = nmin[i]; }
   const bool c0 = v0 < r, c1 = v1 < r;
-  bool cv[3] = {c0, c1, false};
-  if (!(c0 && c1) && vs < r) cv[2] = !((c0 && fabsf(ts) < 1e-4f) || (c1 && fabsf(ts - 1.f) < 1e-4f));
+  bool c2 = false;
+  if (!(c0 && c1) && vs < r) c2 = !((c0 && fabsf(ts) < 1e-4f) || (c1 && fabsf(ts - 1.f) < 1e-4f));
   int cnt = 0;
 #pragma unroll
   for (int q = 0; q < 3; q++) {
-    if (!cv[q] || cnt >= 2) continue;
-    const float* pl = nc3[q];
+    const bool on = q == 0 ? c0 : (q == 1 ? c1 : c2);
+    if (!on || cnt >= 2) continue;
+    const float* pl = q == 0 ? p0 : (q == 1 ? p1 : nmin);
+    const float tq = q == 0 ? 0.f : (q == 1 ? 1.f : ts), vq = q == 0 ? v0 : (q == 1 ? v1 : vs);
     float pos[3], nrm[3], pw[3], nw[3];
-    for (int i = 0; i < 3; i++) { const float c = a[i] + tc[q] * d[i]; nrm[i] = -pl[i]; pos[i] = c - pl[i] * 0.5f * (r + vc[q]); }
+    for (int i = 0; i < 3; i++) { const float c = a[i] + tq * d[i]; nrm[i] = -pl[i]; pos[i] = c - pl[i] * 0.5f * (r + vq); }
     matvec(mR, pos, pw); matvec(mR, nrm, nw);
     for (int i = 0; i < 3; i++) pw[i] += mp[i];
-    lc_push(o, vc[q] - r, pw, nw);
+    if (threadIdx.x == 0) { LaneContacts o = owner; lc_put(o, cnt, vq - r, pw, nw); }
     cnt++;
   }
+  return cnt;
 }
-__device__ __forceinline__ void col_box_mesh(const DevModel& m, const float* bp, const float* bR, const float* bh,
-                                          const float* mp, const float* mR, int mesh, float mesh_rbound, LaneContacts& o) {
-  const HullRef h = get_hull(m, mesh);
-  const float rb2 = mesh_rbound * mesh_rbound * 1.0001f + 1e-12f;
-  for (int v = 0; v < h.nv; v++) {
+__device__ __forceinline__ int col_box_mesh_wave(const HullLane& h, const float* bp, const float* bR, const float* bh,
+                                              const float* mp, const float* mR, float mesh_rbound, const LaneContacts& owner) {
+  const int lane = threadIdx.x;
+  Deep4 keep{0, 0.f, 0.f, 0.f, 0.f};
+  {                                   // hull vertices inside the box: one vertex per lane, kept in vertex order
     float wv[3], rel[3], p[3];
-    matvec(mR, h.v[v], wv);
+    matvec(mR, h.v, wv);
     for (int i = 0; i < 3; i++) { wv[i] += mp[i]; rel[i] = wv[i] - bp[i]; }
     mattvec(bR, rel, p);
     float depth = 1e30f; int k = 0;
+#pragma unroll
     for (int i = 0; i < 3; i++) { const float dd = bh[i] - fabsf(p[i]); if (dd < depth) { depth = dd; k = i; } }
-    if (depth <= 0.f) continue;
-    float nl[3] = {0.f, 0.f, 0.f}, nw[3], pos[3];
-    const float sg = p[k] >= 0.f ? 1.f : -1.f;
-    nl[0] = k == 0 ? sg : 0.f; nl[1] = k == 1 ? sg : 0.f; nl[2] = k == 2 ? sg : 0.f;
+    const float sg = (k == 0 ? p[0] : (k == 1 ? p[1] : p[2])) >= 0.f ? 1.f : -1.f;
+    float nl[3] = {k == 0 ? sg : 0.f, k == 1 ? sg : 0.f, k == 2 ? sg : 0.f}, nw[3], pos[3];
     matvec(bR, nl, nw);
     for (int i = 0; i < 3; i++) pos[i] = wv[i] + nw[i] * 0.5f * depth;
-    lc_keep_deepest(o, -depth, pos, nw);
+    unsigned long long pen = __ballot(lane < h.nv && depth > 0.f);
+    while (pen) {
+      const int v = __ffsll((long long)pen) - 1;
+      pen &= pen - 1;
+      const float pv[3] = {rl(pos[0], v), rl(pos[1], v), rl(pos[2], v)}, nv[3] = {rl(nw[0], v), rl(nw[1], v), rl(nw[2], v)};
+      deep4_add(keep, owner, -rl(depth, v), pv, nv);
+    }
   }
-  for (int c = 0; c < 8; c++) {
+  const float rb2 = mesh_rbound * mesh_rbound * 1.0001f + 1e-12f;
+  for (int c = 0; c < 8; c++) {       // box corners inside the hull
     float loc[3] = {(c & 1 ? bh[0] : -bh[0]), (c & 2 ? bh[1] : -bh[1]), (c & 4 ? bh[2] : -bh[2])}, wc[3], rel[3], p[3];
     matvec(bR, loc, wc);
     for (int i = 0; i < 3; i++) { wc[i] += bp[i]; rel[i] = wc[i] - mp[i]; }
     mattvec(mR, rel, p);
     if (dot3(p, p) > rb2) continue;        // outside the hull's bounding sphere: cannot be inside the hull
-    const float zero[3] = {0.f, 0.f, 0.f}; int f;
-    const float s = hull_line_max(h, p, zero, 0.f, f);
+    float pf[4];
+    const float s = hull_max_wave(h, p[0], p[1], p[2], pf);
     if (s >= 0.f) continue;
-    float nl[3] = {-h.pl[f][0], -h.pl[f][1], -h.pl[f][2]}, nw[3], pos[3];
+    float nl[3] = {-pf[0], -pf[1], -pf[2]}, nw[3], pos[3];
     matvec(mR, nl, nw);
     for (int i = 0; i < 3; i++) pos[i] = wc[i] + nw[i] * 0.5f * s;
-    lc_keep_deepest(o, s, pos, nw);
+    deep4_add(keep, owner, s, pos, nw);
   }
+  return keep.n;
 }
 
 // tangents from the normal (same rule as the oracle's ho_make_frame)
@@ -501,7 +543,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
     const int p = ps * NT + tid;
     LaneContacts lc{0, &w.col_lc[tid]};
     int g1 = 0, g2 = 0;
-    bool isbb = false;
+    bool isbb = false, ismesh = false;
     if (p < m.npair) {
       g1 = m.pair_geom1[p]; g2 = m.pair_geom2[p];
       const int t1 = m.pair_type1[p], t2 = m.pair_type2[p];
@@ -516,6 +558,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         test = (p2[0] - p1[0]) * R1[2] + (p2[1] - p1[1]) * R1[5] + (p2[2] - p1[2]) * R1[8] <= bound;
       }
       isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
+      ismesh = test && t2 == HOIC_GEOM_MESH;
       if (isbb) {
         // per-lane pre-test on the six face axes: a pair separated by more than the margin along a face normal has no
         // contact and does not take a turn in the (sequential) wave-cooperative routine below
@@ -532,19 +575,13 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
           if (pa_ < -mg || pb_ < -mg) isbb = false;
         }
       }
-      if (test && !isbb) {
+      if (test && !isbb && !ismesh) {
         const float s1[3] = {m.pair_size1[p][0], m.pair_size1[p][1], m.pair_size1[p][2]};
         const float s2[3] = {m.pair_size2[p][0], m.pair_size2[p][1], m.pair_size2[p][2]};
         if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_CAPSULE) col_plane_capsule(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_BOX) col_plane_box(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_CAPSULE) col_capsule_capsule(p1, R1, s1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_BOX) col_capsule_box(p1, R1, s1, p2, R2, s2, lc);
-        else if (t2 == HOIC_GEOM_MESH) {
-          const int mesh = m.pair_mesh[p];
-          if (t1 == HOIC_GEOM_CAPSULE) col_capsule_mesh(m, p1, R1, s1, p2, R2, mesh, lc);
-          else if (t1 == HOIC_GEOM_BOX) col_box_mesh(m, p1, R1, s1, p2, R2, mesh, m.geom_rbound[g2], lc);
-          else if (t1 == HOIC_GEOM_PLANE) col_plane_mesh(m, p1, R1, p2, R2, mesh, lc);
-        }
       }
     }
     // box-box pairs: one after the other, the whole wave on each (col_box_box_wave)
@@ -562,6 +599,27 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         for (int i = 0; i < 9; i++) { RA[i] = w.gxmat[ga][i]; RB[i] = w.gxmat[gb][i]; }
         const LaneContacts owner{0, &w.col_lc[L]};
         const int nn = col_box_box_wave(Pa, RA, Ha, Pb, RB, Hb, owner, w.col_poly);
+        if (tid == L) lc.n = nn;
+      }
+      wsync();
+    }
+    // mesh pairs: likewise one after the other; the hull stays in the lanes' registers while consecutive pairs share it
+    {
+      unsigned long long mm = __ballot(ismesh);
+      HullLane hull; int cur = -1;
+      while (mm) {
+        const int L = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const int pp = ps * NT + L, ga = m.pair_geom1[pp], gb = m.pair_geom2[pp], ta = m.pair_type1[pp], mesh = m.pair_mesh[pp];
+        if (mesh != cur) { hull_lane_load(m, mesh, hull); cur = mesh; }
+        float Pa[3], RA[9], Sa[3], Pb[3], RB[9];
+        for (int i = 0; i < 3; i++) { Pa[i] = w.gxpos[ga][i]; Pb[i] = w.gxpos[gb][i]; Sa[i] = m.pair_size1[pp][i]; }
+        for (int i = 0; i < 9; i++) { RA[i] = w.gxmat[ga][i]; RB[i] = w.gxmat[gb][i]; }
+        const LaneContacts owner{0, &w.col_lc[L]};
+        int nn;
+        if (ta == HOIC_GEOM_CAPSULE) nn = col_capsule_mesh_wave(hull, Pa, RA, Sa, Pb, RB, owner);
+        else if (ta == HOIC_GEOM_BOX) nn = col_box_mesh_wave(hull, Pa, RA, Sa, Pb, RB, m.geom_rbound[gb], owner);
+        else nn = col_plane_mesh_wave(hull, Pa, RA, Pb, RB, owner);
         if (tid == L) lc.n = nn;
       }
       wsync();

@@ -448,7 +448,7 @@ __device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, con
 
 __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt, double* warm_lam) {
   const int tid = threadIdx.x;
-  const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025, eps = 1e-7;
+  const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025;
   if (!cfg.c.explain_force)
     return sqrtf(dot3(vf, vf)) + (float)w_t * sqrtf(dot3(vt, vt));
   const int nq = m.nq, ob = m.obj_body, lastg = m.ngeom - 1;

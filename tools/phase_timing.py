@@ -7,9 +7,10 @@ from hoic_amd import lib, mjcf, motions
 from hoic_amd.config import Config
 lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), os.environ.get("HOIC_LIB", "libhoic_hip_timing.so"))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-blob = open(mjcf.packaged_model_path('box'), 'rb').read()
+OBJ = sys.argv[2] if len(sys.argv) > 2 else 'box'
+blob = open(mjcf.packaged_model_path(OBJ), 'rb').read()
 model = mjcf.CompiledModel.from_blob(blob)
-cfg = Config('box_future5_light_add_geom'); cfg.update_adaptive_params(0)
+cfg = Config(f'{OBJ}_future5_light_add_geom'); cfg.update_adaptive_params(0)
 ex = motions.synthetic_expert(model, 17, 600)
 sim = lib.BatchedSim(blob, N)
 sim.set_config(cfg.jkp, cfg.jkd, cfg.torque_lim)
