@@ -558,3 +558,26 @@ def test_step_range_matches_whole_batch(box_blob, setup):
     assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(ta, tb)
     with pytest.raises(lib.HoicError):
         b_sim.step(act[:8], ns[:8], nst[:8], N - 4, 8)      # range past the last env
+
+
+def test_longest_first_launch_order_changes_no_result(box_blob, setup, monkeypatch):
+    """HOIC_REORDER=1 (workgroups dispatched by the measured duration of each env's previous pass) only changes which
+    CU runs an env: states and outputs stay bit-identical; hoic_env_durations reports the sort keys."""
+    cfg, ex, thresh = setup
+    N = 192
+    a_sim = _sim(box_blob, N, cfg, ex, thresh)
+    monkeypatch.setenv("HOIC_REORDER", "1")
+    b_sim = _sim(box_blob, N, cfg, ex, thresh)
+    monkeypatch.delenv("HOIC_REORDER")
+    g = torch.Generator().manual_seed(11)
+    seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(0, 150, (N,), generator=g, dtype=torch.int32)
+    a_sim.reset(seq, start); b_sim.reset(seq, start)
+    for t in range(5):
+        act = (torch.randn(N, 32, generator=g) * 0.3).cuda()
+        ns = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32).cuda(); nst = torch.randint(0, 100, (N,), generator=g, dtype=torch.int32).cuda()
+        ra = [x.clone() for x in a_sim.step(act, ns, nst)]
+        rb = [x.clone() for x in b_sim.step(act, ns, nst)]
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    sub, post = b_sim.env_durations()
+    assert sub.shape == (N,) and (sub > 0).all() and (post > 0).all()
