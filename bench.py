@@ -46,6 +46,24 @@ def traffic_from_profile(envs):
     return None if best is None else best["traffic_bytes_per_launch"]
 
 
+def issue_profile():
+    """Where the dominant kernel's wave time goes, from the committed SQ counter pass (profiles/*_substep_sq_counters.json):
+    the kernel is instruction-issue / dependency-latency bound, which neither roofline the contract names can express."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_substep_sq_counters.json")))
+    if not files:
+        return None
+    try:
+        c = json.load(open(files[-1]))["per_env_step"]
+        wc = float(c["SQ_WAVE_CYCLES"])
+        return {"source": os.path.basename(files[-1]), "wave_quad_cycles_per_env_step": wc,
+                "issuing_frac": c["SQ_ACTIVE_INST_ANY"] / wc, "waitcnt_frac": c["SQ_WAIT_ANY"] / wc,
+                "issue_stall_frac": c["SQ_WAIT_INST_ANY"] / wc, "valu_insts_per_env_step": c["SQ_INSTS_VALU"],
+                "lds_insts_per_env_step": c["SQ_INSTS_LDS"], "waves_per_simd": 2}
+    except Exception:
+        return None
+
+
 def cpu_worker(args):
     """Time the CPU oracle (float64, scalar) on one core for ~`seconds`; returns env-steps done."""
     seed, seconds = args
@@ -195,6 +213,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(envs_per_launch), "kernel": "hoic_substep_kernel",
                          "kernel_ms": k_ms, "poststep_kernel_ms": sum(post_ms) / max(len(post_ms), 1),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * envs_per_launch, "envs_per_launch": envs_per_launch,
+                         "issue_profile": issue_profile(),
                          "note": "launch durations are HIP-event times on each range's own stream; with 2 ranges in flight a launch "
                                  "shares the GPU with the other range's kernels" if n_groups > 1 else None},
         }
