@@ -364,6 +364,9 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
   return s;
 }
 
+#ifndef HOIC_IMPROVEMENT_TOL
+#define HOIC_IMPROVEMENT_TOL 1e-6f
+#endif
 // ---- Newton with exact line search.  In: M, fsmooth, asmooth, warm, rows.  Out: qacc, fcon (LDS).
 // The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
 // line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
@@ -386,6 +389,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   dev_rows_jar(m, w, rk, w.warm, true, evw);
   const float cw = gw + dev_rows_cost(m, w, dk, rk, D_c, evw);
   const bool usewarm = cw < cs;
+  float cost_prev = usewarm ? cw : cs;
   float qacc = vd ? (usewarm ? wm : a0) : 0.f, Ma = vd ? (usewarm ? Mw : fs) : 0.f;   // M asmooth = fsmooth
   if (usewarm) ev = evw;
   else dev_rows_cost(m, w, dk, rk, D_c, ev);      // forces / curvatures back to the asmooth state
@@ -434,9 +438,18 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     ev.jar_f = fmaf(alpha, jv.jar_f, ev.jar_f); ev.jar_l = fmaf(alpha, jv.jar_l, ev.jar_l);
 #pragma unroll
     for (int k = 0; k < NCSLOT; k++) ev.jar_c[k] = fmaf(alpha, jv.jar_c[k], ev.jar_c[k]);
-    dev_rows_cost(m, w, dk, rk, D_c, ev);
+    const float crow = dev_rows_cost(m, w, dk, rk, D_c, ev);
     const float st = wave_max((tid < m.nv) ? fabsf(dq) / (1.f + fabsf(qacc)) : 0.f);
     if (st < 1e-7f) { it++; break; }
+#ifndef HOIC_NO_IMPROVEMENT_STOP
+    // MuJoCo's second criterion (engine_solver.c: improvement = scale * (oldcost - cost) < tolerance): once a Newton
+    // step no longer lowers the cost, what is left of the gradient is float32 rounding and another Hessian solve
+    // would only polish noise
+    const float cost = crow + wave_sum((tid < m.nv) ? 0.5f * (Ma - fs) * (qacc - a0) : 0.f);
+    const float improvement = scale * (cost_prev - cost);
+    cost_prev = cost;
+    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; break; }
+#endif
   }
   // forces at the final acceleration (the row state already belongs to it)
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);
