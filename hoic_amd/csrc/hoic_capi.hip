@@ -115,7 +115,7 @@ __device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
 // differences) for the post-step kernel.
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                           const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
-                                                          const float* __restrict__ action, int first, int use_order) {
+                                                          const float* __restrict__ action, int first, int use_order, int use_lag) {
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
@@ -159,6 +159,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int nsub = cfg.c.sim_step;
 #endif
   int mode = 0, done_sub = 0;
+  // The quantities of the previous forward pass that the first substep reads (M and bias for the PD torque, motion axes
+  // for the applied forces, contacts for the bookkeeping) were left behind by the previous launch; only an env whose
+  // state was replaced since (reset, set_state, failed step) recomputes them with a forward pass on (qlag, vlag).
+  GPTR(float) lag = as_global(st.lagrec) + (size_t)env * LG_SIZE;
+  if (use_lag && as_global(st.lag_valid)[env] != 0 && nsub > 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) M.r[reg] = lag[LG_M + reg * NT + tid];
+    if (tid < NV) w.bias[tid] = lag[LG_BIAS + tid];
+    for (int k = tid; k < NV * 6; k += NT) w.S[k / 6][k % 6] = lag[LG_S + k];
+    const int nc = (int)lag[LG_NCON];
+    if (tid == 0) w.ncon = nc;
+    if (tid < nc) {
+      for (int i = 0; i < 3; i++) w.c_pos[tid][i] = lag[LG_CPOS + tid * 3 + i];
+      for (int i = 0; i < 9; i++) w.c_frame[tid][i] = lag[LG_CFRAME + tid * 9 + i];
+      const int gg = (int)lag[LG_CGEOM + tid];
+      w.c_g1[tid] = (unsigned char)(gg & 255); w.c_g2[tid] = (unsigned char)(gg >> 8);
+    }
+    if (tid < 3) w.gxpos[2][tid] = oldg[2 * 12 + tid];
+    old_objvel = (tid < 6) ? w.qvel[m.nv - 6 + tid] : 0.f;
+    mode = 1;
+    wsync();
+  }
   while (true) {
     // the model / config pointers are laundered every pass: otherwise the compiler hoists the (loop-invariant)
     // model-constant loads out of the loop and pins them in registers
@@ -238,6 +260,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
   if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
   store_state(st, w, env);
+  if (ok && nsub > 0) {       // hand the last forward pass over to the next launch (it ran on the state that is now qlag, vlag)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) lag[LG_M + reg * NT + tid] = M.r[reg];
+    if (tid < NV) lag[LG_BIAS + tid] = w.bias[tid];
+    for (int k = tid; k < NV * 6; k += NT) lag[LG_S + k] = w.S[k / 6][k % 6];
+    const int nc = w.ncon;
+    if (tid == 0) lag[LG_NCON] = (float)nc;
+    if (tid < nc) {
+      for (int i = 0; i < 3; i++) lag[LG_CPOS + tid * 3 + i] = w.c_pos[tid][i];
+      for (int i = 0; i < 9; i++) lag[LG_CFRAME + tid * 9 + i] = w.c_frame[tid][i];
+      lag[LG_CGEOM + tid] = (float)((int)w.c_g1[tid] | ((int)w.c_g2[tid] << 8));
+    }
+    for (int g = tid; g < m.ngeom; g += NT) {
+      for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
+      for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
+    }
+  }
+  if (tid == 0) as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0;
   if (tid == 0) as_global(st.cost)[env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
 #ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock
   if (tid == 0) {
@@ -328,7 +368,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     dev_kinematics(m, w, w.qpos);
     if (tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
     ev.off = as_global(ex.seq_off)[ns]; ev.len = as_global(ex.seq_len)[ns]; ev.start = nst; ev.cur_t = 0;
-    if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; }
+    if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; as_global(st.lag_valid)[env] = 0; }
     store_state(st, w, env);
   }
   dev_write_obs(m, w, ev, obs + (size_t)io * HOIC_OBS_DIM);
@@ -401,7 +441,7 @@ __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restri
   ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], start, 0};
   if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
   store_state(st, w, env);
-  if (tid == 0) { as_global(st.cur_t)[env] = 0; as_global(st.start)[env] = start; as_global(st.seq)[env] = seq; as_global(st.rfc_score)[env] = 0.f; as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0; }
+  if (tid == 0) { as_global(st.lag_valid)[env] = 0; as_global(st.cur_t)[env] = 0; as_global(st.start)[env] = start; as_global(st.seq)[env] = seq; as_global(st.rfc_score)[env] = 0.f; as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0; }
 }
 
 __global__ __launch_bounds__(NT) void hoic_set_state_kernel(const DevModel* __restrict__ mp, DevState st,
@@ -412,6 +452,7 @@ __global__ __launch_bounds__(NT) void hoic_set_state_kernel(const DevModel* __re
     const float v = tid < nv ? qvel[(size_t)env * nv + tid] : 0.f;
     as_global(st.qvel)[(size_t)env * NV + tid] = v; as_global(st.vlag)[(size_t)env * NV + tid] = v; as_global(st.warm)[(size_t)env * NV + tid] = 0.f;
   }
+  if (tid == 0) as_global(st.lag_valid)[env] = 0;
 }
 __global__ __launch_bounds__(NT) void hoic_get_state_kernel(const DevModel* __restrict__ mp, DevState st, float* __restrict__ qpos,
                                                             float* __restrict__ qvel, int* __restrict__ cur_t) {
@@ -480,6 +521,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
 // ------------------------------------------------------------------------------------------------ host side
 struct hoic_sim {
   bool reorder = false;
+  bool use_lag = true;       // HOIC_NO_LAGREC=1: recompute the lagged forward pass at every launch (development aid)
   int n_envs = 0, device = 0;
   DevModel hm;            // host copy
   DevModel* d_model = nullptr;
@@ -744,7 +786,8 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess &&
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
        hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess &&
-       hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess;
+       hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess &&
+       hipMalloc(&s->st.lagrec, n * LG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.lag_valid, n * 4) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
   ok = hipMalloc(&s->d_ex, sizeof(DevExpert)) == hipSuccess && hipMalloc(&s->d_st, sizeof(DevState)) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
@@ -757,10 +800,12 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.overflow, 0, n * 4); hipMemset(s->st.phase, 0, n * 24 * 8);
   hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
   hipMemset(s->st.cost, 0, 2 * n * 4);
+  hipMemset(s->st.lagrec, 0, n * LG_SIZE * 4); hipMemset(s->st.lag_valid, 0, n * 4);
   hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, 0, s->st.cost, s->st.order, n_envs);   // a valid permutation from the start
   // Off unless HOIC_REORDER=1: at the random-policy start of training the previous step's duration predicts the next
   // one only weakly (correlation 0.1-0.4, tools/dispatch_trace.py) and the measured kernel time is unchanged.
   s->reorder = getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '1';
+  s->use_lag = getenv("HOIC_NO_LAGREC") == nullptr;
   hipDeviceSynchronize();
   return s;
 }
@@ -770,7 +815,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   delete s;
@@ -890,7 +935,7 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   const int use_order = s->reorder && first == 0 && count == s->n_envs;
   if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
   if (e) hipEventRecord(e[0], st);
-  hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order);
+  hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order, s->use_lag ? 1 : 0);
   if (e) hipEventRecord(e[1], st);
   hipLaunchKernelGGL(hoic_poststep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
                      d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs);

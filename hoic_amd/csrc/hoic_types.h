@@ -106,6 +106,16 @@ struct DevExpert {
 static_assert(PB_OBJACC + 6 <= PB_SIZE, "post buffer layout");
 // geom poses at launch start (for the 15-substep finite differences, ho_im4.py:553-559)
 #define OG_SIZE (NG * 12)
+// quantities of an env's last forward pass (the pass on the state before the last integration) that the first substep
+// of the next env step reads (one-substep lag): M in the MReg layout, bias, motion axes, contacts
+#define LG_M 0
+#define LG_BIAS (LG_M + 16 * NT)
+#define LG_S (LG_BIAS + NV)
+#define LG_NCON (LG_S + NV * 6)
+#define LG_CPOS (LG_NCON + 4)
+#define LG_CFRAME (LG_CPOS + MAXCON * 3)
+#define LG_CGEOM (LG_CFRAME + MAXCON * 9)
+#define LG_SIZE (LG_CGEOM + MAXCON)
 
 // persistent per-env state in HBM (row per env)
 struct DevState {
@@ -121,6 +131,8 @@ struct DevState {
   int* overflow; // [n] contact-cap overflow counter
   float* post;   // [n, PB_SIZE]
   float* oldg;   // [n, OG_SIZE]
+  float* lagrec; // [n, LG_SIZE]
+  int* lag_valid; // [n] 0: the record does not belong to (qlag, vlag) (after a reset / set_state / failed step)
   double* qp_lam; // [n, 8] warm start of the residual-force QP: lambda[6], valid flag, pad
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
   unsigned* cost;    // [2, n] shader-clock duration (>> 6) of the env's last substep / post-step pass
