@@ -16,6 +16,7 @@ __device__ int g_trace_bb[1 << 16];     // development aid: box-box turns per wo
 __device__ int g_trace_qp[4 << 16];     // QP iterations / line-search steps / columns / warm per workgroup
 #endif
 #include "hoic_env.h"
+#include "hoic_zfilter.h"
 
 static thread_local std::string g_err;
 static void set_err(const std::string& s) { g_err = s; }
@@ -1014,6 +1015,22 @@ extern "C" int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, co
     set_err("hoic_probe_qp: bad arguments (max_col must be in 1..380)"); return HOIC_ERR_ARG;
   }
   hipLaunchKernelGGL(hoic_probe_qp_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, d_cols, d_ncols, d_rhs, max_col, d_lambda, d_stat);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim) {
+  if (n <= 0 || dim <= 0) return 0;
+  return (int64_t)((n + ZF_ROWS - 1) / ZF_ROWS) * dim * 2;
+}
+extern "C" int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out,
+                                int32_t update, float clip, float* d_y, double* d_scratch, void* stream) {
+  if (n <= 0 || dim <= 0 || !d_x || !d_state_in) { set_err("hoic_zfilter: bad arguments"); return HOIC_ERR_ARG; }
+  if (update && (!d_state_out || !d_scratch || d_state_out == d_state_in)) { set_err("hoic_zfilter: update needs a scratch buffer and a state_out that is not state_in"); return HOIC_ERR_ARG; }
+  const dim3 grid((dim + ZF_NT - 1) / ZF_NT, (n + ZF_ROWS - 1) / ZF_ROWS);
+  hipStream_t st = (hipStream_t)stream;
+  if (update) hipLaunchKernelGGL(hoic_zfilter_moments_kernel, grid, dim3(ZF_NT), 0, st, d_x, n, dim, d_scratch);
+  hipLaunchKernelGGL(hoic_zfilter_apply_kernel, grid, dim3(ZF_NT), 0, st, d_x, n, dim, d_scratch, d_state_in, d_state_out, update, clip, d_y);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }

@@ -1,0 +1,74 @@
+// hoic_zfilter.h — the running observation filter on the device (khrylib ZFilter / RunningStat,
+// uhc/khrylib/utils/zfilter.py:8-73; the sampler calls it on every observation, agent_handmimic.py:463).
+//
+// A batch [n, dim] is pushed as a whole: per 128-row chunk the column means and sums of squared deviations (two passes
+// over the chunk, float64), then the chunks are merged one after the other into the running (count, mean, S) with
+// Chan's pairwise update - the same statistics as pushing the rows one at a time - and every row is normalised with
+// the statistics after the batch:  y = clip((x - mean) / (sqrt(S / (count - 1)) + 1e-8), +-clip).
+// Lane = column: a wave reads 256 contiguous bytes of a row, nothing is reduced across lanes, the result does not
+// depend on the launch geometry.  Two launches replace ~30 small tensor kernels of the host mirror.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define ZF_ROWS 128      // rows per chunk
+#define ZF_NT 64
+
+// partial[(chunk * dim + col) * 2 + {0, 1}] = mean, M2 of the chunk's rows
+__global__ __launch_bounds__(ZF_NT) void hoic_zfilter_moments_kernel(const float* __restrict__ x, int n, int dim,
+                                                                     double* __restrict__ partial) {
+  const int col = blockIdx.x * ZF_NT + threadIdx.x, chunk = blockIdx.y;
+  if (col >= dim) return;
+  const int r0 = chunk * ZF_ROWS, r1 = min(r0 + ZF_ROWS, n);
+  const float* p = x + (size_t)r0 * dim + col;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4, p += (size_t)4 * dim) {
+    s0 += (double)p[0]; s1 += (double)p[dim]; s2 += (double)p[2 * (size_t)dim]; s3 += (double)p[3 * (size_t)dim];
+  }
+  for (; r < r1; r++, p += dim) s0 += (double)p[0];
+  const double mean = ((s0 + s1) + (s2 + s3)) / (double)(r1 - r0);
+  p = x + (size_t)r0 * dim + col;
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+  for (r = r0; r + 4 <= r1; r += 4, p += (size_t)4 * dim) {
+    const double d0 = (double)p[0] - mean, d1 = (double)p[dim] - mean, d2 = (double)p[2 * (size_t)dim] - mean, d3 = (double)p[3 * (size_t)dim] - mean;
+    q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+  }
+  for (; r < r1; r++, p += dim) { const double d0 = (double)p[0] - mean; q0 += d0 * d0; }
+  partial[((size_t)chunk * dim + col) * 2] = mean;
+  partial[((size_t)chunk * dim + col) * 2 + 1] = (q0 + q1) + (q2 + q3);
+}
+
+// state = (count, mean[dim], S[dim]).  Every workgroup merges the chunks of its 64 columns itself (a few hundred
+// flops), the workgroups of chunk 0 write the new state, all normalise the rows of their chunk.
+__global__ __launch_bounds__(ZF_NT) void hoic_zfilter_apply_kernel(const float* __restrict__ x, int n, int dim,
+                                                                   const double* __restrict__ partial,
+                                                                   const double* __restrict__ state_in, double* __restrict__ state_out,
+                                                                   int update, float clip, float* __restrict__ y) {
+  const int col = blockIdx.x * ZF_NT + threadIdx.x, chunk = blockIdx.y;
+  if (col >= dim) return;
+  double cnt = state_in[0], mean = state_in[1 + col], S = state_in[1 + dim + col];
+  if (update) {
+    const int nchunk = (n + ZF_ROWS - 1) / ZF_ROWS;
+    for (int c = 0; c < nchunk; c++) {
+      const double nb = (double)(min((c + 1) * ZF_ROWS, n) - c * ZF_ROWS);
+      const double mb = partial[((size_t)c * dim + col) * 2], Sb = partial[((size_t)c * dim + col) * 2 + 1];
+      const double tot = cnt + nb, delta = mb - mean;
+      S = S + Sb + delta * delta * cnt * nb / tot;
+      mean = mean + delta * nb / tot;
+      cnt = tot;
+    }
+    if (chunk == 0) {
+      state_out[1 + col] = mean; state_out[1 + dim + col] = S;
+      if (col == 0) state_out[0] = cnt;
+    }
+  }
+  if (!y) return;
+  const double var = cnt > 1.0 ? S / fmax(cnt - 1.0, 1.0) : mean * mean;       // zfilter.py:35
+  const double den = sqrt(var) + 1e-8;
+  const int r0 = chunk * ZF_ROWS, r1 = min(r0 + ZF_ROWS, n);
+  const double lim = (double)clip;
+  for (int r = r0; r < r1; r++) {
+    const double v = ((double)x[(size_t)r * dim + col] - mean) / den;
+    y[(size_t)r * dim + col] = (float)fmin(fmax(v, -lim), lim);
+  }
+}

@@ -165,11 +165,16 @@ class BatchZFilter:
     """
 
     def __init__(self, dim, clip=5.0, device="cpu"):
-        self.clip = clip
-        self.n = torch.zeros((), dtype=torch.float64, device=device)
-        self.mean = torch.zeros(dim, dtype=torch.float64, device=device)
-        self.S = torch.zeros(dim, dtype=torch.float64, device=device)
+        self.clip, self.dim = clip, int(dim)
+        # (count, mean[dim], S[dim]) packed in one float64 tensor: the layout of hoic_zfilter (include/hoic.h)
+        self._st = torch.zeros(1 + 2 * self.dim, dtype=torch.float64, device=device)
+        self._alt = None            # the other state buffer of the device path (state_out must not alias state_in)
+        self._scratch = None
         self._base = (self.n.clone(), self.mean.clone(), self.S.clone())     # state at the last sync()
+
+    n = property(lambda self: self._st[0], lambda self, v: self._st[0:1].copy_(torch.as_tensor(v, dtype=torch.float64).reshape(1)))
+    mean = property(lambda self: self._st[1:1 + self.dim], lambda self, v: self._st[1:1 + self.dim].copy_(v))
+    S = property(lambda self: self._st[1 + self.dim:], lambda self, v: self._st[1 + self.dim:].copy_(v))
 
     def push(self, x):
         x = x.to(torch.float64)
@@ -180,13 +185,44 @@ class BatchZFilter:
         colsum = (lambda y: y.view(blk, -1, y.shape[1]).sum(1).sum(0)) if blk else (lambda y: y.sum(0))
         mb = colsum(x) / nb
         Sb = colsum((x - mb) ** 2)
-        tot = self.n + nb
-        delta = mb - self.mean
-        self.S = self.S + Sb + delta * delta * self.n * nb / tot
-        self.mean = self.mean + delta * nb / tot
+        n0, m0, S0 = self.n.clone(), self.mean.clone(), self.S.clone()
+        tot = n0 + nb
+        delta = mb - m0
+        self.S = S0 + Sb + delta * delta * n0 * nb / tot
+        self.mean = m0 + delta * nb / tot
         self.n = tot
 
+    def _device_path(self, x):
+        return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.dim
+
+    def _call_device(self, x, update):
+        """hoic_zfilter: two launches (chunk moments; merge + normalise) instead of ~30 tensor kernels."""
+        from . import lib
+        import ctypes as C
+        L = lib.load()
+        x = x.contiguous()
+        n = x.shape[0]
+        y = torch.empty_like(x)
+        out = scratch = None
+        if update:
+            if self._alt is None:
+                self._alt = torch.empty_like(self._st)
+            need = int(L.hoic_zfilter_scratch_doubles(n, self.dim))
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.float64, device=x.device)
+            out, scratch = self._alt, self._scratch
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = L.hoic_zfilter(n, self.dim, ptr(x), ptr(self._st), ptr(out), int(bool(update)), float(self.clip), ptr(y), ptr(scratch),
+                            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise lib.HoicError(f"hoic_zfilter failed ({rc}): {L.hoic_last_error().decode()}")
+        if update:
+            self._st, self._alt = self._alt, self._st
+        return y
+
     def __call__(self, x, update=True):
+        if self._device_path(x) and self._st.device == x.device:
+            return self._call_device(x, update)
         if update:
             self.push(x)
         # var = S/(n-1), and mean^2 when n == 1 (zfilter.py:35)

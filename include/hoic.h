@@ -127,6 +127,17 @@ int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const fl
                            int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
                            float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream);
 
+/* The running observation filter of the sampler (khrylib ZFilter / RunningStat, uhc/khrylib/utils/zfilter.py:8-73,
+ * called on every observation at agent_handmimic.py:463) on a batch, no handle needed.  d_x [n, dim] float32; state =
+ * (count, mean[dim], S[dim]) as 1 + 2 dim float64 on the device.  update != 0: the batch is merged into the state
+ * first (128-row chunks, Chan's pairwise update in a fixed order: the statistics of pushing the rows one by one) and
+ * the new state goes to d_state_out (must not alias d_state_in); d_scratch holds hoic_zfilter_scratch_doubles(n, dim)
+ * float64.  Then, if d_y is not null, y = clip((x - mean) / (sqrt(var) + 1e-8), +-clip) with var = S / (count - 1)
+ * (mean^2 while count == 1) of the state AFTER the batch -> d_y [n, dim] float32. */
+int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim);
+int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out,
+                     int32_t update, float clip, float* d_y, double* d_scratch, void* stream);
+
 /* The residual-force QP of HandObjMimic4.get_rfc_score (ho_im4.py:1040-1083) on caller-supplied data, n independent
  * problems:  min_x |A x - b|^2 + c.x + 1e-7/2 |x|^2, x >= 0.  d_cols [n, max_col, 7] float32: column k of problem i
  * is (a_k[6], c_k); d_ncols [n] columns in use (<= max_col <= 380); d_rhs [n, 6] float64.  Outputs: d_lambda [n, 6]

@@ -581,3 +581,27 @@ def test_longest_first_launch_order_changes_no_result(box_blob, setup, monkeypat
             assert torch.equal(x, y)
     sub, post = b_sim.env_durations()
     assert sub.shape == (N,) and (sub > 0).all() and (post > 0).all()
+
+
+def test_zfilter_device_path_matches_tensor_path():
+    """hoic_zfilter (two HIP launches) against the tensor implementation of BatchZFilter, itself checked against the
+    reference's ZFilter in tests/test_host.py: same statistics to float64 rounding, same normalised rows, over several
+    pushes of ragged batch sizes; update=False leaves the state alone."""
+    from hoic_amd.rl import BatchZFilter
+    g = torch.Generator().manual_seed(2)
+    dev = torch.device("cuda", 0)
+    a = BatchZFilter(617, clip=5.0, device=dev)          # device path (float32 CUDA batches)
+    b = BatchZFilter(617, clip=5.0, device=dev)          # tensor path, forced below
+    b._device_path = lambda x: False
+    for n in (1, 2048, 2048, 77, 4096, 130):
+        x = (torch.randn(n, 617, generator=g) * torch.linspace(0.01, 30.0, 617) + torch.linspace(-3, 3, 617)).to(dev)
+        ya = a(x); yb = b(x)
+        assert ya.dtype == torch.float32 and ya.shape == x.shape
+        torch.testing.assert_close(ya, yb, rtol=0, atol=2e-6)
+        assert float(a.n) == float(b.n)
+        torch.testing.assert_close(a.mean, b.mean, rtol=1e-12, atol=1e-12)
+        torch.testing.assert_close(a.S, b.S, rtol=1e-11, atol=1e-9)
+    st = a._st.clone()
+    x = torch.randn(300, 617, generator=g).to(dev)
+    torch.testing.assert_close(a(x, update=False), b(x, update=False), rtol=0, atol=2e-6)
+    assert torch.equal(st, a._st)
