@@ -224,8 +224,14 @@ class AgentHandMimic:
         groups = self._groups()
         G = len(groups)
         use_streams = G > 1
-        c_info_g = [torch.zeros(9, device=dev, dtype=torch.float64) for _ in range(G)]
-        n_done_g = [torch.zeros((), device=dev, dtype=torch.float64) for _ in range(G)]
+        # Per-step outputs go straight into the rollout's [T, N, .] storage (no copy kernels in a range's chain), the
+        # next-episode draws of all T steps are made up front, masks and statistics are derived once at the end.
+        direct = dt == torch.float32 and dev.type == "cuda"
+        rinfo_all = torch.empty(T, N, 9, device=dev, dtype=torch.float32)
+        flags_all = torch.empty(T, N, 4, device=dev, dtype=torch.int32)
+        pct = torch.empty(N, device=dev, dtype=torch.float32)
+        nseq_all, nstart_all = self._draw_episodes(T * N)
+        nseq_all, nstart_all = nseq_all.view(T, N), nstart_all.view(T, N)
         if use_streams:
             main = torch.cuda.current_stream(dev)
             for st_ in self._streams:
@@ -238,23 +244,28 @@ class AgentHandMimic:
                 with ctx:
                     if use_streams and zf_event is not None:
                         self._streams[gi].wait_event(zf_event)
-                    state = self.running_state(obs[sl])
+                    state = self.running_state(obs[sl], out=states[t, sl] if direct else None)
                     if use_streams:
                         zf_event = torch.cuda.Event(); zf_event.record(self._streams[gi])
-                    action = self.policy_net.select_action(state)
-                    nseq, nstart = self._draw_episodes(count)
-                    _, _, done, info = self.env.step(action, nseq, nstart, first, count)
-                    states[t, sl] = state; actions[t, sl] = action
-                    rewards[t, sl] = self.env.c_reward
-                    masks[t, sl] = (~done).to(dt)
-                    c_info_g[gi] += self.env.c_info.sum(0, dtype=torch.float64)
-                    n_done_g[gi] += done.sum()
+                    if state.data_ptr() != states[t, sl].data_ptr():
+                        states[t, sl] = state
+                    if direct:
+                        action = self.policy_net.select_action(state, out=actions[t, sl])
+                        self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count,
+                                      out=(rewards[t, sl], rinfo_all[t, sl], flags_all[t, sl], pct[sl]))
+                    else:
+                        action = self.policy_net.select_action(state)
+                        self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count)
+                        actions[t, sl] = action
+                        rewards[t, sl] = self.env.c_reward; rinfo_all[t, sl] = self.env.c_info; flags_all[t, sl] = self.env.sim.flags[sl]
         if use_streams:
             for st_ in self._streams:
                 main.wait_stream(st_)
+        done_all = flags_all[:, :, 2] != 0
+        masks.copy_((~done_all).to(dt))
+        c_info += rinfo_all.sum((0, 1), dtype=torch.float64)
+        n_done += done_all.sum()
         obs = self.env.get_obs()
-        for gi in range(G):
-            c_info += c_info_g[gi]; n_done += n_done_g[gi]
         self._obs = obs
         if self.distributed:
             self.running_state.sync()          # one observation filter for all ranks from here on

@@ -219,9 +219,12 @@ class BatchedSim:
         _chk(self.L.hoic_reset(self.h, _ptr(ids), n, _ptr(seq), _ptr(start), _ptr(self.obs), self._stream()), "hoic_reset")
         return self.obs
 
-    def step(self, action, next_seq=None, next_start=None, first=0, count=None):
+    def step(self, action, next_seq=None, next_start=None, first=0, count=None, out=None):
         """One env step of all envs, or of the envs [first, first + count) (``action`` / ``next_*`` then hold ``count``
-        rows and the returned tensors are the matching row views); launched on the current torch stream."""
+        rows and the returned tensors are the matching row views); launched on the current torch stream.
+        ``out``: optional (reward [count] f32, reward_info [count, 9] f32, flags [count, 4] i32, percent [count] f32)
+        contiguous tensors to receive those outputs instead of the simulator's own buffers (a rollout writes them
+        straight into its [T, N, .] storage)."""
         t = self.torch
         count = self.n - first if count is None else int(count)
         a = action.to(device=self.device, dtype=t.float32).contiguous()
@@ -231,7 +234,14 @@ class BatchedSim:
             next_start = next_start.to(device=self.device, dtype=t.int32).contiguous()
             assert next_seq.shape == (count,) and next_start.shape == (count,)
         sl = slice(first, first + count)
-        out = (self.obs[sl], self.reward[sl], self.reward_info[sl], self.flags[sl], self.percent[sl])
+        if out is not None:
+            rw, ri, fl, pc = out
+            assert rw.shape == (count,) and ri.shape == (count, NINFO) and fl.shape == (count, 4) and pc.shape == (count,)
+            assert all(x.is_contiguous() and x.device == self.obs.device for x in out)
+            assert rw.dtype == ri.dtype == pc.dtype == t.float32 and fl.dtype == t.int32
+            out = (self.obs[sl], rw, ri, fl, pc)
+        else:
+            out = (self.obs[sl], self.reward[sl], self.reward_info[sl], self.flags[sl], self.percent[sl])
         if first == 0 and count == self.n:
             _chk(self.L.hoic_step(self.h, _ptr(a), *[_ptr(x) for x in out], _ptr(next_seq), _ptr(next_start), self._stream()),
                  "hoic_step")

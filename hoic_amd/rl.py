@@ -47,9 +47,11 @@ class PolicyGaussian(nn.Module):
         mean = self.action_mean(self.net(x))
         return mean, self.action_log_std.expand_as(mean)
 
-    def select_action(self, x, mean_action=False):
+    def select_action(self, x, mean_action=False, out=None):
         mean, log_std = self.forward(x)
-        return mean if mean_action else mean + torch.exp(log_std) * torch.randn_like(mean)
+        if mean_action:
+            return mean if out is None else out.copy_(mean)
+        return torch.addcmul(mean, torch.exp(log_std), torch.randn_like(mean), out=out)     # mean + std * eps
 
     def get_log_prob(self, x, action):
         mean, log_std = self.forward(x)
@@ -195,14 +197,14 @@ class BatchZFilter:
     def _device_path(self, x):
         return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.dim
 
-    def _call_device(self, x, update):
+    def _call_device(self, x, update, out=None):
         """hoic_zfilter: two launches (chunk moments; merge + normalise) instead of ~30 tensor kernels."""
         from . import lib
         import ctypes as C
         L = lib.load()
         x = x.contiguous()
         n = x.shape[0]
-        y = torch.empty_like(x)
+        y = out if (out is not None and out.is_contiguous() and out.dtype == torch.float32 and out.shape == x.shape) else torch.empty_like(x)
         out = scratch = None
         if update:
             if self._alt is None:
@@ -220,9 +222,10 @@ class BatchZFilter:
             self._st, self._alt = self._alt, self._st
         return y
 
-    def __call__(self, x, update=True):
+    def __call__(self, x, update=True, out=None):
+        """``out``: optional float32 tensor the normalised rows are written into (device path; otherwise ignored)."""
         if self._device_path(x) and self._st.device == x.device:
-            return self._call_device(x, update)
+            return self._call_device(x, update, out)
         if update:
             self.push(x)
         # var = S/(n-1), and mean^2 when n == 1 (zfilter.py:35)
