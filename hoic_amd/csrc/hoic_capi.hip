@@ -111,12 +111,72 @@ __device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
   wsync();
 }
 
+// ---- what follows the substeps of an env step (HandObjMimic4.step after do_simulation, ho_im4.py:631-662): contact
+// averaging, the residual-force QP (float64), termination, reward, the optional in-launch reset and the 617-float
+// observation.  Expects in the workspace: final qpos / qvel, the clipped action, body / geom poses and the contact sums
+// of the last forward pass, the 15-substep finite differences in sc.post.
+__device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig& cfg, Work& w, const DevExpert& ex, const DevState& st,
+                                             ExpertView& ev, int env, int io, bool ok, int solver_iter, const float* vf, const float* vt,
+                                             float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
+                                             int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
+                                             const int* __restrict__ next_start) {
+  const int tid = threadIdx.x;
+  float rfc_score = 0.f;
+  if (ok) {
+    dev_classify_contact(m, w);                                                                // :562
+    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
+    if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
+  }
+  asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
+  ev.cur_t += 1;                                                                                // :641
+  float df[5];
+  dev_ho_diff(m, w, ev, df);
+  const bool body_fail = df[0] > cfg.c.pos_diff_thresh || df[1] > cfg.c.rot_diff_thresh || df[2] > cfg.c.jpos_diff_thresh ||
+                         df[3] > cfg.c.obj_pos_diff_thresh || df[4] > cfg.c.obj_rot_diff_thresh;
+  bool fail = !ok;
+  if (cfg.mode_train) fail = fail || body_fail;                                                 // :655-656
+  const int expert_len = ev.len - ev.start;
+  const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
+  const bool done = fail || end;
+  float rw[10];
+  dev_reward(m, cfg, w, ev, rfc_score, rw);
+  float r = rw[0];
+  if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                     // agent_handmimic.py:479-480
+  if (tid == 0) {
+    reward[io] = r;
+    flags[4 * io] = fail; flags[4 * io + 1] = end; flags[4 * io + 2] = done; flags[4 * io + 3] = solver_iter;
+    percent[io] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
+    as_global(st.rfc_score)[env] = rfc_score;
+  }
+  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
+  if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
+    const int ns = next_seq[io], nst = next_start[io];
+    wsync();
+    dev_reset_state(m, w, ex, ns, nst);
+    dev_kinematics(m, w, w.qpos);
+    if (tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
+    ev.off = as_global(ex.seq_off)[ns]; ev.len = as_global(ex.seq_len)[ns]; ev.start = nst; ev.cur_t = 0;
+    if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; as_global(st.lag_valid)[env] = 0; }
+    store_state(st, w, env);
+  }
+  dev_write_obs(m, w, ev, obs + (size_t)io * HOIC_OBS_DIM);
+  if (tid == 0) as_global(st.cur_t)[env] = ev.cur_t;
+}
+
 // ---- kernel 1 of a step: the 15 substeps (control glue + dynamics + contact solve + integration), f32.
 // Leaves the new state in HBM and a hand-over record (lagged body / geom poses, contact sums, 15-substep finite
 // differences) for the post-step kernel.
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                           const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
-                                                          const float* __restrict__ action, int first, int use_order, int use_lag) {
+                                                          const float* __restrict__ action, int first, int use_order, int use_lag,
+                                                          float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
+                                                          int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
+                                                          const int* __restrict__ next_start, int n_envs) {
+  // obs != nullptr (HOIC_FUSED_STEP=1): the post-step work (dev_poststep) runs at the end of this launch, on the
+  // workspace as it stands, instead of in hoic_poststep_kernel behind a 2.8 KB hand-over record per env.  One launch
+  // per env step, but 153 KB of code, 256 registers and 288 B of scratch; measured equal to the two-launch form both
+  // for whole-batch steps and in the two-range rollout, so the two-launch form stays the default.
+  const bool fused = obs != nullptr;
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
@@ -237,29 +297,41 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (++done_sub >= nsub) break;
   }
   PT(0);
-  if (ok) {
-    const float dt = (float)nsub * m.timestep, idt = 1.f / dt;
-    if (tid < 6) post[PB_OBJACC + tid] = (w.qvel[m.nv - 6 + tid] - old_objvel) * idt;                 // :554
+  {   // 15-substep finite differences (:554-559): to the post-step workspace (fused) or the hand-over record
+    const float dt = (float)nsub * m.timestep, idt = ok ? 1.f / dt : 0.f;
+    if (tid < 6) {
+      const float v = ok ? (w.qvel[m.nv - 6 + tid] - old_objvel) * idt : 0.f;                           // :554
+      if (fused) w.sc.post.obj_avg_acc[tid] = v; else post[PB_OBJACC + tid] = v;
+    }
     for (int g = tid; g < m.ngeom; g += NT) {
-      for (int i = 0; i < 3; i++) post[PB_GVEL + g * 3 + i] = (w.gxpos[g][i] - oldg[g * 12 + i]) * idt;   // :555
-      float Rd[9], aa[3], Ro[9];
-      for (int i = 0; i < 9; i++) Ro[i] = oldg[g * 12 + 3 + i];
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
-          float s = 0.f;
-          for (int k = 0; k < 3; k++) s += w.gxmat[g][3 * i + k] * Ro[3 * j + k];
-          Rd[3 * i + j] = s;
-        }
-      dev_matrix_to_axis_angle(Rd, aa);                                                         // :556-559
-      for (int i = 0; i < 3; i++) post[PB_GANGVEL + g * 3 + i] = aa[i] * idt;
+      float gv[3] = {0.f, 0.f, 0.f}, ga[3] = {0.f, 0.f, 0.f};
+      if (ok) {
+        for (int i = 0; i < 3; i++) gv[i] = (w.gxpos[g][i] - oldg[g * 12 + i]) * idt;                  // :555
+        float Rd[9], aa[3], Ro[9];
+        for (int i = 0; i < 9; i++) Ro[i] = oldg[g * 12 + 3 + i];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) {
+            float sm = 0.f;
+            for (int k = 0; k < 3; k++) sm += w.gxmat[g][3 * i + k] * Ro[3 * j + k];
+            Rd[3 * i + j] = sm;
+          }
+        dev_matrix_to_axis_angle(Rd, aa);                                                         // :556-559
+        for (int i = 0; i < 3; i++) ga[i] = aa[i] * idt;
+      }
+      for (int i = 0; i < 3; i++) {
+        if (fused) { w.sc.post.gvel[g][i] = gv[i]; w.sc.post.gangvel[g][i] = ga[i]; }
+        else { post[PB_GVEL + g * 3 + i] = gv[i]; post[PB_GANGVEL + g * 3 + i] = ga[i]; }
+      }
     }
   }
-  if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
-  for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
-  for (int k = tid; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
-  for (int k = tid; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
-  for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
-  if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
+  if (!fused) {
+    if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
+    for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
+    for (int k = tid; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
+    for (int k = tid; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
+    for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
+    if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
+  }
   store_state(st, w, env);
   if (ok && nsub > 0) {       // hand the last forward pass over to the next launch (it ran on the state that is now qlag, vlag)
 #pragma unroll
@@ -279,7 +351,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
   if (tid == 0) as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0;
-  if (tid == 0) as_global(st.cost)[env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
+  const long long clk1 = (long long)__builtin_readcyclecounter();
+  if (tid == 0) as_global(st.cost)[env] = (unsigned)((clk1 - clk0) >> 6);
+  if (fused) {
+    wsync();
+    dev_poststep(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, vf, vt, obs, reward, reward_info, flags, percent, next_seq, next_start);
+    if (tid == 0) as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk1) >> 6);
+  }
 #ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock
   if (tid == 0) {
     GPTR(long long) tr = as_global(st.phase) + (size_t)env * 24;
@@ -334,47 +412,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
     vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
   }
-  float rfc_score = 0.f;
-  if (ok) {
-    dev_classify_contact(m, w);                                                                // :562
-    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
-    if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
-  }
-  asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
-  ev.cur_t += 1;                                                                                // :641
-  float df[5];
-  dev_ho_diff(m, w, ev, df);
-  const bool body_fail = df[0] > cfg.c.pos_diff_thresh || df[1] > cfg.c.rot_diff_thresh || df[2] > cfg.c.jpos_diff_thresh ||
-                         df[3] > cfg.c.obj_pos_diff_thresh || df[4] > cfg.c.obj_rot_diff_thresh;
-  bool fail = !ok;
-  if (cfg.mode_train) fail = fail || body_fail;                                                 // :655-656
-  const int expert_len = ev.len - ev.start;
-  const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
-  const bool done = fail || end;
-  float rw[10];
-  dev_reward(m, cfg, w, ev, rfc_score, rw);
-  float r = rw[0];
-  if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                     // agent_handmimic.py:479-480
+  dev_poststep(m, cfg, w, ex, st, ev, env, io, ok, solver_iter, vf, vt, obs, reward, reward_info, flags, percent, next_seq, next_start);
   if (tid == 0) {
-    reward[io] = r;
-    flags[4 * io] = fail; flags[4 * io + 1] = end; flags[4 * io + 2] = done; flags[4 * io + 3] = solver_iter;
-    percent[io] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
-    as_global(st.rfc_score)[env] = rfc_score;
-  }
-  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
-  if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
-    const int ns = next_seq[io], nst = next_start[io];
-    wsync();
-    dev_reset_state(m, w, ex, ns, nst);
-    dev_kinematics(m, w, w.qpos);
-    if (tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
-    ev.off = as_global(ex.seq_off)[ns]; ev.len = as_global(ex.seq_len)[ns]; ev.start = nst; ev.cur_t = 0;
-    if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; as_global(st.lag_valid)[env] = 0; }
-    store_state(st, w, env);
-  }
-  dev_write_obs(m, w, ev, obs + (size_t)io * HOIC_OBS_DIM);
-  if (tid == 0) {
-    as_global(st.cur_t)[env] = ev.cur_t;
     as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
 #ifdef HOIC_TRACE_DISPATCH
     GPTR(long long) tr = as_global(st.phase) + (size_t)env * 24;
@@ -521,6 +560,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
 
 // ------------------------------------------------------------------------------------------------ host side
 struct hoic_sim {
+  bool fused = false;        // HOIC_FUSED_STEP=1: post-step work at the end of the substep launch (measured: no gain)
   bool reorder = false;
   bool use_lag = true;       // HOIC_NO_LAGREC=1: recompute the lagged forward pass at every launch (development aid)
   int n_envs = 0, device = 0;
@@ -807,6 +847,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   // one only weakly (correlation 0.1-0.4, tools/dispatch_trace.py) and the measured kernel time is unchanged.
   s->reorder = getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '1';
   s->use_lag = getenv("HOIC_NO_LAGREC") == nullptr;
+  s->fused = getenv("HOIC_FUSED_STEP") != nullptr && getenv("HOIC_FUSED_STEP")[0] == '1';
   hipDeviceSynchronize();
   return s;
 }
@@ -936,10 +977,18 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   const int use_order = s->reorder && first == 0 && count == s->n_envs;
   if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
   if (e) hipEventRecord(e[0], st);
-  hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order, s->use_lag ? 1 : 0);
-  if (e) hipEventRecord(e[1], st);
-  hipLaunchKernelGGL(hoic_poststep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs);
+  if (s->fused) {     // one launch: the post-step work runs at the end of the substep kernel
+    hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+                       s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs);
+    if (e) hipEventRecord(e[1], st);
+  } else {
+    hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+                       s->use_lag ? 1 : 0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
+                       (const int*)nullptr, (const int*)nullptr, s->n_envs);
+    if (e) hipEventRecord(e[1], st);
+    hipLaunchKernelGGL(hoic_poststep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs);
+  }
   if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());
   return HOIC_OK;

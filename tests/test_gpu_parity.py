@@ -605,3 +605,24 @@ def test_zfilter_device_path_matches_tensor_path():
     x = torch.randn(300, 617, generator=g).to(dev)
     torch.testing.assert_close(a(x, update=False), b(x, update=False), rtol=0, atol=2e-6)
     assert torch.equal(st, a._st)
+
+
+def test_fused_step_matches_two_launches(box_blob, setup, monkeypatch):
+    """HOIC_FUSED_STEP=1 (post-step work at the end of the substep launch) gives bit-identical outputs and states."""
+    cfg, ex, thresh = setup
+    N = 128
+    a_sim = _sim(box_blob, N, cfg, ex, thresh)
+    monkeypatch.setenv("HOIC_FUSED_STEP", "1")
+    b_sim = _sim(box_blob, N, cfg, ex, thresh)
+    monkeypatch.delenv("HOIC_FUSED_STEP")
+    g = torch.Generator().manual_seed(12)
+    seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(120, 260, (N,), generator=g, dtype=torch.int32)
+    a_sim.reset(seq, start); b_sim.reset(seq, start)
+    for t in range(5):
+        act = (torch.randn(N, 32, generator=g) * 0.3).cuda()
+        ns = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32).cuda(); nst = torch.randint(0, 100, (N,), generator=g, dtype=torch.int32).cuda()
+        ra = [x.clone() for x in a_sim.step(act, ns, nst)]
+        rb = [x.clone() for x in b_sim.step(act, ns, nst)]
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    assert torch.equal(a_sim.rfc_score(), b_sim.rfc_score())
