@@ -166,17 +166,18 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
 // ---- kernel 1 of a step: the 15 substeps (control glue + dynamics + contact solve + integration), f32.
 // Leaves the new state in HBM and a hand-over record (lagged body / geom poses, contact sums, 15-substep finite
 // differences) for the post-step kernel.
+template <bool FUSED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                           const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
                                                           const float* __restrict__ action, int first, int use_order, int use_lag,
                                                           float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
                                                           int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
                                                           const int* __restrict__ next_start, int n_envs) {
-  // obs != nullptr (HOIC_FUSED_STEP=1): the post-step work (dev_poststep) runs at the end of this launch, on the
+  // FUSED (HOIC_FUSED_STEP=1): the post-step work (dev_poststep) runs at the end of this launch, on the
   // workspace as it stands, instead of in hoic_poststep_kernel behind a 2.8 KB hand-over record per env.  One launch
   // per env step, but 153 KB of code, 256 registers and 288 B of scratch; measured equal to the two-launch form both
   // for whole-batch steps and in the two-range rollout, so the two-launch form stays the default.
-  const bool fused = obs != nullptr;
+  constexpr bool fused = FUSED;
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
@@ -978,11 +979,11 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
   if (e) hipEventRecord(e[0], st);
   if (s->fused) {     // one launch: the post-step work runs at the end of the substep kernel
-    hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+    hipLaunchKernelGGL(hoic_substep_kernel<true>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
                        s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs);
     if (e) hipEventRecord(e[1], st);
   } else {
-    hipLaunchKernelGGL(hoic_substep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+    hipLaunchKernelGGL(hoic_substep_kernel<false>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
                        s->use_lag ? 1 : 0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
                        (const int*)nullptr, (const int*)nullptr, s->n_envs);
     if (e) hipEventRecord(e[1], st);
