@@ -183,11 +183,15 @@ class AgentHandMimic:
 
     def _groups(self):
         """env ranges stepped independently during the rollout ((first, count) pairs)"""
-        G = self.n_groups if (self.device.type == "cuda" and self.n_envs % max(self.n_groups, 1) == 0) else 1
-        if G > 1 and self._streams is None:
+        G = max(1, min(self.n_groups, self.n_envs)) if self.device.type == "cuda" else 1
+        if G > 1 and (self._streams is None or len(self._streams) != G):
             self._streams = [torch.cuda.Stream(self.device) for _ in range(G)]
-        c = self.n_envs // G
-        return [(g * c, c) for g in range(G)]
+        c, r = divmod(self.n_envs, G)            # the first r ranges are one env longer
+        out, first = [], 0
+        for g in range(G):
+            n = c + (1 if g < r else 0)
+            out.append((first, n)); first += n
+        return out
 
     # ------------------------------------------------------------------ episode draws (:444-448)
     def _draw_episodes(self, n):
