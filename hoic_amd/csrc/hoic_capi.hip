@@ -1069,6 +1069,15 @@ extern "C" int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, co
   return HOIC_OK;
 }
 
+extern "C" int32_t hoic_gae(int32_t T, int32_t N, const float* d_rewards, const float* d_masks, const float* d_values,
+                            const float* d_next_values, float gamma, float tau, float* d_adv, float* d_returns, void* stream) {
+  if (T <= 0 || N <= 0 || !d_rewards || !d_masks || !d_values || !d_adv || !d_returns) { set_err("hoic_gae: bad arguments"); return HOIC_ERR_ARG; }
+  const float gamma_tau = (float)((double)gamma * (double)tau);
+  hipLaunchKernelGGL(hoic_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, d_rewards, d_masks, d_values,
+                     d_next_values, gamma, gamma_tau, d_adv, d_returns);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
 extern "C" int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim) {
   if (n <= 0 || dim <= 0) return 0;
   return (int64_t)((n + ZF_ROWS - 1) / ZF_ROWS) * dim * 2;

@@ -72,3 +72,24 @@ __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_apply_kernel(const float* 
     y[(size_t)r * dim + col] = (float)fmin(fmax(v, -lim), lim);
   }
 }
+
+// ---- generalized advantage estimation over a time-major rollout (khrylib core/common.py:12-19): thread = env, the
+// recursion over T runs in registers; every float32 operation is rounded like the tensor expression of the host
+// mirror (no fused multiply-adds), so both give bit-identical advantages.
+//   delta_t = r_t + gamma V_{t+1} m_t - V_t,   A_t = delta_t + gamma tau A_{t+1} m_t,   returns_t = V_t + A_t
+__global__ void hoic_gae_kernel(int T, int N, const float* __restrict__ rewards, const float* __restrict__ masks,
+                                const float* __restrict__ values, const float* __restrict__ next_values, float gamma,
+                                float gamma_tau, float* __restrict__ adv, float* __restrict__ returns) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float prev_v = next_values ? next_values[n] : 0.f, prev_a = 0.f;
+  for (int t = T - 1; t >= 0; t--) {
+    const size_t k = (size_t)t * N + n;
+    const float r = rewards[k], m = masks[k], v = values[k];
+    const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(__fmul_rn(gamma, prev_v), m)), v);
+    prev_a = __fadd_rn(delta, __fmul_rn(__fmul_rn(gamma_tau, prev_a), m));
+    adv[k] = prev_a;
+    returns[k] = __fadd_rn(v, prev_a);
+    prev_v = v;
+  }
+}

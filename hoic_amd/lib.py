@@ -40,7 +40,7 @@ class RewardParams(C.Structure):
 
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
-           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_scratch_doubles", "hoic_enable_timing",
+           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame"]
 
@@ -93,6 +93,7 @@ def load():
     L.hoic_step_times.argtypes = [vp, vp, vp, i32]
     L.hoic_step_range.argtypes = [vp, i32, i32] + [vp] * 9
     L.hoic_zfilter.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, vp]
+    L.hoic_gae.argtypes = [i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp]
     L.hoic_zfilter_scratch_doubles.argtypes = [i32, i32]
     L.hoic_zfilter_scratch_doubles.restype = C.c_int64
     L.hoic_probe_qp.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp]

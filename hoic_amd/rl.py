@@ -83,15 +83,18 @@ def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, di
     over the whole batch (:22) — across all ranks if ``dist_group`` is given.
     """
     T = rewards.shape[0]
-    adv = torch.zeros_like(rewards)
-    prev_v = torch.zeros_like(rewards[0]) if next_values is None else next_values
-    prev_a = torch.zeros_like(rewards[0])
-    for t in range(T - 1, -1, -1):
-        delta = rewards[t] + gamma * prev_v * masks[t] - values[t]
-        prev_a = delta + gamma * tau * prev_a * masks[t]
-        adv[t] = prev_a
-        prev_v = values[t]
-    returns = values + adv
+    if rewards.is_cuda and rewards.dtype == torch.float32 and rewards.dim() == 2:
+        adv, returns = _gae_device(rewards, masks, values, gamma, tau, next_values)     # one HIP launch (hoic_gae)
+    else:
+        adv = torch.zeros_like(rewards)
+        prev_v = torch.zeros_like(rewards[0]) if next_values is None else next_values
+        prev_a = torch.zeros_like(rewards[0])
+        for t in range(T - 1, -1, -1):
+            delta = rewards[t] + gamma * prev_v * masks[t] - values[t]
+            prev_a = delta + gamma * tau * prev_a * masks[t]
+            adv[t] = prev_a
+            prev_v = values[t]
+        returns = values + adv
     s = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)])
     if dist_group is not None:
         import torch.distributed as dist
@@ -100,6 +103,22 @@ def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, di
     mean = s[0] / n
     var = (s[1] - n * mean * mean) / (n - 1)
     return (adv - mean) / torch.sqrt(var), returns
+
+
+def _gae_device(rewards, masks, values, gamma, tau, next_values):
+    from . import lib
+    import ctypes as C
+    L = lib.load()
+    f = lambda x: x.to(torch.float32).contiguous()
+    rewards, masks, values = f(rewards), f(masks), f(values)
+    nv = None if next_values is None else f(next_values)
+    adv, returns = torch.empty_like(rewards), torch.empty_like(rewards)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rc = L.hoic_gae(rewards.shape[0], rewards.shape[1], ptr(rewards), ptr(masks), ptr(values), ptr(nv), float(gamma), float(tau),
+                    ptr(adv), ptr(returns), C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
+    if rc != 0:
+        raise lib.HoicError(f"hoic_gae failed ({rc}): {L.hoic_last_error().decode()}")
+    return adv, returns
 
 
 def ppo_loss(policy, states, actions, advantages, fixed_log_probs, clip_epsilon):

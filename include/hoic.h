@@ -127,6 +127,13 @@ int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const fl
                            int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
                            float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream);
 
+/* Generalized advantage estimation (khrylib core/common.py:12-19, called from agent_pg.py:46) over a time-major
+ * rollout, no handle needed: d_rewards, d_masks (0 at episode ends), d_values [T, N] float32, d_next_values [N] (value
+ * after the last collected step; null: 0).  delta_t = r_t + gamma V_{t+1} m_t - V_t, A_t = delta_t + gamma tau A_{t+1} m_t
+ * -> d_adv [T, N] (not normalised), d_returns = V + A. */
+int32_t hoic_gae(int32_t T, int32_t N, const float* d_rewards, const float* d_masks, const float* d_values,
+                 const float* d_next_values, float gamma, float tau, float* d_adv, float* d_returns, void* stream);
+
 /* The running observation filter of the sampler (khrylib ZFilter / RunningStat, uhc/khrylib/utils/zfilter.py:8-73,
  * called on every observation at agent_handmimic.py:463) on a batch, no handle needed.  d_x [n, dim] float32; state =
  * (count, mean[dim], S[dim]) as 1 + 2 dim float64 on the device.  update != 0: the batch is merged into the state

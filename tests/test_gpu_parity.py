@@ -630,3 +630,22 @@ def test_fused_step_matches_two_launches(box_blob, setup, monkeypatch):
     qa, va, _ = a_sim.get_state(); qb, vb, _ = b_sim.get_state()
     torch.testing.assert_close(qa, qb, rtol=0, atol=1e-4); torch.testing.assert_close(va, vb, rtol=0, atol=5e-3)
     torch.testing.assert_close(a_sim.rfc_score(), b_sim.rfc_score(), rtol=1e-3, atol=1e-4)
+
+
+def test_gae_device_path_is_bit_identical():
+    """hoic_gae (one launch) against the tensor recursion of estimate_advantages: same float32 roundings."""
+    from hoic_amd import rl
+    g = torch.Generator().manual_seed(4)
+    T, N = 13, 4096
+    r = torch.rand(T, N, generator=g).cuda(); m = (torch.rand(T, N, generator=g) > 0.05).float().cuda()
+    v = torch.randn(T, N, generator=g).cuda(); nv = torch.randn(N, generator=g).cuda()
+    for nxt in (nv, None):
+        a_dev, ret_dev = rl._gae_device(r, m, v, 0.95, 0.95, nxt)
+        adv = torch.zeros_like(r); pv = torch.zeros_like(r[0]) if nxt is None else nxt; pa = torch.zeros_like(r[0])
+        for t in range(T - 1, -1, -1):
+            delta = r[t] + 0.95 * pv * m[t] - v[t]
+            pa = delta + 0.95 * 0.95 * pa * m[t]
+            adv[t] = pa; pv = v[t]
+        assert torch.equal(a_dev, adv) and torch.equal(ret_dev, v + adv)
+    a1, r1 = rl.estimate_advantages(r, m, v, 0.95, 0.95, nv)
+    assert torch.isfinite(a1).all() and abs(float(a1.mean())) < 1e-4
