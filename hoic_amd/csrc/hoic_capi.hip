@@ -961,6 +961,7 @@ extern "C" int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, 
                               float* d_obs_out, void* stream) {
   if (!s || !d_seq || !d_start || n <= 0 || n > s->n_envs) { set_err("hoic_reset: bad arguments"); return HOIC_ERR_ARG; }
   if (!s->has_expert) { set_err("hoic_reset: set_expert has not been called"); return HOIC_ERR_STATE; }
+  HIPCHK(hipSetDevice(s->device));
   hipLaunchKernelGGL(hoic_reset_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->ex, s->st, d_env_ids, d_seq, d_start, d_obs_out);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
@@ -974,6 +975,7 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   if (first < 0 || count <= 0 || first + count > s->n_envs) { set_err(std::string(who) + ": env range outside [0, n_envs)"); return HOIC_ERR_ARG; }
   if (!s->has_expert) { set_err(std::string(who) + ": set_expert has not been called"); return HOIC_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(s->device));     // the launches go to the handle's device whatever the caller's current one is
   hipEvent_t* e = s->timing ? s->ev[s->n_timed % hoic_sim::NEV] : nullptr;
   const int use_order = s->reorder && first == 0 && count == s->n_envs;
   if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
@@ -1010,12 +1012,14 @@ extern "C" int32_t hoic_step_range(hoic_sim* s, int32_t first, int32_t count, co
 
 extern "C" int32_t hoic_get_state(hoic_sim* s, float* d_qpos, float* d_qvel, int32_t* d_cur_t, void* stream) {
   if (!s) return HOIC_ERR_ARG;
+  HIPCHK(hipSetDevice(s->device));
   hipLaunchKernelGGL(hoic_get_state_kernel, dim3(s->n_envs), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->st, d_qpos, d_qvel, d_cur_t);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
 extern "C" int32_t hoic_set_state(hoic_sim* s, const float* d_qpos, const float* d_qvel, void* stream) {
   if (!s || !d_qpos || !d_qvel) { set_err("hoic_set_state: null"); return HOIC_ERR_ARG; }
+  HIPCHK(hipSetDevice(s->device));
   hipLaunchKernelGGL(hoic_set_state_kernel, dim3(s->n_envs), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->st, d_qpos, d_qvel);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
@@ -1035,6 +1039,7 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
   ProbeArgs a{d_qpos, d_qvel, d_ctrl, d_applied, d_warm, do_step, d_xpos, d_xquat, d_geom_xpos, d_geom_xmat, d_qM, d_bias,
               d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_ncon, d_solver_iter};
   static const int lds_pad = getenv("HOIC_DBG_LDS_PAD") ? atoi(getenv("HOIC_DBG_LDS_PAD")) : 0;   // occupancy experiments
+  HIPCHK(hipSetDevice(s->device));
   hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), lds_pad, (hipStream_t)stream, s->d_model, s->d_cfg, a);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
@@ -1064,6 +1069,7 @@ extern "C" int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, co
   if (!s || n <= 0 || !d_cols || !d_ncols || !d_rhs || !d_lambda || !d_stat || max_col <= 0 || max_col > QP_MAXCOL) {
     set_err("hoic_probe_qp: bad arguments (max_col must be in 1..380)"); return HOIC_ERR_ARG;
   }
+  HIPCHK(hipSetDevice(s->device));
   hipLaunchKernelGGL(hoic_probe_qp_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, d_cols, d_ncols, d_rhs, max_col, d_lambda, d_stat);
   HIPCHK(hipGetLastError());
   return HOIC_OK;

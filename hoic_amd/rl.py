@@ -114,8 +114,9 @@ def _gae_device(rewards, masks, values, gamma, tau, next_values):
     nv = None if next_values is None else f(next_values)
     adv, returns = torch.empty_like(rewards), torch.empty_like(rewards)
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-    rc = L.hoic_gae(rewards.shape[0], rewards.shape[1], ptr(rewards), ptr(masks), ptr(values), ptr(nv), float(gamma), float(tau),
-                    ptr(adv), ptr(returns), C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
+    with torch.cuda.device(rewards.device):
+        rc = L.hoic_gae(rewards.shape[0], rewards.shape[1], ptr(rewards), ptr(masks), ptr(values), ptr(nv), float(gamma), float(tau),
+                        ptr(adv), ptr(returns), C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
     if rc != 0:
         raise lib.HoicError(f"hoic_gae failed ({rc}): {L.hoic_last_error().decode()}")
     return adv, returns
@@ -233,8 +234,9 @@ class BatchZFilter:
                 self._scratch = torch.empty(need, dtype=torch.float64, device=x.device)
             out, scratch = self._alt, self._scratch
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        rc = L.hoic_zfilter(n, self.dim, ptr(x), ptr(self._st), ptr(out), int(bool(update)), float(self.clip), ptr(y), ptr(scratch),
-                            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        with torch.cuda.device(x.device):
+            rc = L.hoic_zfilter(n, self.dim, ptr(x), ptr(self._st), ptr(out), int(bool(update)), float(self.clip), ptr(y), ptr(scratch),
+                                C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise lib.HoicError(f"hoic_zfilter failed ({rc}): {L.hoic_last_error().decode()}")
         if update:
