@@ -75,13 +75,20 @@ class PPOLearner:
         self.last_losses = None
 
     # ------------------------------------------------------------------ update (agent_pg.py:39-55, agent_ppo.py:16-64)
-    def _allreduce_grads(self, params):
+    def _allreduce_start(self, params):
+        """Start the gradient all-reduce of one network (one flat buffer) without waiting for it."""
         if not self.distributed:
-            return
+            return None
         import torch.distributed as dist
         grads = [p.grad for p in params if p.grad is not None]
         flat = torch._utils._flatten_dense_tensors(grads)
-        dist.all_reduce(flat)
+        return grads, flat, dist.all_reduce(flat, async_op=True)
+
+    def _allreduce_finish(self, pending):
+        if pending is None:
+            return
+        grads, flat, work = pending
+        work.wait()
         flat.div_(self.world)
         for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
             g.copy_(f)
@@ -112,24 +119,37 @@ class PPOLearner:
             fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
         vparams = list(self.value_net.parameters())
         pparams = [p for p in self.policy_net.parameters() if p.requires_grad]
-        for _ in range(self.opt_num_epochs):
-            with self._autocast():
-                value_loss = (self.value_net(states).float() - returns).pow(2).mean()      # agent_pg.py:18-25
-            self.optimizer_value.zero_grad(set_to_none=True)
-            value_loss.backward()
-            self._allreduce_grads(vparams)
-            self.optimizer_value.step()
-            with self._autocast():
-                surr = ppo_loss(self.policy_net, states, actions, advantages, fixed_log_probs, self.clip_epsilon)
-            self.optimizer_policy.zero_grad(set_to_none=True)
-            surr.backward()
-            self._allreduce_grads(pparams)
+
+        def policy_step(pending):
+            self._allreduce_finish(pending)
             # policy_grad_clip=[(parameters() generator, 40)] clips only on the first optimizer step of the run
             # (agent_handmimic.py:67); strict_reference=False clips every step
             if not (self.strict_reference and self._policy_clip_used):
                 torch.nn.utils.clip_grad_norm_(pparams, 40)
                 self._policy_clip_used = True
             self.optimizer_policy.step()
+
+        # Per network the order is forward, backward, all-reduce, step, as in the reference loop.  Across networks the
+        # two chains are independent, so with several ranks each gradient all-reduce runs while the OTHER network does
+        # its forward and backward: value all-reduce of epoch k under the policy pass of epoch k, policy all-reduce of
+        # epoch k under the value pass of epoch k + 1.  Only the last one is exposed.
+        p_pending, p_waiting = None, False
+        for _ in range(self.opt_num_epochs):
+            with self._autocast():
+                value_loss = (self.value_net(states).float() - returns).pow(2).mean()      # agent_pg.py:18-25
+            self.optimizer_value.zero_grad(set_to_none=True)
+            value_loss.backward()
+            v_pending = self._allreduce_start(vparams)
+            if p_waiting:
+                policy_step(p_pending); p_waiting = False
+            with self._autocast():
+                surr = ppo_loss(self.policy_net, states, actions, advantages, fixed_log_probs, self.clip_epsilon)
+            self.optimizer_policy.zero_grad(set_to_none=True)
+            surr.backward()
+            p_pending, p_waiting = self._allreduce_start(pparams), True
+            self._allreduce_finish(v_pending)
+            self.optimizer_value.step()
+        policy_step(p_pending)
         self.last_losses = (float(value_loss.detach()), float(surr.detach()))
 
 
