@@ -133,7 +133,7 @@ struct DevState {
   float* oldg;   // [n, OG_SIZE]
   float* lagrec; // [n, LG_SIZE]
   int* lag_valid; // [n] 0: the record does not belong to (qlag, vlag) (after a reset / set_state / failed step)
-  double* qp_lam; // [n, 8] warm start of the residual-force QP: lambda[6], valid flag, pad
+  double* qp_lam; // [n, 8] multipliers of the last residual-force QP: lambda[6], valid flag, pad (diagnostic; the active-set solve starts cold)
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
   unsigned* cost;    // [2, n] shader-clock duration (>> 6) of the env's last substep / post-step pass
   int* order;        // [2, n] launch order of the next step: workgroup b runs env order[b], longest first

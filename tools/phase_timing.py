@@ -1,4 +1,4 @@
-"""Per-phase cycle breakdown of hoic_step_kernel (needs hoic_amd/libhoic_hip_timing.so, built with -DHOIC_PHASE_TIMING)."""
+"""Per-phase cycle breakdown of hoic_substep_kernel (needs hoic_amd/libhoic_hip_timing.so, built with -DHOIC_PHASE_TIMING)."""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, '.')

@@ -1,4 +1,4 @@
-"""Run only hoic_step_kernel (no policy / update): development aid for rocprofv3 --kernel-trace / --pmc passes.
+"""Run only the two step kernels (hoic_substep_kernel, hoic_poststep_kernel) (no policy / update): development aid for rocprofv3 --kernel-trace / --pmc passes.
 usage: python3 tools/sim_only.py [n_envs] [steps] [obj]"""
 import sys, os
 sys.path.insert(0, '.')
