@@ -129,7 +129,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("HOIC_FORCE_DIST") == "1"     # HOIC_FORCE_DIST: exercise the RCCL calls with one rank
     # CPU baseline first: worker processes are forked before torch / HIP are initialised in this process
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
