@@ -12,8 +12,16 @@ the same checkpoint dict keys.  What changes is WHERE things run:
 * with several GPUs every rank owns its envs and a full replica; only policy/value gradients (one flat
   bucket each), three scalars for the advantage normalisation and the ZFilter moments cross xGMI (RCCL).
 
-Deliberate, documented differences to the reference: fixed-horizon batches (``ceil(min_batch/n_envs)`` steps of
-every env) with a value bootstrap at the cut instead of whole episodes; float32 instead of float64.
+Two sampling modes (``sample_mode``):
+
+* ``"fixed"`` (default, the throughput mode): ``ceil(min_batch/n_envs)`` steps of every env, episodes continue
+  across iterations, value bootstrap at the cut — a deliberate difference to the reference;
+* ``"episodes"`` (the reference's batch, :430-535): every env is one of the reference's sampler workers and collects
+  WHOLE episodes until it holds ``floor(min_batch/n_envs)`` steps (``n_envs`` plays ``num_threads``); no bootstrap,
+  every episode in the batch is complete.  With few envs this is latency-bound; it exists so that the reference's
+  learner can be reproduced on the HIP simulator (tools/reward_curve.py compares the two modes over seeds).
+
+float32 instead of float64 in both.
 """
 from __future__ import annotations
 
@@ -30,6 +38,7 @@ import torch
 from . import motions
 from .config import Config
 from .env import BatchedHandObjMimic
+from .lib import NV as lib_NV
 from .rl import MLP, BatchZFilter, PolicyGaussian, RunningStat, Value, ZFilter, estimate_advantages, ppo_loss
 
 
@@ -44,8 +53,30 @@ class RefUnpickler(pickle.Unpickler):
         return super().find_class(module, name)
 
 
-class LoggerRL(SimpleNamespace):
-    """Fields of uhc/khrylib/rl/core/logger_rl.py the training loop reads."""
+class LoggerRL:
+    """The sampler statistics of uhc/khrylib/rl/core/logger_rl.py:4-68, filled from device reductions.  ``reward`` is
+    the env reward (1.0 per step, ho_im4.py:662), so ``total_reward == num_steps`` and ``avg_episode_reward ==
+    avg_episode_len``; the ``c_*`` fields are the custom reward WITHOUT the end bonus (LoggerRL.step sees c_reward
+    before agent_handmimic.py:479-480 adds it)."""
+
+    def __init__(self, num_steps=0, num_episodes=0, total_c_reward=0.0, min_c_reward=math.inf, max_c_reward=-math.inf,
+                 total_c_info=0.0, min_episode_reward=math.inf, max_episode_reward=-math.inf, sample_time=0.0, **extra):
+        self.num_steps, self.num_episodes = int(num_steps), int(num_episodes)
+        self.total_reward = float(num_steps)
+        self.total_c_reward, self.min_c_reward, self.max_c_reward = float(total_c_reward), float(min_c_reward), float(max_c_reward)
+        self.total_c_info = total_c_info
+        self.min_episode_reward, self.max_episode_reward = float(min_episode_reward), float(max_episode_reward)
+        self.sample_time = sample_time
+        ep = max(self.num_episodes, 1)                 # a fixed-horizon window may hold no episode end at all
+        st = max(self.num_steps, 1)
+        self.avg_episode_len = self.num_steps / ep     # end_sampling(), :41-47
+        self.avg_episode_reward = self.total_reward / ep
+        self.avg_c_reward = self.total_c_reward / st
+        self.avg_c_info = self.total_c_info / st
+        self.avg_episode_c_reward = self.total_c_reward / ep
+        self.avg_episode_c_info = self.total_c_info / ep
+        for k, v in extra.items():
+            setattr(self, k, v)
 
 
 class PPOLearner:
@@ -103,18 +134,34 @@ class PPOLearner:
         t0 = time.time()
         self.policy_net.train(); self.value_net.train()
         T, N = batch.rewards.shape
+        valid = getattr(batch, "valid", None)
         states = batch.states.reshape(T * N, -1)
         actions = batch.actions.reshape(T * N, -1)
+        if valid is not None:           # whole-episode batches: padded [T, N] storage, only the valid rows are samples
+            vflat = valid.reshape(T * N)
+            states, actions = states[vflat], actions[vflat]
         with torch.no_grad(), self._autocast():
-            values = self.value_net(states).float().reshape(T, N)
-        advantages, returns = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau,
-                                                  batch.next_values, dist_group=True if self.distributed else None)
+            values = self.value_net(states).float()
+        if valid is not None:
+            values = torch.zeros(T * N, 1, device=values.device, dtype=values.dtype).masked_scatter_(vflat[:, None], values)
+        advantages, returns = estimate_advantages(batch.rewards, batch.masks, values.reshape(T, N), self.gamma, self.tau,
+                                                  getattr(batch, "next_values", None),
+                                                  dist_group=True if self.distributed else None, valid=valid)
         advantages = advantages.reshape(T * N, 1); returns = returns.reshape(T * N, 1)
-        self.optimize(states, actions, advantages, returns)
+        weight = 1.0
+        if valid is not None:
+            advantages, returns = advantages[vflat], returns[vflat]
+            if self.distributed:        # ranks hold different sample counts: weight the local means by M_r * world / sum(M)
+                import torch.distributed as dist
+                cnt = torch.tensor([float(states.shape[0])], device=states.device, dtype=torch.float64)
+                tot = cnt.clone(); dist.all_reduce(tot)
+                weight = float(cnt * self.world / tot)
+        self.optimize(states, actions, advantages, returns, weight)
         return time.time() - t0
 
-    def optimize(self, states, actions, advantages, returns):
-        """The 5 full-batch epochs of value and policy steps (agent_ppo.py:16-56) on flat [M, .] tensors."""
+    def optimize(self, states, actions, advantages, returns, weight=1.0):
+        """The 5 full-batch epochs of value and policy steps (agent_ppo.py:16-56) on flat [M, .] tensors.  ``weight``
+        scales both losses (ranks with unequal sample counts, see update_params)."""
         with torch.no_grad(), self._autocast():
             fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
         vparams = list(self.value_net.parameters())
@@ -138,14 +185,14 @@ class PPOLearner:
             with self._autocast():
                 value_loss = (self.value_net(states).float() - returns).pow(2).mean()      # agent_pg.py:18-25
             self.optimizer_value.zero_grad(set_to_none=True)
-            value_loss.backward()
+            (value_loss * weight if weight != 1.0 else value_loss).backward()
             v_pending = self._allreduce_start(vparams)
             if p_waiting:
                 policy_step(p_pending); p_waiting = False
             with self._autocast():
                 surr = ppo_loss(self.policy_net, states, actions, advantages, fixed_log_probs, self.clip_epsilon)
             self.optimizer_policy.zero_grad(set_to_none=True)
-            surr.backward()
+            (surr * weight if weight != 1.0 else surr).backward()
             p_pending, p_waiting = self._allreduce_start(pparams), True
             self._allreduce_finish(v_pending)
             self.optimizer_value.step()
@@ -156,8 +203,10 @@ class PPOLearner:
 class AgentHandMimic:
     def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
-                 strict_reference=True, solver_iterations=8, n_groups=None):
+                 strict_reference=True, solver_iterations=8, n_groups=None, sample_mode="fixed", eval_envs=None):
+        assert sample_mode in ("fixed", "episodes")
         self.cfg = self.cc_cfg = cfg
+        self.sample_mode = sample_mode
         # rollout pipelining: 2 half-batches once a half still fills the GPU's 2048 wavefront slots
         self.n_groups = int(n_groups) if n_groups is not None else (2 if n_envs >= 4096 and n_envs % 2 == 0 else 1)
         self._streams = None
@@ -169,7 +218,10 @@ class AgentHandMimic:
         if distributed:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device or 0)
+        if isinstance(device, torch.device):         # torch.device("cuda") carries no index: use the current device
+            dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        else:
+            dev_index = int(device or 0)
         self.epoch = 0
         # data + env (setup_data_loader / setup_env, :107-123)
         if expert_seqs is None:
@@ -177,9 +229,12 @@ class AgentHandMimic:
             expert_seqs = motions.synthetic_expert(mjcf.load_packaged(model if isinstance(model, str) else "box"))
         self.expert_seqs = expert_seqs
         self.seq_num = len(expert_seqs)
+        self._model_arg, self._solver_iterations, self._dev_index = model, solver_iterations, dev_index
         self.env = BatchedHandObjMimic(cfg, expert_seqs, model, n_envs, "train", dev_index, solver_iterations)
         self.device = self.env.device
         self.n_envs = n_envs
+        self.eval_envs = eval_envs          # envs of the separate evaluation simulator (None: one per sequence, <= 64)
+        self._eval_env = None
         self.state_dim, self.action_dim = self.env.observation_space.shape[0], self.env.action_space.shape[0]
         # nets + optimizers (:125-169)
         from . import tuning
@@ -221,9 +276,39 @@ class AgentHandMimic:
         start = (u * self._max_start[seq].to(u.dtype)).to(torch.int32)
         return seq.to(torch.int32), start
 
+    def _make_log(self, steps, rewards, end_flags, done_flags, rinfo, valid, t0):
+        """LoggerRL of a rollout held as [T, N] tensors.  ``rewards`` carry the end bonus the kernel added on 'end'
+        steps (hoic_capi.hip dev_poststep); the c_reward statistics are taken without it, as LoggerRL.step sees them
+        (agent_handmimic.py:476-482) — they feed env.end_reward of the next iteration (:318-319)."""
+        bonus = float(self.env.pushed_end_reward) if self.end_reward else 0.0
+        cr = rewards.to(torch.float64) - bonus * end_flags.to(torch.float64)
+        if valid is None:
+            cmin, cmax, csum = cr.min(), cr.max(), cr.sum()
+            n_done = done_flags.sum().to(torch.float64)
+            c_info = rinfo.sum((0, 1), dtype=torch.float64)
+        else:
+            big = torch.full_like(cr, math.inf)
+            cmin, cmax = torch.where(valid, cr, big).min(), torch.where(valid, cr, -big).max()
+            csum = torch.where(valid, cr, torch.zeros_like(cr)).sum()
+            n_done = (done_flags & valid).sum().to(torch.float64)
+            c_info = (rinfo.to(torch.float64) * valid[..., None]).sum((0, 1))
+        stats = torch.stack([csum, cmin, cmax, n_done])
+        if self.distributed:
+            import torch.distributed as dist
+            tot = torch.cat([stats[[0, 3]], c_info, torch.tensor([float(steps)], device=stats.device, dtype=torch.float64)])
+            dist.all_reduce(tot)
+            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:-1]; steps = int(tot[-1].item())
+        s = stats.cpu().numpy(); ci = c_info.cpu().numpy()
+        return LoggerRL(num_steps=steps, num_episodes=int(s[3]), total_c_reward=s[0], min_c_reward=s[1], max_c_reward=s[2],
+                        total_c_info=ci, sample_time=time.time() - t0, end_bonus=bonus)
+
     # ------------------------------------------------------------------ rollout (sample / sample_process, :430-535)
     @torch.no_grad()
     def sample(self, min_batch_size):
+        if self.sample_mode == "episodes":
+            return self._sample_episodes(min_batch_size)
         t0 = time.time()
         self.env.set_mode("train")
         self.policy_net.eval()
@@ -234,8 +319,6 @@ class AgentHandMimic:
         actions = torch.empty(T, N, self.action_dim, device=dev, dtype=dt)
         rewards = torch.empty(T, N, device=dev, dtype=dt)
         masks = torch.empty(T, N, device=dev, dtype=dt)
-        c_info = torch.zeros(9, device=dev, dtype=torch.float64)
-        n_done = torch.zeros((), device=dev, dtype=torch.float64)
         if self._obs is None:
             seq, start = self._draw_episodes(N)
             self._obs = self.env.reset(seq, start)
@@ -287,8 +370,6 @@ class AgentHandMimic:
                 main.wait_stream(st_)
         done_all = flags_all[:, :, 2] != 0
         masks.copy_((~done_all).to(dt))
-        c_info += rinfo_all.sum((0, 1), dtype=torch.float64)
-        n_done += done_all.sum()
         obs = self.env.get_obs()
         self._obs = obs
         if self.distributed:
@@ -296,25 +377,55 @@ class AgentHandMimic:
         next_state = self.running_state(obs, update=False)
         next_values = self.value_net(next_state).squeeze(1)
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
-                                exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values)
-        steps = T * N
-        # the end reward is part of `rewards`; c_reward statistics are reported without it, like the reference
-        end_bonus = self.env.end_reward if self.end_reward else 0.0
-        cr = rewards.to(torch.float64)
-        stats = torch.stack([cr.sum(), cr.min(), cr.max(), n_done])
+                                exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values, valid=None)
+        log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0)
+        return batch, log
+
+    @torch.no_grad()
+    def _sample_episodes(self, min_batch_size, sync_every=8):
+        """The reference's batch (sample / sample_process, :430-535): every env is one sampler worker that collects WHOLE
+        episodes until it holds ``thread_batch_size = floor(min_batch_size / n_envs)`` steps (:509, :437); a worker
+        that has its quota idles (its env keeps being stepped by the launch, its rows are marked invalid).  Nothing is
+        bootstrapped: every episode in the batch ends with mask 0.  The observation filter sees every row of an active
+        worker (the reference keeps only worker 0's updates)."""
+        t0 = time.time()
+        self.env.set_mode("train")
+        self.policy_net.eval()
+        N, dev, dt = self.n_envs, self.device, self.dtype
+        quota = max(1, int(math.floor(min_batch_size / N)))
+        seq, start = self._draw_episodes(N)
+        obs = self.env.reset(seq, start)
+        active = torch.ones(N, dtype=torch.bool, device=dev)
+        count = torch.zeros(N, dtype=torch.int64, device=dev)
+        S, A, R, RI, FL, VA = [], [], [], [], [], []
+        max_steps = quota + int(self.env.seq_len.max()) + sync_every + 1
+        for t in range(max_steps):
+            rows = obs if t == 0 else obs[active]      # t == 0: everyone is active (no sync needed)
+            if rows.shape[0] > 0:
+                self.running_state.push(rows)
+            state = self.running_state(obs, update=False).to(dt)
+            action = self.policy_net.select_action(state)
+            nseq, nstart = self._draw_episodes(N)
+            self.env.step(action, nseq, nstart)
+            S.append(state); A.append(action); R.append(self.env.c_reward.clone()); RI.append(self.env.c_info.clone())
+            FL.append(self.env.sim.flags.clone()); VA.append(active.clone())
+            count += active
+            done = FL[-1][:, 2] != 0
+            active = active & ~(done & (count >= quota))
+            obs = self.env.get_obs()
+            if (t + 1) % sync_every == 0 and not bool(active.any()):
+                break
+        self._obs = None                       # the fixed-horizon sampler must not continue these episodes
+        states, actions = torch.stack(S), torch.stack(A)
+        rewards, rinfo, flags, valid = torch.stack(R).to(dt), torch.stack(RI), torch.stack(FL), torch.stack(VA)
+        T = states.shape[0]
+        done_all = flags[:, :, 2] != 0
         if self.distributed:
-            import torch.distributed as dist
-            tot = torch.cat([stats[[0, 3]], c_info]); dist.all_reduce(tot)
-            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:]
-            steps *= self.world
-        s = stats.cpu().numpy(); ci = c_info.cpu().numpy()
-        episodes = max(s[3], 1.0)
-        log = LoggerRL(num_steps=steps, num_episodes=int(s[3]), avg_episode_len=steps / episodes,
-                       total_c_reward=s[0], avg_c_reward=s[0] / steps, min_c_reward=s[1], max_c_reward=s[2],
-                       avg_c_info=ci / steps, avg_episode_c_reward=s[0] / episodes, sample_time=time.time() - t0,
-                       end_bonus=end_bonus)
+            self.running_state.sync()
+        batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=(~done_all).to(dt),
+                                exps=torch.ones(T, N, device=dev, dtype=dt), next_values=None, valid=valid)
+        steps = int(valid.sum().item())
+        log = self._make_log(steps, rewards, flags[:, :, 1] != 0, done_all, rinfo, valid, t0)
         return batch, log
 
     def update_params(self, batch):
@@ -349,36 +460,77 @@ class AgentHandMimic:
         return info
 
     # ------------------------------------------------------------------ deterministic evaluation (:339-403)
+    def _eval_sim(self, n):
+        """A separate small simulator for evaluation rollouts (the training batch keeps its episodes; one env per
+        evaluated sequence instead of stepping all n_envs identically)."""
+        if self._eval_env is None or self._eval_env.n_envs != n:
+            if self._eval_env is not None:
+                self._eval_env.close()
+            self._eval_env = BatchedHandObjMimic(self.cfg, self.expert_seqs, self._model_arg, n, "test", self._dev_index,
+                                                 self._solver_iterations)
+        env = self._eval_env
+        env.end_reward = 0.0
+        env.update_reward_params()          # the reward weights of the current epoch, no end bonus
+        return env
+
     @torch.no_grad()
     def eval_policy(self, epoch=0, max_steps=10000):
-        env = self.env
+        env = self._eval_sim(1)
         env.set_mode("test")
-        N = self.n_envs
-        seq = torch.full((N,), self.seq_num - 1, dtype=torch.int32)
-        obs = env.reset(seq, torch.zeros(N, dtype=torch.int32))
-        res = {k: [] for k in ("reward", "info", "pred", "gt")}
-        ex = self.expert_seqs[self.seq_num - 1]
-        percent = 0.0
-        for t in range(max_steps):
-            res["gt"].append(ex["hand_dof_seq"][min(t, ex["hand_dof_seq"].shape[0] - 1)])
-            res["pred"].append(env.get_hand_qpos()[0].double().cpu().numpy())
+        si = self.seq_num - 1
+        obs = env.reset(torch.full((1,), si, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
+        ex = self.expert_seqs[si]
+        T = ex["hand_dof_seq"].shape[0]
+        qs, rew, infos, dones, pcts = [], [], [], [], []
+        self.policy_net.eval()
+        for t in range(min(max_steps, T)):          # the sequence end sets done within T steps; one sync at the end
+            qs.append(env.sim.get_state()[0][0])
             state = self.running_state(obs, update=False)
-            action = self.policy_net.select_action(state, mean_action=True)
+            action = self.policy_net.select_action(state.to(self.dtype), mean_action=True)
             obs, _, done, info = env.step(action)
-            res["reward"].append(float(env.c_reward[0])); res["info"].append(env.c_info[0].double().cpu().numpy())
-            percent = float(info["percent"][0])
-            if bool(done[0]):
-                break
-        env.set_mode("train")
-        self._obs = None
-        info_m = np.array(res["info"]).mean(0)
-        gt, pred = np.array(res["gt"]), np.array(res["pred"])
+            rew.append(env.c_reward[0].clone()); infos.append(env.c_info[0].clone()); dones.append(done[0].clone())
+            pcts.append(info["percent"][0].clone())
+        dn = torch.stack(dones).cpu().numpy()
+        n = int(np.argmax(dn)) + 1 if dn.any() else len(dn)
+        pred = torch.stack(qs).double().cpu().numpy()[:n, :env.hand_qpos_dim]
+        rew = torch.stack(rew).double().cpu().numpy()[:n]; info_m = torch.stack(infos).double().cpu().numpy()[:n].mean(0)
+        gt = np.asarray(ex["hand_dof_seq"])[:n]
         names = ("pose_reward", "wpose_reward", "jpos_reward", "vel_reward", "obj_pos_reward", "obj_rot_reward",
                  "obj_vel_reward", "obj_rfc_reward")
-        m = {"pose_err": float(np.linalg.norm(gt[6:] - pred[6:], axis=-1).mean()) if len(gt) > 6 else 0.0,
-             "avg_reward": float(np.mean(res["reward"])), "total_reward": float(np.sum(res["reward"])), "percent": percent}
-        m.update({n: float(info_m[i]) for i, n in enumerate(names)})
+        # pose_err slices FRAMES 6.. of the stacked arrays, as the reference does (:384); mpjpe from the kinematics of
+        # the recorded states (one probe launch; the reference reads the one-substep-lagged body_xpos)
+        hb0 = env.sim.model.scalar("hand_body0")
+        kin = env.sim.probe_forward(torch.stack(qs)[:n], torch.zeros(n, lib_NV), kinematics_only=True)
+        mpjpe = np.linalg.norm(np.asarray(ex["body_pos_seq"])[:n] - kin["xpos"][:, hb0:hb0 + 21], axis=-1).mean()
+        m = {"pose_err": float(np.linalg.norm(gt[6:] - pred[6:], axis=-1).mean()) if n > 6 else 0.0, "mpjpe": float(mpjpe),
+             "avg_reward": float(rew.mean()), "total_reward": float(rew.sum()), "percent": float(torch.stack(pcts)[n - 1])}
+        m.update({nm: float(info_m[i]) for i, nm in enumerate(names)})
         return m
+
+    @torch.no_grad()
+    def eval_sequences(self, seq_ids=None, train_termination=True, max_steps=None):
+        """Deterministic (mean-action) episodes from frame 0 of the given sequences (default: all), one env per
+        sequence in ONE batch on the evaluation simulator.  Returns reward per step, mean length and mean tracked
+        fraction — the quantities tools/reward_curve.py compares between samplers."""
+        ids = list(range(self.seq_num)) if seq_ids is None else list(seq_ids)
+        n = len(ids)
+        env = self._eval_sim(n)
+        env.set_mode("train" if train_termination else "test")
+        obs = env.reset(torch.tensor(ids, dtype=torch.int32), torch.zeros(n, dtype=torch.int32))
+        dev = self.device
+        alive = torch.ones(n, dtype=torch.bool, device=dev); tot = torch.zeros(n, device=dev, dtype=torch.float64)
+        cnt = torch.zeros(n, device=dev); pct = torch.zeros(n, device=dev)
+        T = int(max(self.expert_seqs[i]["hand_dof_seq"].shape[0] for i in ids)) if max_steps is None else int(max_steps)
+        self.policy_net.eval()
+        for _ in range(T):
+            state = self.running_state(obs, update=False)
+            action = self.policy_net.select_action(state.to(self.dtype), mean_action=True)
+            obs, _, done, info = env.step(action)
+            tot += torch.where(alive, env.c_reward.double(), torch.zeros_like(tot)); cnt += alive.float()
+            pct = torch.where(alive, info["percent"], pct)
+            alive &= ~done
+        return {"reward_per_step": float(tot.sum() / cnt.sum()), "mean_len": float(cnt.mean()), "mean_percent": float(pct.mean()),
+                "per_seq_len": cnt.cpu().numpy().tolist()}
 
     @torch.no_grad()
     def eval_physics(self, epoch=0, seq_index=None, max_steps=10000):
@@ -386,32 +538,30 @@ class AgentHandMimic:
         scripts/eval_handmimic.py:274-303 (mimic / reference pairs): jitter, penetration depth, hand-object contact
         count and the physically plausible frame ratio, computed by hoic_amd.metrics.PhysMetrics."""
         from .metrics import PhysMetrics
-        env = self.env
+        env = self._eval_sim(1)
         si = self.seq_num - 1 if seq_index is None else int(seq_index)
         env.set_mode("test")
-        N = self.n_envs
-        obs = env.reset(torch.full((N,), si, dtype=torch.int32), torch.zeros(N, dtype=torch.int32))
+        obs = env.reset(torch.full((1,), si, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
         ex = self.expert_seqs[si]
         T = ex["hand_dof_seq"].shape[0]
-        pred = []
+        qs, dones = [], []
+        self.policy_net.eval()
         for t in range(min(max_steps, T)):
-            q, _, _ = env.sim.get_state()
-            pred.append(q[0].double().cpu().numpy())
-            action = self.policy_net.select_action(self.running_state(obs, update=False), mean_action=True)
+            qs.append(env.sim.get_state()[0][0])
+            action = self.policy_net.select_action(self.running_state(obs, update=False).to(self.dtype), mean_action=True)
             obs, _, done, _ = env.step(action)
-            if bool(done[0]):
-                break
-        env.set_mode("train")
-        self._obs = None
-        pred = np.array(pred)
+            dones.append(done[0].clone())
+        dn = torch.stack(dones).cpu().numpy()
+        n = int(np.argmax(dn)) + 1 if dn.any() else len(dn)
+        pred = torch.stack(qs).double().cpu().numpy()[:n]
         ref = np.concatenate([ex["hand_dof_seq"], ex["obj_pose_seq"]], 1)[:len(pred)]
         out = {}
-        for name, qs in (("mimic", pred), ("ref", ref)):
-            pm = PhysMetrics(env.sim.model, qs, sim=env.sim)
+        for name, qseq in (("mimic", pred), ("ref", ref)):
+            pm = PhysMetrics(env.sim.model, qseq, sim=env.sim)
             hand_acc, obj_acc, obj_ang_acc = pm.eval_jitter()
             out[name] = {"hand_acc": hand_acc, "obj_acc": obj_acc, "obj_ang_acc": obj_ang_acc,
                          "pene_mm": float(np.mean(pm.eval_penetration())), "cp_num": float(np.mean(pm.eval_contact_point())),
-                         "plausible_frame_ratio": float(100 - np.mean(pm.eval_stable()) * 100), "frames": int(len(qs))}
+                         "plausible_frame_ratio": float(100 - np.mean(pm.eval_stable()) * 100), "frames": int(len(qseq))}
         return out
 
     # ------------------------------------------------------------------ checkpoints (:175-186, :234-245)

@@ -126,6 +126,11 @@ class Config:
         if self.action_type != "position": bad.append("action_type != position")
         if self.noise_future_pose: bad.append("noise_future_pose")
         if self.future_w_size != 5: bad.append("future_w_size != 5")
+        # options the batched sampler would silently ignore: the per-epoch rfc_rate decay (agent_handmimic.py:268-272) and
+        # mean-action steps drawn with probability 1 - noise_rate (:464, exps = 1 - mean_action)
+        if self.rfc_decay: bad.append("rfc_decay")
+        if np.any(np.asarray(self.adp_noise_rate_cp, dtype=np.float64) != 1.0): bad.append("adp_noise_rate_cp != 1")
+        if self.reward_type != 9: bad.append("reward_type != 9 (only ho_mimic_reward_9 is fused into the step kernel)")
         if bad:
             raise NotImplementedError("options outside the release configs are not on the accelerated path: " + ", ".join(bad))
 

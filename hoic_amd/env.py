@@ -88,6 +88,7 @@ class BatchedHandObjMimic:
     def update_reward_params(self):
         """Push reward weights / end_reward (refreshed every epoch, agent_handmimic.py:264-282, 318-319)."""
         self.sim.set_reward_params(self.cc_cfg.reward_wk(), self.end_reward, self.use_end_reward)
+        self.pushed_end_reward = float(self.end_reward) if self.use_end_reward else 0.0     # what the kernel adds on 'end' steps
 
     def reset(self, seq_idx=None, start_idx=None, env_ids=None):
         t = self.torch

@@ -73,14 +73,16 @@ class Value(nn.Module):
 
 
 # ----------------------------------------------------------------------------- advantages
-def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, dist_group=None):
+def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, dist_group=None, valid=None):
     """GAE(lambda) over time-major rollouts: rewards/masks/values are [T, N] (N parallel envs).
 
     Per env this is exactly the reference recursion (core/common.py:12-19): delta_t = r_t + gamma V_{t+1} m_t - V_t,
     A_t = delta_t + gamma tau A_{t+1} m_t with m_t = 0 at episode ends.  ``next_values`` [N] bootstraps the value after
     the last collected step (the reference only ever sees complete episodes, so it has nothing to bootstrap;
-    pass None for that behaviour).  Returns (normalised advantages, returns), normalised with the UNBIASED std
-    over the whole batch (:22) — across all ranks if ``dist_group`` is given.
+    pass None for that behaviour).  ``valid`` [T, N] bool: entries that belong to the batch (whole-episode sampling
+    pads every env's column behind its last complete episode; a padded entry never feeds a valid one because the
+    last valid entry of a column has m = 0).  Returns (normalised advantages, returns), normalised with the
+    UNBIASED std over the (valid part of the) whole batch (:22) — across all ranks if ``dist_group`` is given.
     """
     T = rewards.shape[0]
     if rewards.is_cuda and rewards.dtype == torch.float32 and rewards.dim() == 2:
@@ -95,7 +97,11 @@ def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, di
             adv[t] = prev_a
             prev_v = values[t]
         returns = values + adv
-    s = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)])
+    if valid is None:
+        a, cnt = adv, torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)
+    else:
+        a, cnt = torch.where(valid, adv, torch.zeros_like(adv)), valid.sum().to(adv.dtype)
+    s = torch.stack([a.sum(), (a * a).sum(), cnt])
     if dist_group is not None:
         import torch.distributed as dist
         dist.all_reduce(s, group=dist_group if dist_group is not True else None)
@@ -133,23 +139,32 @@ def ppo_loss(policy, states, actions, advantages, fixed_log_probs, clip_epsilon)
 
 # ----------------------------------------------------------------------------- observation filter
 class RunningStat:
-    """Same attributes as the reference class so pickled checkpoints interchange (zfilter.py:7-49)."""
+    """Same attributes (``_n``, ``_M``, ``_S``) as the reference class so pickled checkpoints interchange
+    (zfilter.py:7-49).  The update is the pairwise moment merge BatchZFilter uses, here on host arrays: pushing one
+    row is merging a batch of one."""
 
     def __init__(self, shape):
         self._n = 0
         self._M = np.zeros(shape)
         self._S = np.zeros(shape)
 
+    def merge(self, rows):
+        rows = np.asarray(rows, dtype=np.float64).reshape((-1,) + self._M.shape)
+        nb = rows.shape[0]
+        if nb == 0:
+            return
+        mb = rows.mean(0)
+        Sb = np.square(rows - mb).sum(0)
+        tot = self._n + nb
+        delta = mb - self._M
+        self._S[...] = self._S + Sb + np.square(delta) * (self._n * nb / tot)
+        self._M[...] = self._M + delta * (nb / tot)
+        self._n = tot
+
     def push(self, x):
         x = np.asarray(x)
         assert x.shape == self._M.shape
-        self._n += 1
-        if self._n == 1:
-            self._M[...] = x
-        else:
-            oldM = self._M.copy()
-            self._M[...] = oldM + (x - oldM) / self._n
-            self._S[...] = self._S + (x - oldM) * (x - self._M)
+        self.merge(x[None])
 
     n = property(lambda self: self._n)
     mean = property(lambda self: self._M)

@@ -31,7 +31,15 @@ def _cfg():
     return Config("box_future5_light_add_geom", cfg_dict=d)
 
 
-def _worker(rank, world, port, q):
+def _episode_valid(T, N):
+    """whole-episode batches: env e holds 2 + (3 e) % (T - 2) valid steps, so ranks hold unequal sample counts"""
+    valid = torch.zeros(T, N, dtype=torch.bool)
+    for e in range(N):
+        valid[:2 + (3 * e) % (T - 2), e] = True
+    return valid
+
+
+def _worker(rank, world, port, q, episodes=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,9 +48,16 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     learner = PPOLearner(_cfg(), 24, 6, "cpu", torch.float64, distributed=True)
     full = _make_batch(1, 6, 8, 24, 6)
-    sl = slice(rank * 4, (rank + 1) * 4)
+    per = 8 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    if episodes:
+        # unequal split of the envs on purpose (rank 0 gets 3 of 8 at world 2) on top of unequal per-env counts
+        cut = [0, 3, 8] if world == 2 else [per * r for r in range(world + 1)]
+        sl = slice(cut[rank], cut[rank + 1])
+        full.valid = _episode_valid(6, 8); full.next_values = None
+        full.masks = torch.where(torch.roll(full.valid, -1, 0) & full.valid, full.masks, torch.zeros_like(full.masks))
     from types import SimpleNamespace
-    part = SimpleNamespace(**{k: (v[:, sl] if v.dim() >= 2 else v[sl]) for k, v in vars(full).items()})
+    part = SimpleNamespace(**{k: (v if v is None else (v[:, sl] if v.dim() >= 2 else v[sl])) for k, v in vars(full).items()})
     learner.update_params(part)
     # two sampling rounds, a sync after each (agent.sample does one per iteration)
     zf = BatchZFilter(24); zf.push(full.states[:3, sl].reshape(-1, 24)); zf.sync()
@@ -54,27 +69,39 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process():
+import pytest
+
+
+@pytest.mark.parametrize("world,episodes", [(2, False), (4, False), (2, True)])
+def test_ranks_equal_one_process(world, episodes):
+    """world 2 and 4, fixed-horizon batches (equal shares) and whole-episode batches (unequal sample counts per rank:
+    the local means are weighted by M_r * world / sum M).  PPOLearner.optimize starts each gradient all-reduce
+    asynchronously and finishes it after the OTHER network's pass; the result must still be the single-process one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, episodes)) for r in range(world)]
     for p in procs:
         p.start()
-    pol2, val2, zmean, zS, zn = q.get(timeout=90)
+    pol2, val2, zmean, zS, zn = q.get(timeout=180)
     for p in procs:
-        p.join(60)
+        p.join(90)
         assert p.exitcode == 0
     from hoic_amd.agent import PPOLearner
     from hoic_amd.rl import BatchZFilter
     torch.manual_seed(0)
     single = PPOLearner(_cfg(), 24, 6, "cpu", torch.float64, distributed=False)
     full = _make_batch(1, 6, 8, 24, 6)
+    if episodes:
+        full.valid = _episode_valid(6, 8); full.next_values = None
+        full.masks = torch.where(torch.roll(full.valid, -1, 0) & full.valid, full.masks, torch.zeros_like(full.masks))
     single.update_params(full)
     for k, v in single.policy_net.state_dict().items():
         np.testing.assert_allclose(v.numpy(), pol2[k], atol=1e-12, err_msg=k)
     for k, v in single.value_net.state_dict().items():
         np.testing.assert_allclose(v.numpy(), val2[k], atol=1e-12, err_msg=k)
+    if episodes:
+        return                      # the filter part below splits the envs evenly
     zf = BatchZFilter(24); zf.push(full.states.reshape(-1, 24))
     np.testing.assert_allclose(zf.mean.numpy(), zmean, atol=1e-12)
     np.testing.assert_allclose(zf.S.numpy(), zS, rtol=1e-10, atol=1e-10)

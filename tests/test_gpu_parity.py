@@ -8,6 +8,8 @@ Tolerances (float32 kernel vs float64 oracle, stated per quantity):
   obs / reward after k env steps   : 2e-4 absolute over the first steps of an episode (contact dynamics amplify
                                      rounding; long open-loop trajectories are compared statistically instead)
 """
+import types
+
 import numpy as np
 import pytest
 import torch
@@ -479,6 +481,83 @@ def test_agent_iteration_runs_and_learns_something(box_blob, setup):
     for side in ("mimic", "ref"):
         assert all(np.isfinite(v) for v in ph[side].values()) and 0 <= ph[side]["plausible_frame_ratio"] <= 100
     assert ph["ref"]["frames"] == ph["mimic"]["frames"] > 10
+
+
+def _small_agent(ex, n_envs, min_batch, mode="fixed", seed=1, log_std=-2.3):
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config, release_cfg_dict
+    d = release_cfg_dict("box"); d["min_batch_size"] = min_batch; d["policy_hsize"] = [256, 128]; d["value_hsize"] = [256, 128]
+    d["seed"] = seed; d["log_std"] = log_std
+    cfg = Config("box_future5_light_add_geom", cfg_dict=d)
+    return AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode)
+
+
+def test_logger_statistics_exclude_end_bonus(box_blob, box_model):
+    """LoggerRL's c_reward statistics are taken before the end bonus is added (agent_handmimic.py:476-482,
+    logger_rl.py:28-34); they feed env.end_reward of the next iteration (:318-319).  Short sequences and a nearly
+    deterministic policy so that many episodes reach their end inside the window."""
+    ex = motions.synthetic_expert(box_model, 3, 40)       # 40 frames: start 0, 'end' after 34 steps
+    agent = _small_agent(ex, 64, 64 * 80, log_std=-6.0)
+    agent.env.end_reward = 7.5; agent.per_epoch_update(0)
+    assert agent.env.pushed_end_reward == 7.5
+    batch, log = agent.sample(agent.cfg.min_batch_size)
+    flags_end = batch.rewards > 2.0                        # a step reward is <= 1 without the bonus
+    assert int(flags_end.sum()) > 20, "the test needs episodes that reach the sequence end"
+    assert log.max_c_reward <= 1.0 + 1e-6 and log.min_c_reward >= 0.0
+    raw = batch.rewards.double() - 7.5 * flags_end.double()
+    np.testing.assert_allclose(log.total_c_reward, float(raw.sum()), rtol=1e-6)
+    np.testing.assert_allclose(log.avg_c_reward, float(raw.mean()), rtol=1e-6)
+    assert log.num_steps == batch.rewards.numel() and log.total_reward == log.num_steps
+    assert log.num_episodes == int((batch.masks == 0).sum()) and abs(log.avg_episode_len - log.num_steps / max(log.num_episodes, 1)) < 1e-9
+    assert log.avg_episode_reward == log.avg_episode_len         # env reward is 1.0 per step (ho_im4.py:662)
+    assert log.end_bonus == 7.5 and log.avg_c_info.shape == (9,)
+    # optimize_policy feeds the un-bonused mean back (agent_handmimic.py:318-319)
+    info = agent.optimize_policy(1, save_model=False)
+    g = agent.cfg.gamma
+    np.testing.assert_allclose(agent.env.end_reward, info["log"].avg_c_reward * g / (1 - g), rtol=1e-12)
+    assert info["log"].avg_c_reward <= 1.0
+    agent.env.close()
+
+
+def test_sample_episodes_mode_is_the_reference_batch(box_blob, setup):
+    """sample_mode='episodes' (sample_process, agent_handmimic.py:430-501): every env collects whole episodes until it
+    holds floor(min_batch / n_envs) steps; every episode in the batch is complete, nothing is bootstrapped."""
+    _, ex, _ = setup
+    N, B = 16, 16 * 40
+    agent = _small_agent(ex, N, B, mode="episodes")
+    batch, log = agent.sample(B)
+    valid, masks = batch.valid, batch.masks
+    T = valid.shape[0]
+    assert batch.next_values is None and valid.shape == masks.shape == batch.rewards.shape == (T, N)
+    v = valid.cpu().numpy(); m = masks.cpu().numpy()
+    quota = B // N
+    for e in range(N):
+        col = v[:, e]
+        n = int(col.sum())
+        assert n >= quota and col[:n].all() and not col[n:].any()          # one contiguous run from step 0
+        assert m[n - 1, e] == 0.0                                             # ... that ends with an episode end
+        ends = np.nonzero(m[:n, e] == 0.0)[0]
+        assert n - 1 == ends[-1] and (len(ends) == 1 or ends[-2] + 1 < quota)   # stopped at the FIRST end at or past the quota
+    assert log.num_steps == int(v.sum()) and log.num_episodes == int(((m == 0) & v).sum())
+    assert 0 < log.avg_c_reward <= 1 and log.max_c_reward <= 1 + 1e-6
+    # the update consumes only the valid rows; padded rows change nothing
+    sd0 = {k: t.clone() for k, t in agent.policy_net.state_dict().items()}
+    vd0 = {k: t.clone() for k, t in agent.value_net.state_dict().items()}
+    agent.update_params(batch)
+    p1 = [t.clone() for t in agent.policy_net.parameters()]
+    agent2 = _small_agent(ex, N, B, mode="episodes")
+    agent2.policy_net.load_state_dict(sd0); agent2.value_net.load_state_dict(vd0)
+    junk = types.SimpleNamespace(**vars(batch))
+    junk.states = torch.where(valid[..., None], batch.states, torch.full_like(batch.states, 3.0))
+    junk.rewards = torch.where(valid, batch.rewards, torch.full_like(batch.rewards, -50.0))
+    agent2.update_params(junk)
+    for a, b in zip(p1, agent2.policy_net.parameters()):
+        assert torch.allclose(a, b, atol=1e-6)
+    # the two modes can alternate on one agent
+    agent.sample_mode = "fixed"
+    b2, l2 = agent.sample(B)
+    assert b2.valid is None and b2.rewards.shape == (B // N, N) and l2.num_steps == B
+    agent.env.close(); agent2.env.close()
 
 
 def _rfc_like_instance(rng, ncon, npt=5):

@@ -1,57 +1,141 @@
 #!/usr/bin/env python3
-"""Reward-curve comparison at equal step count: the same PPO learner fed by
-  (A) the reference-shaped CPU sampler — forked worker processes, one float64 CPU-oracle env each, whole episodes,
-      batch-1 policy forward per step, like uhc/agents/agent_handmimic.py:430-535 — and
-  (B) the batched HIP simulator (AgentHandMimic.sample, 4096 envs on the GPU).
-Both start from the same seeded weights and use the same schedule (Config.update_adaptive_params), the same synthetic
-expert motions and >= cfg.min_batch_size samples per iteration.  Writes one JSON with the two curves.
+"""Reward curves at equal step count, several seeds per arm: the same PPO learner (PPOLearner, same schedule, same
+synthetic motions, >= cfg.min_batch_size samples per iteration) fed by different samplers.
 
-The CPU side uses oracle/ (test infrastructure) as its environment: this script is an evaluation tool, not part of
+Arms
+  cpu_episodes   reference-shaped CPU sampler: forked worker processes, one float64 CPU-oracle env each, WHOLE episodes
+                 until the worker holds floor(min_batch / workers) steps, batch-1 policy forward per step
+                 (uhc/agents/agent_handmimic.py:430-535)
+  cpu_fixed      the batched sampler's FIXED-HORIZON scheme on the CPU oracle: `envs` persistent oracle envs spread over
+                 the workers, ceil(min_batch / envs) steps of every env per iteration, episodes continue across
+                 iterations, value bootstrap at the cut — isolates the simulator from the batching scheme
+  hip_fixed      the product default: AgentHandMimic(sample_mode="fixed") on the HIP simulator
+  hip_episodes   AgentHandMimic(sample_mode="episodes"): the reference's whole-episode batch on the HIP simulator,
+                 n_envs = `--episode-workers` playing num_threads
+  hip_fixed_long fixed horizon with 4x longer windows (envs / 4 environments): a diagnostic for the truncation length
+
+Every `--eval-every` iterations each run evaluates its current policy + observation filter with deterministic
+(mean-action) episodes from frame 0 of all 17 sequences on the HIP simulator (AgentHandMimic.eval_sequences): reward
+per step and tracked fraction.  The output JSON holds every run's curves and, per arm, mean +- std bands over seeds.
+
+The CPU arms use oracle/ (test infrastructure) as their environment: this script is an evaluation tool, not part of
 the product path.  The literal reference sampler (MuJoCo 2.1.0 + mujoco_py) cannot run here.
 
-    python3 tools/reward_curve.py --iters 20 --workers 32 --out profiles/r01_reward_curve.json
+    python3 tools/reward_curve.py --arms cpu_episodes,hip_fixed,hip_episodes --seeds 5 --iters 100 \
+        --out profiles/r02_reward_curve.json
 """
 import argparse
 import json
 import math
 import multiprocessing as mp
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+N_SEQ, SEQ_LEN = 17, 600
 
 
-def worker_main(conn, wid, obj, n_seq, seq_len):
-    """One CPU sampler process (sample_process of the reference): never touches the GPU."""
-    import torch
-    torch.set_num_threads(1)
+# ----------------------------------------------------------------------------------------------- CPU sampler workers
+def _make_worker_env(obj):
     from hoic_amd import mjcf, motions
     from hoic_amd.config import Config
-    from hoic_amd.rl import PolicyGaussian
     from oracle import hoo
     blob = open(mjcf.packaged_model_path(obj), "rb").read()
     model = mjcf.CompiledModel.from_blob(blob)
     cfg = Config(f"{obj}_future5_light_add_geom")
-    ex = motions.synthetic_expert(model, n_seq, seq_len)
-    env = hoo.OracleEnv(blob)
-    env.set_cfg(cfg.jkp, cfg.jkd, cfg.torque_lim, (cfg.pos_diff_thresh, cfg.rot_diff_thresh, cfg.jpos_diff_thresh,
-                                                   cfg.obj_pos_diff_thresh, cfg.obj_rot_diff_thresh))
+    ex = motions.synthetic_expert(model, N_SEQ, SEQ_LEN)
+
+    def new_env():
+        env = hoo.OracleEnv(blob)
+        env.set_cfg(cfg.jkp, cfg.jkd, cfg.torque_lim, (cfg.pos_diff_thresh, cfg.rot_diff_thresh, cfg.jpos_diff_thresh,
+                                                       cfg.obj_pos_diff_thresh, cfg.obj_rot_diff_thresh))
+        return env
+    return cfg, ex, new_env
+
+
+def worker_main(conn, wid, obj, seed, shared, n_fixed_envs):
+    """One CPU sampler process: never touches the GPU.  `shared`: policy parameters in shared memory (name -> tensor)."""
+    import torch
+    torch.set_num_threads(1)
+    from hoic_amd.rl import PolicyGaussian
+    cfg, ex, new_env = _make_worker_env(obj)
     policy = PolicyGaussian(cfg, 32, 617)
-    rng = np.random.default_rng(1000 + wid)
-    torch.manual_seed(1000 + wid)
+    for k, p in policy.named_parameters():
+        p.data = shared[k]                               # views of the parent's shared tensors: no copies per iteration
+    rng = np.random.default_rng(100000 * seed + 1000 + wid)
+    torch.manual_seed(100000 * seed + 1000 + wid)
+    env = new_env()
+    fixed = None                                          # cpu_fixed: persistent envs + their current observations
+
+    def draw():
+        seq = int(rng.integers(0, max(N_SEQ - 1, 1)))                            # never the held-out sequence (:444)
+        return seq, int(rng.integers(0, max(ex[seq]["hand_dof_seq"].shape[0] - 200, 1)))   # (:448)
+
     while True:
         msg = conn.recv()
         if msg is None:
             break
-        if msg[0] == "eval":      # deterministic episode (mean action) on sequence `seq` from frame 0, train-mode termination
-            _, epoch, sd, mean, std, seq = msg
+        kind = msg[0]
+        if kind == "episodes":
+            _, epoch, mean, std, n_steps, end_reward = msg
             cfg.update_adaptive_params(epoch)
             wk = cfg.reward_wk()
-            policy.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            S, A, R, C, M, RAW = [], [], [], [], [], []
+            with torch.no_grad():
+                while len(R) < n_steps:
+                    seq, start = draw()
+                    env.set_expert(ex[seq])
+                    obs = env.reset(start)
+                    for _ in range(10000):
+                        st = np.clip((obs - mean) / (std + 1e-8), -5.0, 5.0)
+                        a = policy.select_action(torch.as_tensor(st[None], dtype=torch.float32))[0].numpy().astype(np.float64)
+                        nobs, info = env.step(a)
+                        c, _ = env.reward(wk)
+                        r = c + end_reward if (end_reward and info["end"]) else c             # (:479-480)
+                        S.append(st.astype(np.float32)); A.append(a.astype(np.float32)); R.append(r); C.append(c)
+                        RAW.append(obs.astype(np.float32)); M.append(0.0 if info["done"] else 1.0)
+                        obs = nobs
+                        if info["done"]:
+                            break
+            conn.send((np.array(S), np.array(A), np.array(R, np.float32), np.array(C, np.float32), np.array(M, np.float32),
+                       np.array(RAW)))
+        elif kind == "fixed":
+            _, epoch, mean, std, T, end_reward = msg
+            cfg.update_adaptive_params(epoch)
+            wk = cfg.reward_wk()
+            if fixed is None:
+                fixed = []
+                for _ in range(n_fixed_envs):
+                    e = new_env(); seq, start = draw(); e.set_expert(ex[seq])
+                    fixed.append([e, e.reset(start)])
+            E = len(fixed)
+            S = np.zeros((T, E, 617), np.float32); A = np.zeros((T, E, 32), np.float32); RAW = np.zeros((T, E, 617), np.float32)
+            R = np.zeros((T, E), np.float32); C = np.zeros((T, E), np.float32); M = np.zeros((T, E), np.float32)
+            with torch.no_grad():
+                for t in range(T):
+                    obs = np.stack([f[1] for f in fixed])
+                    st = np.clip((obs - mean) / (std + 1e-8), -5.0, 5.0)
+                    act = policy.select_action(torch.as_tensor(st, dtype=torch.float32)).numpy().astype(np.float64)
+                    S[t] = st; A[t] = act; RAW[t] = obs
+                    for i, f in enumerate(fixed):
+                        nobs, info = f[0].step(act[i])
+                        c, _ = f[0].reward(wk)
+                        C[t, i] = c; R[t, i] = c + end_reward if (end_reward and info["end"]) else c
+                        M[t, i] = 0.0 if info["done"] else 1.0
+                        if info["done"]:
+                            seq, start = draw(); f[0].set_expert(ex[seq]); nobs = f[0].reset(start)
+                        f[1] = nobs
+            conn.send((S, A, R, C, M, RAW, np.stack([f[1] for f in fixed]).astype(np.float32)))
+        elif kind == "eval":      # deterministic episode on sequence `seq` from frame 0, train-mode termination
+            _, epoch, mean, std, seq = msg
+            cfg.update_adaptive_params(epoch)
+            wk = cfg.reward_wk()
             env.set_expert(ex[seq]); obs = env.reset(0)
             tot, n, pct = 0.0, 0, 0.0
             with torch.no_grad():
@@ -64,34 +148,6 @@ def worker_main(conn, wid, obj, n_seq, seq_len):
                     if info["done"]:
                         break
             conn.send((seq, tot, n, pct))
-            continue
-        epoch, sd, mean, std, n_steps, end_reward = msg
-        cfg.update_adaptive_params(epoch)
-        wk = cfg.reward_wk()
-        policy.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-        policy.action_log_std.data.fill_(float(cfg.adp_log_std))
-        S, A, R, M, RAW = [], [], [], [], []
-        done_steps = 0
-        with torch.no_grad():
-            while done_steps < n_steps:
-                seq = int(rng.integers(0, max(n_seq - 1, 1)))                       # never the held-out sequence (:444)
-                start = int(rng.integers(0, max(ex[seq]["hand_dof_seq"].shape[0] - 200, 1)))   # (:448)
-                env.set_expert(ex[seq])
-                obs = env.reset(start)
-                for _ in range(10000):
-                    st = np.clip((obs - mean) / (std + 1e-8), -5.0, 5.0)
-                    a = policy.select_action(torch.as_tensor(st[None], dtype=torch.float32))[0].numpy().astype(np.float64)
-                    nobs, info = env.step(a)
-                    r, _ = env.reward(wk)
-                    if end_reward and info["end"]:
-                        r += end_reward                                                   # (:479-480)
-                    S.append(st.astype(np.float32)); A.append(a.astype(np.float32)); R.append(r); RAW.append(obs.astype(np.float32))
-                    M.append(0.0 if info["done"] else 1.0)
-                    done_steps += 1
-                    obs = nobs
-                    if info["done"]:
-                        break
-        conn.send((np.array(S), np.array(A), np.array(R, np.float32), np.array(M, np.float32), np.array(RAW)))
 
 
 def gae_flat(rewards, masks, values, gamma, tau):
@@ -114,162 +170,237 @@ def filter_stats(filt):
     return filt.mean.cpu().numpy(), torch.sqrt(var).cpu().numpy()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--workers", type=int, default=min(32, os.cpu_count() or 1))
-    ap.add_argument("--obj", default="box")
-    ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_reward_curve.json"))
-    args = ap.parse_args()
-    n_seq, seq_len = 17, 600
-
-    # ---- fork the CPU samplers BEFORE anything initialises the GPU in this process
+# ----------------------------------------------------------------------------------------------- one run (arm, seed)
+def run_cpu_arm(args, arm, seed):
+    import torch
+    torch.set_num_threads(1)
+    from hoic_amd.config import Config
+    from hoic_amd.rl import PolicyGaussian
+    cfg = Config(f"{args.obj}_future5_light_add_geom")
+    cfg.seed = seed
+    torch.manual_seed(seed)
+    proto = PolicyGaussian(cfg, 32, 617)                  # only for the parameter shapes of the shared buffers
+    shared = {k: torch.zeros_like(p.data).share_memory_() for k, p in proto.named_parameters()}
+    W = args.workers
+    n_fixed = args.envs // W if arm == "cpu_fixed" else 0
+    # ---- fork the CPU samplers BEFORE anything initialises the GPU in this process (torch is imported, HIP is not)
     ctx = mp.get_context("fork")
     pipes, procs = [], []
-    for wid in range(args.workers):
+    for wid in range(W):
         a, b = ctx.Pipe()
-        p = ctx.Process(target=worker_main, args=(b, wid, args.obj, n_seq, seq_len), daemon=True)
+        p = ctx.Process(target=worker_main, args=(b, wid, args.obj, seed, shared, n_fixed), daemon=True)
         p.start(); pipes.append(a); procs.append(p)
 
-    import torch
+    from types import SimpleNamespace
     from hoic_amd import mjcf, motions
     from hoic_amd.agent import AgentHandMimic, PPOLearner
-    from hoic_amd.config import Config
     from hoic_amd.rl import BatchZFilter
     dev = torch.device("cuda", 0)
-
-    # ---- (A) CPU oracle sampler + the same learner
-    cfg = Config(f"{args.obj}_future5_light_add_geom")
-    torch.manual_seed(int(cfg.seed))
+    torch.manual_seed(seed)
     learner = PPOLearner(cfg, 617, 32, dev)
-    init_policy = {k: v.detach().clone() for k, v in learner.policy_net.state_dict().items()}
-    init_value = {k: v.detach().clone() for k, v in learner.value_net.state_dict().items()}
     filt = BatchZFilter(617, clip=5.0, device=dev)
-    curve_cpu, end_reward = [], 0.0
-    eval_its = sorted(set(list(range(0, args.iters, max(args.iters // 4, 1))) + [args.iters]))
-    ckpt_cpu, ckpt_gpu = {}, {}
-    per_worker = int(math.ceil(cfg.min_batch_size / args.workers))
-    t_cpu0 = time.time()
-    for it in range(args.iters):
-        cfg.update_adaptive_params(it)
-        for g in learner.optimizer_policy.param_groups:
-            g["lr"] = float(cfg.adp_policy_lr)
-        if cfg.fix_std:
-            learner.policy_net.action_log_std.data.fill_(float(cfg.adp_log_std))
-        sd = {k: v.detach().cpu().numpy() for k, v in learner.policy_net.state_dict().items()}
-        mean, std = filter_stats(filt)
-        if it in eval_its:
-            ckpt_cpu[it] = (sd, mean, std)
-        t0 = time.time()
-        for c in pipes:
-            c.send((it, sd, mean, std, per_worker, end_reward))
-        parts = [c.recv() for c in pipes]
-        t_sample = time.time() - t0
-        S = np.concatenate([p[0] for p in parts]); A = np.concatenate([p[1] for p in parts])
-        R = np.concatenate([p[2] for p in parts]); M = np.concatenate([p[3] for p in parts]); RAW = np.concatenate([p[4] for p in parts])
-        filt.push(torch.as_tensor(RAW, device=dev))
-        states = torch.as_tensor(S, device=dev); actions = torch.as_tensor(A, device=dev)
-        with torch.no_grad():
-            values = learner.value_net(states).squeeze(1).double().cpu().numpy()
-        adv, ret = gae_flat(R.astype(np.float64), M.astype(np.float64), values, cfg.gamma, cfg.tau)
-        learner.policy_net.train(); learner.value_net.train()
-        learner.optimize(states, actions, torch.as_tensor(adv, device=dev, dtype=torch.float32)[:, None],
-                         torch.as_tensor(ret, device=dev, dtype=torch.float32)[:, None])
-        n_ep = int((M == 0).sum())
-        raw_r = R.astype(np.float64).sum() - (end_reward * 0)     # end bonus is part of R only on 'end' steps
-        avg_c = float(R.mean())
-        if cfg.end_reward:
-            end_reward = float(avg_c * cfg.gamma / (1 - cfg.gamma))
-        curve_cpu.append({"iter": it, "steps": int(len(R)), "episodes": n_ep, "avg_c_reward": avg_c,
-                          "avg_episode_len": float(len(R) / max(n_ep, 1)), "sample_s": t_sample})
-        print("cpu", curve_cpu[-1], flush=True)
-    t_cpu = time.time() - t_cpu0
-    ckpt_cpu[args.iters] = ({k: v.detach().cpu().numpy() for k, v in learner.policy_net.state_dict().items()},) + filter_stats(filt)
-
-    # ---- (B) batched HIP simulator, same initial weights
-    cfg2 = Config(f"{args.obj}_future5_light_add_geom")
     model = mjcf.load_packaged(args.obj)
-    expert = motions.synthetic_expert(model, n_seq, seq_len)
-    agent = AgentHandMimic(cfg2, device=dev, n_envs=args.envs, model=args.obj, expert_seqs=expert)
-    agent.policy_net.load_state_dict(init_policy); agent.value_net.load_state_dict(init_value)
-    curve_gpu = []
-    t_gpu0 = time.time()
-    for it in range(args.iters):
-        if it in eval_its:
-            ckpt_gpu[it] = ({k: v.detach().cpu().numpy() for k, v in agent.policy_net.state_dict().items()},) + filter_stats(agent.running_state)
-        info = agent.optimize_policy(it, save_model=False)
-        log = info["log"]
-        curve_gpu.append({"iter": it, "steps": int(log.num_steps), "episodes": int(log.num_episodes),
-                          "avg_c_reward": float(log.avg_c_reward), "avg_episode_len": float(log.avg_episode_len),
-                          "sample_s": float(info["T_sample"])})
-        print("gpu", curve_gpu[-1], flush=True)
-    t_gpu = time.time() - t_gpu0
-    ckpt_gpu[args.iters] = ({k: v.detach().cpu().numpy() for k, v in agent.policy_net.state_dict().items()},) + filter_stats(agent.running_state)
+    expert = motions.synthetic_expert(model, N_SEQ, SEQ_LEN)
+    evalr = AgentHandMimic(Config(f"{args.obj}_future5_light_add_geom"), device=dev, n_envs=32, model=args.obj, expert_seqs=expert)
 
-    # ---- evaluation: every checkpoint of both runs on BOTH simulators (deterministic episodes from frame 0 of every
-    # sequence incl. the held-out one, train-mode termination): mean reward per step and fraction of the sequence tracked
-    def eval_oracle(ck, epoch):
-        sd, mean, std = ck
-        jobs = list(range(n_seq)); res = []
+    def publish():
+        for k, p in learner.policy_net.named_parameters():
+            shared[k].copy_(p.detach().cpu())
+
+    def evaluate(it):
+        evalr.cfg.update_adaptive_params(min(it, args.iters - 1))
+        evalr.policy_net.load_state_dict(learner.policy_net.state_dict())
+        evalr.running_state = filt
+        return evalr.eval_sequences()
+
+    def evaluate_oracle(it):
+        mean, std = filter_stats(filt)
+        jobs = list(range(N_SEQ)); res = []
         while jobs:
             batch = jobs[:len(pipes)]; jobs = jobs[len(pipes):]
             for c, sq in zip(pipes, batch):
-                c.send(("eval", epoch, sd, mean, std, sq))
+                c.send(("eval", min(it, args.iters - 1), mean, std, sq))
             res += [c.recv() for c, _ in zip(pipes, batch)]
         tot = sum(r[1] for r in res); n = sum(r[2] for r in res)
         return {"reward_per_step": tot / max(n, 1), "mean_len": n / len(res), "mean_percent": float(np.mean([r[3] for r in res]))}
 
-    @torch.no_grad()
-    def eval_gpu(ck, epoch):
-        sd, mean, std = ck
-        pol = agent.policy_net
-        keep = {k: v.detach().clone() for k, v in pol.state_dict().items()}
-        pol.load_state_dict({k: torch.as_tensor(v, device=dev) for k, v in sd.items()}); pol.eval()
-        saved_bonus = agent.env.end_reward; agent.env.end_reward = 0.0      # the oracle evaluation has no end bonus either
-        cfg2.update_adaptive_params(epoch); agent.env.update_reward_params(); agent.env.set_mode("train")
-        N = args.envs
-        seq = (torch.arange(N) % n_seq).to(torch.int32)
-        obs = agent.env.reset(seq, torch.zeros(N, dtype=torch.int32))
-        m_t = torch.as_tensor(mean, device=dev, dtype=torch.float32); s_t = torch.as_tensor(std, device=dev, dtype=torch.float32)
-        alive = torch.ones(N, dtype=torch.bool, device=dev); tot = torch.zeros(N, device=dev, dtype=torch.float64)
-        n = torch.zeros(N, device=dev); pct = torch.zeros(N, device=dev)
-        for _ in range(seq_len):
-            st = torch.clamp((obs - m_t) / (s_t + 1e-8), -5.0, 5.0)
-            a = pol.select_action(st, mean_action=True)
-            obs, _, done, info = agent.env.step(a)
-            tot += torch.where(alive, agent.env.c_reward.double(), torch.zeros_like(tot)); n += alive.float()
-            pct = torch.where(alive, info["percent"], pct)
-            alive &= ~done
-            if not bool(alive.any()):
-                break
-        pol.load_state_dict(keep)
-        agent._obs = None
-        agent.env.end_reward = saved_bonus; agent.env.update_reward_params()
-        sel = slice(0, n_seq)
-        return {"reward_per_step": float(tot[sel].sum() / n[sel].sum()), "mean_len": float(n[sel].mean()), "mean_percent": float(pct[sel].mean())}
-
-    evals = []
-    for it in sorted(ckpt_cpu):
-        row = {"iter": it}
-        for name, ck in (("cpu_trained", ckpt_cpu[it]), ("gpu_trained", ckpt_gpu[it])):
-            row[name] = {"on_oracle": eval_oracle(ck, min(it, args.iters - 1)), "on_hip": eval_gpu(ck, min(it, args.iters - 1))}
-        evals.append(row)
-        print("eval", json.dumps(row), flush=True)
+    curve, evals, end_reward = [], [], 0.0
+    T_fixed = int(math.ceil(cfg.min_batch_size / max(n_fixed * W, 1))) if arm == "cpu_fixed" else 0
+    per_worker = int(math.floor(cfg.min_batch_size / W))                   # thread_batch_size (:509)
+    t_start = time.time()
+    for it in range(args.iters + 1):
+        cfg.update_adaptive_params(min(it, args.iters - 1))
+        for g in learner.optimizer_policy.param_groups:
+            g["lr"] = float(cfg.adp_policy_lr)
+        if cfg.fix_std:
+            learner.policy_net.action_log_std.data.fill_(float(cfg.adp_log_std))
+        publish()
+        if it % args.eval_every == 0 or it == args.iters:
+            ev = {"iter": it, "on_hip": evaluate(it)}
+            if it in (0, args.iters):
+                ev["on_oracle"] = evaluate_oracle(it)
+            evals.append(ev); print(arm, seed, "eval", json.dumps(ev), flush=True)
+        if it == args.iters:
+            break
+        mean, std = filter_stats(filt)
+        t0 = time.time()
+        if arm == "cpu_episodes":
+            for c in pipes:
+                c.send(("episodes", it, mean, std, per_worker, end_reward))
+            parts = [c.recv() for c in pipes]
+            t_sample = time.time() - t0
+            S, A, R, C, M, RAW = [np.concatenate([p[i] for p in parts]) for i in range(6)]
+            filt.push(torch.as_tensor(RAW, device=dev))
+            states = torch.as_tensor(S, device=dev); actions = torch.as_tensor(A, device=dev)
+            with torch.no_grad():
+                values = learner.value_net(states).squeeze(1).double().cpu().numpy()
+            adv, ret = gae_flat(R.astype(np.float64), M.astype(np.float64), values, cfg.gamma, cfg.tau)
+            learner.policy_net.train(); learner.value_net.train()
+            learner.optimize(states, actions, torch.as_tensor(adv, device=dev, dtype=torch.float32)[:, None],
+                             torch.as_tensor(ret, device=dev, dtype=torch.float32)[:, None])
+        else:
+            for c in pipes:
+                c.send(("fixed", it, mean, std, T_fixed, end_reward))
+            parts = [c.recv() for c in pipes]
+            t_sample = time.time() - t0
+            S, A, R, C, M, RAW = [np.concatenate([p[i] for p in parts], axis=1) for i in range(6)]
+            nxt = np.concatenate([p[6] for p in parts])
+            filt.push(torch.as_tensor(RAW.reshape(-1, 617), device=dev))
+            tt = lambda x: torch.as_tensor(x, device=dev)
+            with torch.no_grad():
+                nv = learner.value_net(filt(tt(nxt), update=False)).squeeze(1)
+            batch = SimpleNamespace(states=tt(S), actions=tt(A), rewards=tt(R), masks=tt(M), next_values=nv, valid=None)
+            learner.update_params(batch)
+        n_ep = int((M == 0).sum())
+        avg_c = float(C.astype(np.float64).mean())              # WITHOUT the end bonus (LoggerRL.step, :476-482)
+        if cfg.end_reward:
+            end_reward = float(avg_c * cfg.gamma / (1 - cfg.gamma))       # (:318-319)
+        curve.append({"iter": it, "steps": int(C.size), "episodes": n_ep, "avg_c_reward": avg_c,
+                      "avg_episode_len": float(C.size / max(n_ep, 1)), "sample_s": t_sample})
+        if it % 10 == 0:
+            print(arm, seed, curve[-1], flush=True)
     for c in pipes:
         c.send(None)
-    out = {"what": "avg custom reward per collected step (LoggerRL.avg_c_reward) per PPO iteration; same learner, same "
-                   "initial weights and schedule; (cpu) float64 CPU-oracle envs, whole episodes per worker process; "
-                   "(gpu) float32 HIP batched simulator, fixed-horizon batches",
-           "obj": args.obj, "iters": args.iters, "workers": args.workers, "envs": args.envs,
-           "cpu": curve_cpu, "gpu": curve_gpu, "wall_s": {"cpu": t_cpu, "gpu": t_gpu},
-           "eval_what": "deterministic (mean-action) episodes from frame 0 of all 17 sequences, train-mode termination; every "
-                        "checkpoint of both runs evaluated on both simulators (oracle = float64 CPU restatement, hip = the product)",
-           "eval": evals}
-    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    return {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "workers": W}
+
+
+def run_hip_arm(args, arm, seed):
+    import torch
+    from hoic_amd import mjcf, motions
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config
+    dev = torch.device("cuda", 0)
+    cfg = Config(f"{args.obj}_future5_light_add_geom")
+    cfg.seed = seed
+    model = mjcf.load_packaged(args.obj)
+    expert = motions.synthetic_expert(model, N_SEQ, SEQ_LEN)
+    torch.manual_seed(seed)
+    mode, n_envs = {"hip_fixed": ("fixed", args.envs), "hip_episodes": ("episodes", args.episode_workers),
+                    "hip_fixed_long": ("fixed", max(args.envs // 4, 1))}[arm]
+    agent = AgentHandMimic(cfg, device=dev, n_envs=n_envs, model=args.obj, expert_seqs=expert, sample_mode=mode)
+    curve, evals = [], []
+    t_start = time.time()
+    for it in range(args.iters + 1):
+        if it % args.eval_every == 0 or it == args.iters:
+            cfg.update_adaptive_params(min(it, args.iters - 1))
+            ev = {"iter": it, "on_hip": agent.eval_sequences()}
+            evals.append(ev); print(arm, seed, "eval", json.dumps(ev), flush=True)
+        if it == args.iters:
+            break
+        info = agent.optimize_policy(it, save_model=False)
+        log = info["log"]
+        curve.append({"iter": it, "steps": int(log.num_steps), "episodes": int(log.num_episodes),
+                      "avg_c_reward": float(log.avg_c_reward), "avg_episode_len": float(log.avg_episode_len),
+                      "sample_s": float(info["T_sample"])})
+        if it % 10 == 0:
+            print(arm, seed, curve[-1], flush=True)
+    return {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "envs": n_envs,
+            "sample_mode": mode}
+
+
+# ----------------------------------------------------------------------------------------------- driver
+def bands(runs):
+    """mean +- std over seeds of the evaluation quantities, per arm and evaluation iteration"""
+    out = {}
+    for arm in sorted({r["arm"] for r in runs}):
+        rs = [r for r in runs if r["arm"] == arm]
+        its = [e["iter"] for e in rs[0]["eval"]]
+        rows = []
+        for k, it in enumerate(its):
+            rp = np.array([r["eval"][k]["on_hip"]["reward_per_step"] for r in rs])
+            pc = np.array([r["eval"][k]["on_hip"]["mean_percent"] for r in rs])
+            rows.append({"iter": it, "reward_per_step_mean": float(rp.mean()), "reward_per_step_std": float(rp.std(ddof=1)) if len(rp) > 1 else 0.0,
+                         "tracked_mean": float(pc.mean()), "tracked_std": float(pc.std(ddof=1)) if len(pc) > 1 else 0.0, "seeds": len(rs)})
+        cr = np.array([[c["avg_c_reward"] for c in r["curve"]] for r in rs])
+        out[arm] = {"eval": rows, "avg_c_reward_mean": cr.mean(0).tolist(), "avg_c_reward_std": (cr.std(0, ddof=1) if len(rs) > 1 else np.zeros(cr.shape[1])).tolist()}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arms", default="cpu_episodes,hip_fixed,hip_episodes")
+    ap.add_argument("--seeds", type=int, default=5)
+    ap.add_argument("--cpu-fixed-seeds", type=int, default=None, help="seeds of the cpu_fixed arm (default: --seeds)")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--eval-every", type=int, default=5)
+    ap.add_argument("--workers", type=int, default=32, help="sampler processes per CPU run (the reference's --num_threads)")
+    ap.add_argument("--obj", default="box")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--episode-workers", type=int, default=64, help="n_envs of the hip_episodes arm (plays num_threads)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_reward_curve.json"))
+    ap.add_argument("--run-one", nargs=3, metavar=("ARM", "SEED", "OUTFILE"), default=None)
+    args = ap.parse_args()
+
+    if args.run_one:
+        arm, seed, outfile = args.run_one[0], int(args.run_one[1]), args.run_one[2]
+        res = run_cpu_arm(args, arm, seed) if arm.startswith("cpu") else run_hip_arm(args, arm, seed)
+        json.dump(res, open(outfile, "w"))
+        return
+
+    arms = [a for a in args.arms.split(",") if a]
+    tmp = tempfile.mkdtemp(prefix="rcurve_")
+    jobs = []
+    for arm in arms:
+        ns = args.cpu_fixed_seeds if (arm == "cpu_fixed" and args.cpu_fixed_seeds is not None) else args.seeds
+        jobs += [(arm, 1 + s) for s in range(ns)]
+    # every run is its own process (its own HIP context); CPU runs and whole-episode HIP runs are latency-bound and run
+    # side by side, the fixed-horizon HIP runs fill the GPU and go one after the other
+    common = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--eval-every", str(args.eval_every),
+              "--workers", str(args.workers), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
+    t0 = time.time()
+    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes")], [j for j in jobs if j[0] in ("hip_fixed", "hip_fixed_long")]
+    procs = []
+    for arm, seed in side:
+        f = os.path.join(tmp, f"{arm}_{seed}.json")
+        procs.append((arm, seed, f, subprocess.Popen(common + ["--run-one", arm, str(seed), f])))
+    for arm, seed in serial:
+        f = os.path.join(tmp, f"{arm}_{seed}.json")
+        p = subprocess.Popen(common + ["--run-one", arm, str(seed), f]); p.wait()
+        procs.append((arm, seed, f, p))
+    runs = []
+    for arm, seed, f, p in procs:
+        p.wait()
+        if p.returncode != 0 or not os.path.exists(f):
+            print(f"run {arm} seed {seed} failed (exit {p.returncode})", flush=True)
+            continue
+        runs.append(json.load(open(f)))
+    out = {"what": "deterministic (mean-action) episodes from frame 0 of all 17 sequences on the HIP simulator, reward per step and "
+                   "tracked fraction, every `eval_every` PPO iterations; avg_c_reward = LoggerRL.avg_c_reward of the collected "
+                   "batch (without the end bonus); the same PPOLearner / schedule / synthetic motions in every arm",
+           "arms": {"cpu_episodes": "float64 CPU-oracle envs, whole episodes per worker process (reference-shaped)",
+                    "cpu_fixed": "float64 CPU-oracle envs, the batched sampler's fixed-horizon scheme",
+                    "hip_fixed": "HIP simulator, fixed-horizon batches with value bootstrap (product default)",
+                    "hip_episodes": "HIP simulator, whole-episode batches (sample_mode='episodes')",
+                    "hip_fixed_long": "HIP simulator, fixed horizon, 4x fewer envs and 4x longer windows"},
+           "obj": args.obj, "iters": args.iters, "eval_every": args.eval_every, "workers": args.workers, "envs": args.envs,
+           "episode_workers": args.episode_workers, "host_cores": os.cpu_count(), "wall_s": time.time() - t0,
+           "bands": bands(runs), "runs": runs}
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
-    a = np.array([c["avg_c_reward"] for c in curve_cpu]); b = np.array([c["avg_c_reward"] for c in curve_gpu])
-    print("avg_c_reward first/last  cpu %.4f -> %.4f   gpu %.4f -> %.4f   max |cpu - gpu| %.4f" % (a[0], a[-1], b[0], b[-1], np.abs(a - b).max()))
+    for arm, b in out["bands"].items():
+        e = b["eval"][-1]
+        print(f"{arm:15s} seeds {e['seeds']}  final reward/step {e['reward_per_step_mean']:.4f} +- {e['reward_per_step_std']:.4f}  "
+              f"tracked {e['tracked_mean']:.3f} +- {e['tracked_std']:.3f}")
 
 
 if __name__ == "__main__":
