@@ -34,7 +34,7 @@ __device__ void load_state(const DevModel& m, const DevState& st, Work& w, int e
     w.ctrl[tid] = 0.f; w.applied[tid] = 0.f; w.qacc[tid] = 0.f;
   }
   if (tid < NHG) { for (int i = 0; i < 12; i++) w.rec_sum[tid][i] = 0.f; w.rec_cnt[tid] = 0; }
-  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; }
+  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; w.capped = 0; }
   wsync();
 }
 __device__ void store_state(const DevState& st, const Work& w, int env) {
@@ -59,22 +59,11 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   if (tid < NV) w.fsmooth[tid] = fs;
   PT(20);
   float a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs); PT(8);     // unconstrained acceleration
-#ifdef HOIC_EXP_EXTRA_HSOLVE   // cost experiment: extra dependent solves per forward pass
-  for (int rep = 0; rep < HOIC_EXP_EXTRA_HSOLVE; rep++) a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs + 1e-30f * a0);
-#endif
   if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
   wsync();
   RowK rk;
   dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
-#ifdef HOIC_EXP_CONS
-  for (int rep = 0; rep < HOIC_EXP_CONS; rep++) { asm volatile("" ::: "memory"); dev_make_constraint(m, w, rk, w.qpos, w.qvel); }
-#endif
-#ifndef HOIC_X_NOSOLVE
   dev_solve(m, w, M, rk, cfg.c.solver_iterations); PT(9);
-#endif
-#ifdef HOIC_EXP_SOLVE
-  for (int rep = 0; rep < HOIC_EXP_SOLVE; rep++) { asm volatile("" ::: "memory"); dev_solve(m, w, M, rk, cfg.c.solver_iterations); }
-#endif
   float bad = 0.f;
   if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
   return !(wave_max(bad) > 0.f);
@@ -150,7 +139,8 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
   }
   if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
   if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
-    const int ns = next_seq[io], nst = next_start[io];
+    const int ns = min(max(next_seq[io], 0), ex.n_seq - 1);
+    const int nst = min(max(next_start[io], 0), as_global(ex.seq_len)[ns] - 2);
     wsync();
     dev_reset_state(m, w, ex, ns, nst);
     dev_kinematics(m, w, w.qpos);
@@ -205,7 +195,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
     vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
   }
-  int* ovf = (int*)&as_global(st.overflow)[env];
+  int* ovf = (int*)&as_global(st.diag)[2 * env];
+  int ncapped = 0;
   GPTR(float) post = as_global(st.post) + (size_t)env * PB_SIZE;
   GPTR(float) oldg = as_global(st.oldg) + (size_t)env * OG_SIZE;
   // One loop, three modes, so that every stage has a single (inlined) call site:
@@ -215,11 +206,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   //   mode 2  after a failed substep: kinematics of the restored state for the observation / reward
   float old_objvel = 0.f;
   bool ok = true;
-#ifdef HOIC_DBG_NSUB
-  const int nsub = HOIC_DBG_NSUB;
-#else
   const int nsub = cfg.c.sim_step;
-#endif
   int mode = 0, done_sub = 0;
   // The quantities of the previous forward pass that the first substep reads (M and bias for the PD torque, motion axes
   // for the applied forces, contacts for the bookkeeping) were left behind by the previous launch; only an env whose
@@ -254,16 +241,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     PT(0);
     if (mode == 1) {
       dev_record_contact(ml, w); PT(2);           // :543 (contacts of the previous forward pass)
-#ifndef HOIC_X_NOPD
       dev_pd_torque(ml, cl, w, M, ev); PT(1);     // :518-523
-#endif
       dev_applied(ml, cl, w, vf, vt);             // :526-540
-#ifdef HOIC_EXP_GLUE
-      { asm volatile("" ::: "memory"); dev_record_contact(ml, w); dev_applied(ml, cl, w, vf, vt); }
-#endif
-#ifdef HOIC_EXP_PD
-      { asm volatile("" ::: "memory"); dev_pd_torque(ml, cl, w, M, ev); }
-#endif
     }
     dev_forward_kin(ml, w, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
     if (mode == 0) {
@@ -278,6 +257,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     if (mode == 2) break;
     ok = dev_forward_dyn(ml, cl, w, M);       // :545 mj_step = forward ...
+    ncapped += w.capped;
 #ifdef HOIC_TRACE_DISPATCH
     trace_ncon += w.ncon; trace_iter += w.solver_iter; trace_ncon_max = max(trace_ncon_max, w.ncon);
     if (done_sub >= nsub - 5) trace_late += w.solver_iter;
@@ -290,10 +270,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       mode = 2;
       continue;
     }
-#ifdef HOIC_EXP_EULER
-    { if (tid < NV) w.tv0[tid] = w.qvel[tid]; if (tid < NQP) w.tq0[tid] = w.qpos[tid]; wsync(); dev_euler(ml, w, M);
-      if (tid < NV) w.qvel[tid] = w.tv0[tid]; if (tid < NQP) w.qpos[tid] = w.tq0[tid]; wsync(); }
-#endif
     dev_euler(ml, w, M); PT(10);              //              ... + Euler
     if (++done_sub >= nsub) break;
   }
@@ -351,7 +327,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
     }
   }
-  if (tid == 0) as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0;
+  if (tid == 0) { as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0; if (ncapped) as_global(st.diag)[2 * env + 1] += ncapped; }
   const long long clk1 = (long long)__builtin_readcyclecounter();
   if (tid == 0) as_global(st.cost)[env] = (unsigned)((clk1 - clk0) >> 6);
   if (fused) {
@@ -469,12 +445,15 @@ __global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __
 
 __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restrict__ mp, DevExpert ex, DevState st,
                                                         const int* __restrict__ env_ids, const int* __restrict__ seqs,
-                                                        const int* __restrict__ starts, float* __restrict__ obs) {
+                                                        const int* __restrict__ starts, float* __restrict__ obs, int n_envs) {
   __shared__ Work w;
   const DevModel& m = *mp;
   const int k = blockIdx.x, tid = threadIdx.x;
   const int env = env_ids ? env_ids[k] : k;
-  const int seq = seqs[k], start = starts[k];
+  if (env < 0 || env >= n_envs) return;              // ids outside the batch are ignored (wave-uniform)
+  // device-side draws are clamped into the table: sequence in [0, n_seq), start so that two frames remain
+  const int seq = min(max(seqs[k], 0), ex.n_seq - 1);
+  const int start = min(max(starts[k], 0), as_global(ex.seq_len)[seq] - 2);
   if (tid < NQP) w.qpos[tid] = 0.f;
   wsync();
   dev_reset_state(m, w, ex, seq, start);
@@ -503,6 +482,17 @@ __global__ __launch_bounds__(NT) void hoic_get_state_kernel(const DevModel* __re
   if (cur_t && tid == 0) cur_t[env] = as_global(st.cur_t)[env];
 }
 
+// after hoic_set_expert: every env's (sequence, start, cur_t) must index the new table (the caller is expected to reset)
+__global__ void hoic_clamp_episode_kernel(DevExpert ex, DevState st, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int sq = st.seq[e]; sq = sq < 0 ? 0 : (sq >= ex.n_seq ? ex.n_seq - 1 : sq);
+  const int len = ex.seq_len[sq];
+  int sa = st.start[e]; sa = sa < 0 ? 0 : (sa > len - 2 ? len - 2 : sa);
+  int ct = st.cur_t[e]; ct = ct < 0 ? 0 : (ct > len - 1 - sa ? len - 1 - sa : ct);
+  st.seq[e] = sq; st.start[e] = sa; st.cur_t[e] = ct; st.lag_valid[e] = 0;
+}
+
 struct ProbeArgs {
   const float *qpos, *qvel, *ctrl, *applied, *warm;
   int do_step;
@@ -520,7 +510,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
     w.applied[tid] = (a.applied && tid < m.nv) ? a.applied[(size_t)env * m.nv + tid] : 0.f;
     w.warm[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;
   }
-  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; }
+  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.capped = 0; }
   wsync();
   dev_load_constants(m, w);
   MReg M;
@@ -825,7 +815,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.qvel, n * NV * 4) == hipSuccess && hipMalloc(&s->st.vlag, n * NV * 4) == hipSuccess &&
        hipMalloc(&s->st.warm, n * NV * 4) == hipSuccess && hipMalloc(&s->st.cur_t, n * 4) == hipSuccess &&
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
-       hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.overflow, n * 4) == hipSuccess &&
+       hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.diag, n * 8) == hipSuccess &&
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
        hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess &&
        hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess &&
@@ -839,7 +829,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.qpos, 0, n * NQP * 4); hipMemset(s->st.qlag, 0, n * NQP * 4); hipMemset(s->st.qvel, 0, n * NV * 4);
   hipMemset(s->st.vlag, 0, n * NV * 4); hipMemset(s->st.warm, 0, n * NV * 4); hipMemset(s->st.cur_t, 0, n * 4);
   hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
-  hipMemset(s->st.overflow, 0, n * 4); hipMemset(s->st.phase, 0, n * 24 * 8);
+  hipMemset(s->st.diag, 0, n * 8); hipMemset(s->st.phase, 0, n * 24 * 8);
   hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
   hipMemset(s->st.cost, 0, 2 * n * 4);
   hipMemset(s->st.lagrec, 0, n * LG_SIZE * 4); hipMemset(s->st.lag_valid, 0, n * 4);
@@ -858,7 +848,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.overflow, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.diag, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   delete s;
@@ -902,15 +892,18 @@ extern "C" int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* se
   if (!s || n_seq <= 0 || !seq_len || !hand_dof || !hand_dof_vel || !obj_pose || !obj_vel || !obj_angvel || !body_pos || !body_quat) {
     set_err("hoic_set_expert: bad arguments"); return HOIC_ERR_ARG;
   }
+  // validate everything before the previous tables are released
+  std::vector<int> off(n_seq);
+  size_t T = 0;
+  for (int i = 0; i < n_seq; i++) { if (seq_len[i] < 2) { set_err("hoic_set_expert: sequence shorter than 2 frames"); return HOIC_ERR_ARG; } off[i] = (int)T; T += seq_len[i]; }
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipDeviceSynchronize());
   for (void* p : s->ex_allocs) hipFree(p);
   s->ex_allocs.clear();
-  std::vector<int> off(n_seq);
-  size_t T = 0;
-  for (int i = 0; i < n_seq; i++) { if (seq_len[i] < 2) { set_err("hoic_set_expert: sequence shorter than 2 frames"); return HOIC_ERR_ARG; } off[i] = (int)T; T += seq_len[i]; }
+  s->has_expert = false;               // until the new tables are complete, step / reset refuse to run
   const int nh = s->hm.hand_nq;
   DevExpert& x = s->ex;
+  x = DevExpert{};
   x.n_seq = n_seq; x.total = (int)T;
   x.seq_off = upload(s, off.data(), n_seq); x.seq_len = upload(s, seq_len, n_seq);
   const size_t R = (size_t)s->expert_reserve;
@@ -920,9 +913,14 @@ extern "C" int32_t hoic_set_expert(hoic_sim* s, int32_t n_seq, const int32_t* se
   s->expert_cap = (int)(T + R);
   s->h_seq_off = off; s->h_seq_len.assign(seq_len, seq_len + n_seq);
   if (!x.seq_off || !x.seq_len || !x.hand_dof || !x.hand_dof_vel || !x.obj_pose || !x.obj_vel || !x.obj_angvel || !x.body_pos || !x.body_quat) {
+    for (void* p : s->ex_allocs) hipFree(p);
+    s->ex_allocs.clear(); x = DevExpert{};
     set_err("hoic_set_expert: hipMalloc failed"); return HOIC_ERR_DEVICE;
   }
   HIPCHK(hipMemcpy(s->d_ex, &s->ex, sizeof(DevExpert), hipMemcpyHostToDevice));
+  // envs still point at (sequence, start) of the previous table: bring them inside the new one until the caller resets
+  hipLaunchKernelGGL(hoic_clamp_episode_kernel, dim3((s->n_envs + 255) / 256), dim3(256), 0, 0, s->ex, s->st, s->n_envs);
+  HIPCHK(hipDeviceSynchronize());
   s->has_expert = true;
   return HOIC_OK;
 }
@@ -962,7 +960,7 @@ extern "C" int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, 
   if (!s || !d_seq || !d_start || n <= 0 || n > s->n_envs) { set_err("hoic_reset: bad arguments"); return HOIC_ERR_ARG; }
   if (!s->has_expert) { set_err("hoic_reset: set_expert has not been called"); return HOIC_ERR_STATE; }
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(hoic_reset_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->ex, s->st, d_env_ids, d_seq, d_start, d_obs_out);
+  hipLaunchKernelGGL(hoic_reset_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->ex, s->st, d_env_ids, d_seq, d_start, d_obs_out, s->n_envs);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -1038,9 +1036,8 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
   if (!s || n <= 0 || !d_qpos || !d_qvel) { set_err("hoic_probe_forward: bad arguments"); return HOIC_ERR_ARG; }
   ProbeArgs a{d_qpos, d_qvel, d_ctrl, d_applied, d_warm, do_step, d_xpos, d_xquat, d_geom_xpos, d_geom_xmat, d_qM, d_bias,
               d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_ncon, d_solver_iter};
-  static const int lds_pad = getenv("HOIC_DBG_LDS_PAD") ? atoi(getenv("HOIC_DBG_LDS_PAD")) : 0;   // occupancy experiments
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), lds_pad, (hipStream_t)stream, s->d_model, s->d_cfg, a);
+  hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->d_cfg, a);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -1100,6 +1097,22 @@ extern "C" int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const 
   return HOIC_OK;
 }
 
+extern "C" int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64_t* solver_cap_hits, int32_t* envs_with_overflow,
+                                        int32_t reset) {
+  if (!s) { set_err("hoic_get_diagnostics: null handle"); return HOIC_ERR_ARG; }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<int> d((size_t)s->n_envs * 2);
+  HIPCHK(hipMemcpy(d.data(), s->st.diag, d.size() * 4, hipMemcpyDeviceToHost));
+  long long ov = 0, cap = 0; int nenv = 0;
+  for (int e = 0; e < s->n_envs; e++) { ov += d[2 * e]; cap += d[2 * e + 1]; nenv += d[2 * e] != 0; }
+  if (contact_overflow_total) *contact_overflow_total = ov;
+  if (solver_cap_hits) *solver_cap_hits = cap;
+  if (envs_with_overflow) *envs_with_overflow = nenv;
+  if (reset) HIPCHK(hipMemset(s->st.diag, 0, d.size() * 4));
+  return HOIC_OK;
+}
+
 extern "C" int32_t hoic_enable_timing(hoic_sim* s, int32_t enable) {
   if (!s) return HOIC_ERR_ARG;
   if (enable && !s->ev[0][0])
@@ -1156,11 +1169,11 @@ extern "C" int32_t hoicdbg_phase_raw(hoic_sim* s, long long* out) {     // devel
 extern "C" int32_t hoicdbg_phase_cycles(hoic_sim* s, double* out24, int32_t* overflow_total) {
   if (!s || !out24) return HOIC_ERR_ARG;
   std::vector<long long> h((size_t)s->n_envs * 24);
-  std::vector<int> ov(s->n_envs);
+  std::vector<int> ov((size_t)s->n_envs * 2);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(h.data(), s->st.phase, h.size() * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(ov.data(), s->st.overflow, ov.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ov.data(), s->st.diag, ov.size() * 4, hipMemcpyDeviceToHost));
   for (int k = 0; k < 24; k++) { double a = 0; for (int e = 0; e < s->n_envs; e++) a += (double)h[(size_t)e * 24 + k]; out24[k] = a / s->n_envs; }
-  if (overflow_total) { long long t = 0; for (int v : ov) t += v; *overflow_total = (int32_t)t; }
+  if (overflow_total) { long long t = 0; for (int e = 0; e < s->n_envs; e++) t += ov[2 * e]; *overflow_total = (int32_t)t; }
   return HOIC_OK;
 }

@@ -26,25 +26,9 @@ struct ExpertView {
 // ---- position + velocity stages of the forward pass on state (q, v); leaves M (registers), bias, contacts, S
 __device__ __forceinline__ void dev_forward_kin(const DevModel& m, Work& w, MReg& M, const float* q, const float* v, int* overflow) {
   dev_kinematics(m, w, q); PT(3);
-#ifdef HOIC_EXP_KIN      // cost experiments (development aid): repeat one stage, measure the kernel-time delta
-  for (int rep = 0; rep < HOIC_EXP_KIN; rep++) { asm volatile("" ::: "memory"); dev_kinematics(m, w, q); }
-#endif
   dev_mass_matrix(m, w, M); PT(4);
-#ifdef HOIC_EXP_MASS
-  for (int rep = 0; rep < HOIC_EXP_MASS; rep++) { asm volatile("" ::: "memory"); dev_mass_matrix(m, w, M); }
-#endif
-#ifndef HOIC_X_NOBIAS
   dev_bias(m, w, v); PT(5);
-#endif
-#ifdef HOIC_EXP_BIAS
-  for (int rep = 0; rep < HOIC_EXP_BIAS; rep++) { asm volatile("" ::: "memory"); dev_bias(m, w, v); }
-#endif
-#ifndef HOIC_X_NOCOLL
   dev_collision(m, w, overflow); PT(6);
-#endif
-#ifdef HOIC_EXP_COLL
-  for (int rep = 0; rep < HOIC_EXP_COLL; rep++) { asm volatile("" ::: "memory"); dev_collision(m, w, nullptr); }
-#endif
 }
 
 // ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass

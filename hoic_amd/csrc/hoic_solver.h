@@ -394,13 +394,14 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   if (usewarm) ev = evw;
   else dev_rows_cost(m, w, dk, rk, D_c, ev);      // forces / curvatures back to the asmooth state
   int it = 0;
+  bool capped = true;     // the loop ran out of iterations (no stop criterion met)
   bool fresh = false;     // jtf holds J'f of the current qacc
   float jtf = 0.f;
   for (; it < maxit; it++) {
     jtf = dev_jt_force(m, w, rk, ev);
     const float g = vd ? (Ma - fs - jtf) : 0.f;
     const float g2 = wave_sum(tid < 32 ? g * g : 0.f);
-    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; break; }
+    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; break; }
     PT(20);
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
     const float sd = dev_hsolve(m, w, M, ev.curv_f + ev.curv_l, m.nv, true, -g);
@@ -440,20 +441,18 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     for (int k = 0; k < NCSLOT; k++) ev.jar_c[k] = fmaf(alpha, jv.jar_c[k], ev.jar_c[k]);
     const float crow = dev_rows_cost(m, w, dk, rk, D_c, ev);
     const float st = wave_max((tid < m.nv) ? fabsf(dq) / (1.f + fabsf(qacc)) : 0.f);
-    if (st < 1e-7f) { it++; break; }
-#ifndef HOIC_NO_IMPROVEMENT_STOP
+    if (st < 1e-7f) { it++; capped = false; break; }
     // MuJoCo's second criterion (engine_solver.c: improvement = scale * (oldcost - cost) < tolerance): once a Newton
     // step no longer lowers the cost, what is left of the gradient is float32 rounding and another Hessian solve
     // would only polish noise
     const float cost = crow + wave_sum((tid < m.nv) ? 0.5f * (Ma - fs) * (qacc - a0) : 0.f);
     const float improvement = scale * (cost_prev - cost);
     cost_prev = cost;
-    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; break; }
-#endif
+    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; capped = false; break; }
   }
   // forces at the final acceleration (the row state already belongs to it)
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);
   if (tid < NV) { w.fcon[tid] = vd ? jtf : 0.f; w.qacc[tid] = qacc; }
-  if (tid == 0) w.solver_iter = it;
+  if (tid == 0) { w.solver_iter = it; w.capped = capped ? 1 : 0; }
   wsync();
 }

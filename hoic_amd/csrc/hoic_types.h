@@ -128,7 +128,8 @@ struct DevState {
   int* start;    // [n]
   int* seq;      // [n]
   float* rfc_score;  // [n]
-  int* overflow; // [n] contact-cap overflow counter
+  int* diag;     // [n, 2] running counters: forward passes that found more than MAXCON contacts (the list is cut after
+                 // MAXCON), substeps whose Newton loop used up cfg.solver_iterations without meeting a stop criterion
   float* post;   // [n, PB_SIZE]
   float* oldg;   // [n, OG_SIZE]
   float* lagrec; // [n, LG_SIZE]
@@ -152,9 +153,6 @@ struct DofK { float floss, flR; };   // friction-loss row constants of dof (lane
 // per-env LDS workspace
 struct Work {
   float qpos[NQP], qvel[NV], qacc[NV], warm[NV], qlag[NQP], vlag[NV], action[NV];
-#ifdef HOIC_EXP_EULER
-  float tv0[NV], tq0[NQP];
-#endif
   // kinematics of the last forward pass
   float xpos[NB][3], xquat[NB][4];
   float gxpos[NG][3];
@@ -198,7 +196,7 @@ struct Work {
     struct { float col_lc[4 * 7 * NT]; float col_poly[32]; };
   };
   // contacts of the current forward pass
-  int ncon, nrow, solver_iter, fail;
+  int ncon, nrow, solver_iter, fail, capped;
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
   unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
   // model constants used every pass (loaded once per launch)

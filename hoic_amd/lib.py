@@ -42,7 +42,7 @@ EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
-           "hoic_append_expert_frame"]
+           "hoic_append_expert_frame", "hoic_get_diagnostics"]
 
 
 def build(force: bool = False) -> str:
@@ -85,7 +85,7 @@ def load():
     L.hoic_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.hoic_set_state.argtypes = [vp, vp, vp, vp]
     L.hoic_get_rfc_score.argtypes = [vp, vp, vp]
-    L.hoic_probe_forward.argtypes = [vp, i32] + [vp] * 5 + [i32] + [vp] * 13
+    L.hoic_probe_forward.argtypes = [vp, i32] + [vp] * 5 + [i32] + [vp] * 14       # 13 outputs + stream
     L.hoic_enable_timing.argtypes = [vp, i32]
     L.hoic_last_step_ms.argtypes = [vp]
     L.hoic_last_step_ms.restype = f32
@@ -100,6 +100,7 @@ def load():
     L.hoic_env_durations.argtypes = [vp, vp, vp]
     L.hoic_set_expert_reserve.argtypes = [vp, i32]
     L.hoic_append_expert_frame.argtypes = [vp] * 9
+    L.hoic_get_diagnostics.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(i32), i32]
     L.hoic_last_poststep_ms.restype = f32
     for n in EXPORTS:
         if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms", "hoic_last_poststep_ms",
@@ -268,6 +269,13 @@ class BatchedSim:
         out = self.torch.zeros(self.n, device=self.device)
         _chk(self.L.hoic_get_rfc_score(self.h, _ptr(out), self._stream()), "hoic_get_rfc_score")
         return out
+
+    def diagnostics(self, reset=False):
+        """{'contact_overflow': forward passes cut at the 32-contact cap, 'solver_cap_hits': substeps whose Newton loop ran
+        out of iterations, 'envs_with_overflow'} accumulated since creation / the last reset (hoic_get_diagnostics)"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        _chk(self.L.hoic_get_diagnostics(self.h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "hoic_get_diagnostics")
+        return {"contact_overflow": int(a.value), "solver_cap_hits": int(b.value), "envs_with_overflow": int(c.value)}
 
     def enable_timing(self, on=True):
         _chk(self.L.hoic_enable_timing(self.h, int(on)), "hoic_enable_timing")

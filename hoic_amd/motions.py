@@ -144,6 +144,32 @@ def preprocess_seq(model: mjcf.CompiledModel, seq: dict, motion_freq: int = 30, 
             "body_quat_seq": xquat[:, hb0:hb0 + nhb].copy(), "seq_len": T}
 
 
+def load_expert(cfg, model: mjcf.CompiledModel, base_dir: str = "", verbose: bool = False, sim=None):
+    """The data loader of the training script (DatasetSingleDepth.__init__, dataset_singledepth.py:21-76): read the pickled
+    ``{seq_name: [{"hand_pose_seq" (T, 26), "obj_pose_seq" (T, 7), ...}, ...]}`` named by ``cfg.data_specs['expert_fn']``
+    and preprocess every sequence; the dataset is a separate download (README.md:61), so without the file the synthetic
+    motions of SURVEY.md §8(d) stand in (17 sequences x 600 frames)."""
+    import os
+    import pickle
+    specs = getattr(cfg, "data_specs", {}) or {}
+    fn = specs.get("expert_fn")
+    path = None
+    for cand in ([fn, os.path.join(base_dir, fn)] if fn else []):
+        if cand and os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
+        if verbose:
+            print(f"[motions] no expert file ({fn!r}): using the synthetic reference motions")
+        return synthetic_expert(model)
+    with open(path, "rb") as f:
+        data = pickle.load(f)
+    seqs = data[specs["seq_name"]]
+    if verbose:
+        print(f"[motions] {len(seqs)} sequences from {path} [{specs['seq_name']}]")
+    return [preprocess_seq(model, s, specs.get("motion_freq", 30), sim=sim) for s in seqs]
+
+
 # ----------------------------------------------------------------------------- synthetic data (SURVEY.md §8(d))
 def _euler_xyz_quat(e):
     cx, cy, cz = np.cos(e / 2).T

@@ -87,7 +87,8 @@ int32_t hoic_append_expert_frame(hoic_sim* s, const float* hand_dof, const float
 /* ---- reset: MujocoEnv.reset + HandObjMimic4.reset_model (mujoco_env.py:95-114, ho_im4.py:690-716) for the
  * envs listed in d_env_ids (n entries, int32; NULL = all envs in order).  d_seq / d_start: per listed env,
  * the sequence index and start frame (agent_handmimic.py:444-452).  d_obs_out: [n_envs,617] rows of the
- * listed envs are overwritten. */
+ * listed envs are overwritten.  Ids outside [0, n_envs) are ignored; sequence / start values are clamped into the
+ * expert table (the same holds for d_next_seq / d_next_start of hoic_step). */
 int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, const int32_t* d_seq, const int32_t* d_start,
                    float* d_obs_out, void* stream);
 
@@ -152,6 +153,18 @@ int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const double* d_s
  * dual-Newton fallback iterations.  Test / diagnostic entry: hoic_step runs the same routine on its own columns. */
 int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, const int32_t* d_ncols, const double* d_rhs,
                       int32_t max_col, double* d_lambda, int32_t* d_stat, void* stream);
+
+/* Run-time guards of the two compiled capacities (the reference model allows nconmax = 100 contacts and 20 solver
+ * iterations, assets/hand_model/spheremesh/sphere_mesh_hand_add_geom.xml:4-8; MuJoCo reports either limit as a warning
+ * in mjData.warning, which the env never reads).  Counters accumulate over all steps since creation or the last reset:
+ *   contact_overflow_total  forward passes in which the narrow phase produced more than 32 contacts for one env; the
+ *                           list is then cut after the first 32 in pair order (floor pairs, table, hand-object, hand-hand)
+ *   solver_cap_hits         substeps whose Newton loop used hoic_env_config.solver_iterations iterations without
+ *                           meeting a stop criterion (gradient, step or cost-improvement tolerance)
+ *   envs_with_overflow      number of envs with at least one overflow
+ * Any output may be NULL; reset != 0 clears the counters.  Synchronises the device. */
+int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64_t* solver_cap_hits,
+                             int32_t* envs_with_overflow, int32_t reset);
 
 /* hoic_step is two launches: the substep kernel (15 fused substeps, the dominant kernel) and the post-step
  * kernel (contact averaging, residual-force QP, termination, reward, observation).  Durations in milliseconds of

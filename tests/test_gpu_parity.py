@@ -363,23 +363,25 @@ def test_episode_reward_parity(box_blob, oracle_lib, setup):
         assert np.abs(qfinal[i][:33] - ref[i][2]).max() < 5e-3, (i, np.abs(qfinal[i][:33] - ref[i][2]).max())
 
 
-def test_glue_against_reference_goldens(box_blob, setup):
-    """obs / reward / termination diffs of the HIP path against vectors produced by the REFERENCE's Python
-    (tests/golden/env_glue.npz): load the golden state through set_state, make the expert the golden expert, and
-    compare the reset observation (body poses are then the FK of the golden qpos on both sides)."""
-    cfg, ex, thresh = setup
-    z = cases(golden("env_glue.npz"))
-    c = z[3]                                            # cur_t = 0, start 0: a reset observation
-    exg = {k[3:]: v for k, v in c.items() if k.startswith("ex_")}
-    # replace the golden's random body poses by the FK of its hand DoFs so the expert is self-consistent
-    model = mjcf.CompiledModel.from_blob(box_blob)
-    q = np.zeros((exg["hand_dof_seq"].shape[0], 33)); q[:, :26] = exg["hand_dof_seq"]; q[:, 26:] = exg["obj_pose_seq"]
-    sim = _sim(box_blob, 1, cfg, [exg], thresh)
-    obs = sim.reset([0], [0]).cpu().numpy()[0]
-    from oracle import hoo
-    o = _oracle(hoo, box_blob, cfg, thresh, exg)
-    np.testing.assert_allclose(obs, o.reset(0), atol=3e-6)
-    assert obs.shape == (617,)
+def test_reset_obs_against_reference_goldens():
+    """The HIP reset observation against vectors produced by the REFERENCE's own get_full_obs_v5
+    (tests/golden/reset_obs.npz, generated by gen_golden_reset_obs.py from ho_im4.py:280-356 on the state reset_model
+    leaves behind): compared DIRECTLY, no oracle in between.  Box, Bottle and Banana; one case clamps the future
+    window at the sequence end."""
+    z = cases(golden("reset_obs.npz"))
+    for c in z:
+        obj = str(c["obj"])
+        blob, cfg, _, thresh = _obj_setup(obj)
+        model = mjcf.CompiledModel.from_blob(blob)
+        ex = motions.synthetic_expert(model, int(c["n_seq"]), int(c["T"]))
+        sim = _sim(blob, 2, cfg, ex, thresh)
+        obs = sim.reset([int(c["seq"])] * 2, [int(c["start"])] * 2).cpu().numpy()
+        assert obs.shape == (2, 617)
+        np.testing.assert_allclose(obs[0], c["obs"], atol=3e-6, err_msg=f"{obj} seq {c['seq']} start {c['start']}")
+        q, v, t = sim.get_state()
+        np.testing.assert_allclose(q[1].cpu().numpy(), c["qpos"], atol=1e-6); np.testing.assert_allclose(v[1].cpu().numpy(), c["qvel"], atol=2e-6)
+        assert int(t[0]) == 0
+        sim.close()
 
 
 def test_rfc_and_contact_bookkeeping(box_blob, oracle_lib, setup):
@@ -728,3 +730,130 @@ def test_gae_device_path_is_bit_identical():
         assert torch.equal(a_dev, adv) and torch.equal(ret_dev, v + adv)
     a1, r1 = rl.estimate_advantages(r, m, v, 0.95, 0.95, nv)
     assert torch.isfinite(a1).all() and abs(float(a1.mean())) < 1e-4
+
+
+def test_diagnostics_guard_the_compiled_caps(box_blob, setup):
+    """hoic_get_diagnostics: the 32-contact cap and the Newton iteration cap are observable.  A contact-rich rollout
+    (starts in the grasp phase, object in the hand on the table side) must not overflow the contact list; with a
+    1-iteration solver cap the cap counter must fire, and reset clears both."""
+    cfg, ex, thresh = setup
+    N = 1024
+    sim = _sim(box_blob, N, cfg, ex, thresh)
+    rng = np.random.default_rng(5)
+    seqs = rng.integers(0, 4, N); starts = rng.integers(90, 300, N)       # around and after the pick-up at frame 100
+    sim.reset(seqs, starts)
+    assert sim.diagnostics() == {"contact_overflow": 0, "solver_cap_hits": 0, "envs_with_overflow": 0}
+    it_hist = np.zeros(64, dtype=np.int64)
+    for t in range(12):
+        a = torch.as_tensor(rng.normal(size=(N, 32)) * 0.1, dtype=torch.float32)
+        out = sim.step(a, torch.as_tensor(seqs, dtype=torch.int32), torch.as_tensor(starts, dtype=torch.int32))
+        it_hist += np.bincount(out[3][:, 3].cpu().numpy().clip(0, 63), minlength=64)
+    d = sim.diagnostics()
+    assert d["contact_overflow"] == 0 and d["envs_with_overflow"] == 0, d
+    # the default cap is 8 iterations: report how often the last substep of a step used them all
+    frac_cap = it_hist[8:].sum() / it_hist.sum()
+    print("solver_cap_hits over 12 steps x 15 substeps x 1024 envs:", d["solver_cap_hits"], "| last-substep iteration histogram",
+          it_hist[:10].tolist(), "| fraction at the cap", frac_cap)
+    assert d["solver_cap_hits"] <= 0.02 * 12 * 15 * N
+    sim.close()
+    sim = _sim(box_blob, 64, cfg, ex, thresh, solver_iterations=1)
+    sim.reset(seqs[:64], starts[:64])
+    sim.step(torch.as_tensor(rng.normal(size=(64, 32)) * 0.1, dtype=torch.float32))
+    d1 = sim.diagnostics(reset=True)
+    assert d1["solver_cap_hits"] > 0
+    assert sim.diagnostics() == {"contact_overflow": 0, "solver_cap_hits": 0, "envs_with_overflow": 0}
+    sim.close()
+
+
+def test_single_env_adapter_has_the_reference_signature(box_blob, oracle_lib, setup):
+    """hoic_amd.env.HandObjMimic4 — NumPy in / out, step(a[32]) -> (obs[617], 1.0, done, {fail, end, percent}) as
+    uhc/envs/ho_im4.py:611-662 — stepped against the oracle on the same action tape."""
+    from hoic_amd.env import HandObjMimic4
+    cfg, ex, thresh = setup
+    e = dict(ex[1]); start = 150
+    sliced = {k: np.asarray(v)[start:] for k, v in e.items() if k.endswith("_seq")}      # load_seq(start_idx, full_seq=True)
+    env = HandObjMimic4(cfg, sliced, "box", None, "train")
+    o = _oracle(oracle_lib, box_blob, cfg, thresh, sliced)
+    obs = env.reset(); ref = o.reset(0)
+    assert obs.shape == (617,) and obs.dtype == np.float64 and env.observation_space.shape == (617,) and env.action_space.shape == (32,)
+    np.testing.assert_allclose(obs, ref, atol=3e-6)
+    tape = motions.action_tape(6, 1, seed=11)[:, 0]
+    wk = cfg.reward_wk()
+    for t in range(6):
+        obs, r, done, info = env.step(tape[t])
+        ref, rinfo = o.step(tape[t]); rr, rterms = o.reward(wk)
+        assert r == 1.0 and isinstance(done, bool) and set(info) == {"fail", "end", "percent"}
+        assert done == rinfo["done"] and info["fail"] == rinfo["fail"] and info["end"] == rinfo["end"]
+        assert abs(info["percent"] - rinfo["percent"]) < 1e-6
+        np.testing.assert_allclose(obs, ref, atol=3e-4)
+        assert abs(env.c_reward - rr) < 2e-4 and abs(env.rfc_score - rinfo["rfc_score"]) < 5e-3 * (1 + rinfo["rfc_score"])
+        np.testing.assert_allclose(env.get_hand_qpos(), o.get("qpos")[:26], atol=2e-5)
+        np.testing.assert_allclose(env.get_obj_qpos(), o.get("qpos")[26:33], atol=2e-5)
+        assert env.cur_t == t + 1
+    assert env.get_expert_attr("hand_dof_seq", 3).shape == (26,)
+    env._b.close()
+
+
+def test_reference_checkpoint_drives_the_hip_simulator(box_blob, oracle_lib, setup):
+    """f.3: a checkpoint pickled by the reference's own PolicyGaussian / Value / ZFilter classes
+    (tests/golden/ref_checkpoint_small.p) is loaded through AgentHandMimic.load_checkpoint and evaluated on the
+    device; the same deterministic episode through the oracle with the same weights gives the same result."""
+    import os
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config, release_cfg_dict
+    from hoic_amd.rl import BatchZFilter
+    cfg0, ex, thresh = setup
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(g, "ref_checkpoint_small.npz"))
+    d = release_cfg_dict("box"); d["policy_hsize"] = z["policy_hsize"].tolist(); d["value_hsize"] = z["value_hsize"].tolist()
+    cfg = Config("box_future5_light_add_geom", cfg_dict=d)
+    agent = AgentHandMimic(cfg, n_envs=8, expert_seqs=ex)
+    agent.load_checkpoint(0, path=os.path.join(g, "ref_checkpoint_small.p"))
+    x = torch.tensor(z["x_raw"], dtype=torch.float32, device=agent.device)
+    with torch.no_grad():
+        xn = agent.running_state(x, update=False)
+        np.testing.assert_allclose(xn.cpu().numpy(), z["x_norm"], atol=2e-5)
+        np.testing.assert_allclose(agent.policy_net.select_action(xn, mean_action=True).cpu().numpy(), z["action_mean"], atol=2e-5)
+        np.testing.assert_allclose(agent.value_net(xn).cpu().numpy(), z["value"], atol=2e-5)
+    m = agent.eval_policy()
+    assert 0 < m["percent"] <= 1 and np.isfinite([m["avg_reward"], m["pose_err"], m["mpjpe"]]).all()
+    # the same episode on the oracle (float64 copies of the same weights and filter)
+    cfg.update_adaptive_params(0)
+    pol = agent.policy_net.__class__(cfg, 32, 617).double(); pol.load_state_dict({k: v.double().cpu() for k, v in agent.policy_net.state_dict().items()})
+    filt = BatchZFilter.from_reference(agent.running_state.to_reference())
+    si = len(ex) - 1
+    o = _oracle(oracle_lib, box_blob, cfg, thresh, ex[si]); o.set_cfg(cfg.jkp, cfg.jkd, cfg.torque_lim, thresh, mode_train=0)
+    obs = o.reset(0); tot, n, pct = 0.0, 0, 0.0
+    with torch.no_grad():
+        for _ in range(ex[si]["hand_dof_seq"].shape[0]):
+            a = pol.select_action(filt(torch.tensor(obs[None]), update=False), mean_action=True)[0].numpy()
+            obs, info = o.step(a); r, _ = o.reward(cfg.reward_wk()); tot += r; n += 1; pct = info["percent"]
+            if info["done"]:
+                break
+    assert abs(m["percent"] - pct) < 1e-6 and abs(m["avg_reward"] - tot / n) < 2e-3 * (tot / n)
+    agent.env.close()
+
+
+def test_train_script_runs_two_iterations(tmp_path):
+    """scripts/train_hand_mimic.py with the reference's command line, 2 iterations at a small size, then a resume from
+    the checkpoint it wrote (--epoch)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("train_hand_mimic", os.path.join(ROOT, "scripts", "train_hand_mimic.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    base = str(tmp_path)
+    argv = ["--cfg", "box_future5_light_add_geom", "--num_threads", "32", "--no_log", "--n_envs", "256", "--num_epoch", "2", "--base_dir", base]
+    agent = mod.main(argv)
+    assert agent.epoch == 1 and agent.n_envs == 256
+    agent.save_checkpoint(1)
+    p0 = [p.detach().clone() for p in agent.policy_net.parameters()]
+    agent.env.close()
+    agent2 = mod.main(argv[:-4] + ["--num_epoch", "2", "--base_dir", base, "--epoch", "2"])      # nothing left to do: loads iter_0002.p
+    for a, b in zip(p0, agent2.policy_net.parameters()):
+        assert torch.equal(a, b)
+    agent2.env.close()
+    agent3 = mod.main(["--cfg", "box_future5_light_add_geom", "--num_threads", "16", "--sample_mode", "episodes", "--num_epoch", "1",
+                       "--base_dir", base])
+    assert agent3.n_envs == 16 and agent3.sample_mode == "episodes"
+    agent3.env.close()

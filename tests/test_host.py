@@ -288,3 +288,38 @@ def test_logger_rl_fields_follow_the_reference():
     assert lg.avg_c_reward == 0.7 and lg.avg_episode_c_reward == 105.0
     np.testing.assert_allclose(lg.avg_c_info, np.arange(9.0)); np.testing.assert_allclose(lg.avg_episode_c_info, np.arange(9.0) * 150)
     assert LoggerRL(num_steps=64, num_episodes=0, total_c_reward=32.0).avg_episode_len == 64       # no episode end in the window
+
+
+def test_load_expert_reads_the_reference_pickle_schema(box_model, tmp_path):
+    """DatasetSingleDepth's on-disk schema (dataset_singledepth.py:30-34, 79-84): {seq_name: [{hand_pose_seq, obj_pose_seq}]}."""
+    import pickle
+    raw = motions.synthetic_sequences(box_model, 3, 230)
+    fn = tmp_path / "box.pkl"
+    with open(fn, "wb") as f:
+        pickle.dump({"box_seq": raw, "other": []}, f)
+    d = release_cfg_dict("box"); d["data_specs"] = dict(d["data_specs"], expert_fn=str(fn))
+    ex = motions.load_expert(Config("box_future5_light_add_geom", cfg_dict=d), box_model)
+    ref = motions.synthetic_expert(box_model, 3, 230)
+    assert len(ex) == 3
+    for a, b in zip(ex, ref):
+        for k in ("hand_dof_seq", "hand_dof_vel_seq", "obj_pose_seq", "obj_vel_seq", "obj_angle_vel_seq", "body_pos_seq", "body_quat_seq"):
+            np.testing.assert_allclose(a[k], b[k], atol=1e-14, err_msg=k)
+    # no file -> the synthetic stand-in (17 x 600)
+    ex2 = motions.load_expert(Config("box_future5_light_add_geom"), box_model)
+    assert len(ex2) == 17 and ex2[0]["hand_dof_seq"].shape == (600, 26)
+
+
+def test_train_script_takes_the_reference_flags():
+    """scripts/train_hand_mimic.py accepts every flag of the reference's script (scripts/train_hand_mimic.py:19-34) with
+    the same defaults."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_hand_mimic", os.path.join(ROOT, "scripts", "train_hand_mimic.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    a = mod.build_parser().parse_args(["--cfg", "box_future5_light_add_geom", "--num_threads", "32", "--no_log"])
+    assert (a.cfg, a.num_threads, a.no_log, a.gpu_index, a.epoch, a.render, a.test, a.show_noise, a.resume, a.debug, a.full_eval) == \
+           ("box_future5_light_add_geom", 32, True, 0, 0, False, False, False, None, False, False)
+    assert mod.build_parser().parse_args([]).num_threads == 16
+    if os.path.exists("/root/reference/scripts/train_hand_mimic.py"):
+        ref_flags = set(re.findall(r'add_argument\("(--\w+)"', open("/root/reference/scripts/train_hand_mimic.py").read()))
+        ours = set(re.findall(r'add_argument\("(--\w+)"', open(os.path.join(ROOT, "scripts", "train_hand_mimic.py")).read()))
+        assert ref_flags <= ours, ref_flags - ours

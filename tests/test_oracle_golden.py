@@ -92,3 +92,28 @@ def test_axis_angle(oracle_lib):
     from hoic_amd.motions import matrix_to_axis_angle
     z = golden("axis_angle.npz")
     np.testing.assert_allclose(matrix_to_axis_angle(z["R"]), z["aa"], atol=1e-12)
+
+
+def test_oracle_reset_matches_reference_reset_obs(oracle_lib):
+    """reset_model + get_full_obs_v5 + calc_ho_diff + ho_mimic_reward_9 of the reference on the state a reset leaves
+    behind (tests/golden/reset_obs.npz, FK-consistent body poses) against the oracle's reset, for all three objects."""
+    from hoic_amd import mjcf, motions
+    from hoic_amd.config import Config
+    z = cases(golden("reset_obs.npz"))
+    assert len(z) == 12
+    for c in z:
+        obj = str(c["obj"])
+        blob = open(mjcf.packaged_model_path(obj), "rb").read()
+        model = mjcf.CompiledModel.from_blob(blob)
+        cfg = Config(f"{obj}_future5_light_add_geom"); cfg.update_adaptive_params(0)
+        ex = motions.synthetic_expert(model, int(c["n_seq"]), int(c["T"]))
+        o = oracle_lib.OracleEnv(blob)
+        o.set_cfg(cfg.jkp, cfg.jkd, cfg.torque_lim)
+        o.set_expert(ex[int(c["seq"])])
+        obs = o.reset(int(c["start"]))
+        np.testing.assert_allclose(obs, c["obs"], atol=1e-12, err_msg=obj)
+        np.testing.assert_allclose(o.calc_ho_diff(), c["diffs"], atol=1e-12)
+        o.set("rfc_score", [0.0])
+        r, info = o.reward(cfg.reward_wk())
+        np.testing.assert_allclose(r, float(c["reward"]), atol=1e-12)
+        np.testing.assert_allclose(info[:len(c["reward_info"])], c["reward_info"], atol=1e-12)
