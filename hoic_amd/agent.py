@@ -500,7 +500,7 @@ class AgentHandMimic:
         # pose_err slices FRAMES 6.. of the stacked arrays, as the reference does (:384); mpjpe from the kinematics of
         # the recorded states (one probe launch; the reference reads the one-substep-lagged body_xpos)
         hb0 = env.sim.model.scalar("hand_body0")
-        kin = env.sim.probe_forward(torch.stack(qs)[:n], torch.zeros(n, lib_NV), kinematics_only=True)
+        kin = env.sim.probe_forward(torch.stack(qs)[:n].cpu().numpy(), np.zeros((n, lib_NV), np.float32), kinematics_only=True)
         mpjpe = np.linalg.norm(np.asarray(ex["body_pos_seq"])[:n] - kin["xpos"][:, hb0:hb0 + 21], axis=-1).mean()
         m = {"pose_err": float(np.linalg.norm(gt[6:] - pred[6:], axis=-1).mean()) if n > 6 else 0.0, "mpjpe": float(mpjpe),
              "avg_reward": float(rew.mean()), "total_reward": float(rew.sum()), "percent": float(torch.stack(pcts)[n - 1])}
