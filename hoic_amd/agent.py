@@ -104,6 +104,8 @@ class PPOLearner:
         self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
         self.opt_num_epochs = cfg.num_optim_epoch
         self.last_losses = None
+        assert update_dtype in ("f32", "bf16", "f16x3")
+        self._engines = None             # f16x3: SplitMLP of (value net, policy net)
 
     # ------------------------------------------------------------------ update (agent_pg.py:39-55, agent_ppo.py:16-64)
     def _allreduce_start(self, params):
@@ -130,6 +132,13 @@ class PPOLearner:
         import contextlib
         return contextlib.nullcontext()
 
+    def _split_engines(self):
+        """update_dtype='f16x3': the two MLPs run on the error-compensated f16 matrix-core GEMMs (hoic_amd/mlp.py)"""
+        if self._engines is None:
+            from .mlp import SplitMLP
+            self._engines = (SplitMLP(self.value_net.net), SplitMLP(self.policy_net.net))
+        return self._engines
+
     def update_params(self, batch):
         t0 = time.time()
         self.policy_net.train(); self.value_net.train()
@@ -140,8 +149,14 @@ class PPOLearner:
         if valid is not None:           # whole-episode batches: padded [T, N] storage, only the valid rows are samples
             vflat = valid.reshape(T * N)
             states, actions = states[vflat], actions[vflat]
-        with torch.no_grad(), self._autocast():
-            values = self.value_net(states).float()
+        if self.update_dtype == "f16x3" and states.is_cuda and states.dtype == torch.float32:
+            from .mlp import PackedInput
+            states = PackedInput(states)            # split once per iteration, shared by both networks and all epochs
+            with torch.no_grad():
+                values = self.value_net.value_head(self._split_engines()[0].forward(states, need_grad=False))
+        else:
+            with torch.no_grad(), self._autocast():
+                values = self.value_net(states).float()
         if valid is not None:
             values = torch.zeros(T * N, 1, device=values.device, dtype=values.dtype).masked_scatter_(vflat[:, None], values)
         advantages, returns = estimate_advantages(batch.rewards, batch.masks, values.reshape(T, N), self.gamma, self.tau,
@@ -159,6 +174,34 @@ class PPOLearner:
         self.optimize(states, actions, advantages, returns, weight)
         return time.time() - t0
 
+    def _optimize_f16x3(self, inp, actions, advantages, returns, weight, policy_step, vparams, pparams):
+        """optimize() with both MLP bodies on the f16x3 GEMMs: the bodies' forward returns the last hidden activation as
+        a leaf, PyTorch runs head + loss + their backward, the bodies' backward fills the MLP gradients."""
+        veng, peng = self._split_engines()
+        with torch.no_grad():
+            fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=peng.forward(inp, need_grad=False))
+        p_pending, p_waiting = None, False
+        for _ in range(self.opt_num_epochs):
+            h = veng.forward(inp)
+            value_loss = (self.value_net.value_head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
+            self.optimizer_value.zero_grad(set_to_none=True)
+            (value_loss * weight if weight != 1.0 else value_loss).backward()
+            veng.backward(h.grad)
+            v_pending = self._allreduce_start(vparams)
+            if p_waiting:
+                policy_step(p_pending); p_waiting = False
+            h = peng.forward(inp)
+            surr = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
+            self.optimizer_policy.zero_grad(set_to_none=True)
+            (surr * weight if weight != 1.0 else surr).backward()
+            peng.backward(h.grad)
+            p_pending, p_waiting = self._allreduce_start(pparams), True
+            self._allreduce_finish(v_pending)
+            self.optimizer_value.step()
+        policy_step(p_pending)
+        self.last_losses = (float(value_loss.detach()), float(surr.detach()))
+        veng.check_overflow()
+
     def optimize(self, states, actions, advantages, returns, weight=1.0):
         """The 5 full-batch epochs of value and policy steps (agent_ppo.py:16-56) on flat [M, .] tensors.  ``weight``
         scales both losses (ranks with unequal sample counts, see update_params)."""
@@ -166,6 +209,10 @@ class PPOLearner:
             fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
         vparams = list(self.value_net.parameters())
         pparams = [p for p in self.policy_net.parameters() if p.requires_grad]
+        f16x3 = self.update_dtype == "f16x3" and actions.is_cuda and actions.dtype == torch.float32
+        if f16x3 and torch.is_tensor(states):
+            from .mlp import PackedInput
+            states = PackedInput(states)
 
         def policy_step(pending):
             self._allreduce_finish(pending)
@@ -176,6 +223,8 @@ class PPOLearner:
                 self._policy_clip_used = True
             self.optimizer_policy.step()
 
+        if f16x3:
+            return self._optimize_f16x3(states, actions, advantages, returns, weight, policy_step, vparams, pparams)
         # Per network the order is forward, backward, all-reduce, step, as in the reference loop.  Across networks the
         # two chains are independent, so with several ranks each gradient all-reduce runs while the OTHER network does
         # its forward and backward: value all-reduce of epoch k under the policy pass of epoch k, policy all-reduce of

@@ -20,6 +20,7 @@ __device__ int g_trace_qp[4 << 16];     // QP iterations / line-search steps / c
 
 static thread_local std::string g_err;
 static void set_err(const std::string& s) { g_err = s; }
+void hoic_set_error(const std::string& s) { g_err = s; }     // for the other translation units of the library (hoic_mlp.hip)
 extern "C" const char* hoic_last_error(void) { return g_err.c_str(); }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return HOIC_ERR_DEVICE; } } while (0)

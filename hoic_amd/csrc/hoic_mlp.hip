@@ -1,0 +1,439 @@
+// hoic_mlp.hip — the dense policy / value GEMMs of the PPO update on the matrix cores at float32 accuracy.
+//
+// The update (AgentPPO.update_policy / AgentPG.update_value, uhc/khrylib/rl/agents/agent_ppo.py:16-56, agent_pg.py:18-25)
+// is 5 full-batch epochs of forward + backward through two 617-2048-1024-512 GELU MLPs on >= 50 000 samples: 12 TFLOP
+// of float32 GEMM per iteration, 73 % of the loop at the f32 MFMA rate (157 TFLOP/s).  gfx950's f16 MFMA runs 16x
+// faster.  Here every float32 operand x is carried as an error-free pair of halves
+//     x * 2^e = hi + lo,   hi = f16(x 2^e),  lo = f16(x 2^e - hi)          (22 significand bits; e per tensor)
+// and a product sum is three f16 MFMAs into ONE float32 accumulator:  hi.hi + hi.lo + lo.hi   (lo.lo < 2^-22 dropped).
+// f16 x f16 products are exact in float32, so the result carries float32-class rounding (2^-22 per operand instead of
+// 2^-24) at 16/3 of the f32 MFMA rate.  Power-of-two scales 2^e keep every tensor inside the f16 range and are undone
+// exactly in the epilogue.
+//
+// Storage format "H4L4": a packed tensor [R x C] is R rows of 2C halves; columns come in groups of four,
+// [h0 h1 h2 h3 l0 l1 l2 l3] (16 bytes).  A lane's MFMA fragment (8 consecutive k) is then two 16-byte reads whose
+// first / second halves are the hi / lo fragments, and an epilogue lane that owns 4 consecutive columns writes one
+// 16-byte group.
+//
+// One GEMM kernel, "NT" form:  C[m][n] = alpha * sum_k A[m][k] B[n][k]  with A [M x K], B [N x K] packed, K contiguous.
+//   forward      A = activations [M x K_in],  B = W [N_out x K_in]            epilogue: + bias, GELU, GELU', pack
+//   backward dX  A = dZ [M x N_out],          B = W^T [K_in x N_out]          epilogue: * GELU'(z), pack (+ transposed)
+//   backward dW  A = dZ^T [N_out x M],        B = H^T [K_in x M], split over M epilogue: float32 slabs
+// Transposed copies of activations / gradients are written by the producing epilogue.
+// Tile 256 x BN (BN = 256 | 128), 8 wavefronts, K step 32, two LDS stages filled by global_load_lds (16 B per lane,
+// LDS image lane-linear, XOR swizzle applied to the SOURCE address and to the ds_read), v_mfma_f32_32x32x16_f16.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/hoic.h"
+
+extern "C" const char* hoic_last_error(void);
+void hoic_set_error(const std::string& s);    // hoic_capi.hip
+#define MCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { hoic_set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return HOIC_ERR_DEVICE; } } while (0)
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((__attribute__((address_space(1))) const void*)(p))
+
+// ---------------------------------------------------------------------------------------------- split helpers
+__device__ __forceinline__ void split_f16(float y, _Float16& h, _Float16& l) {
+  h = (_Float16)y;
+  l = (_Float16)(y - (float)h);
+}
+__device__ __forceinline__ unsigned pack_hl(float y) {      // hi in the low half-word, lo in the high one
+  _Float16 h, l;
+  split_f16(y, h, l);
+  return (unsigned)__builtin_bit_cast(u16, h) | ((unsigned)__builtin_bit_cast(u16, l) << 16);
+}
+// GELU (exact erf form, torch.nn.GELU default) and its derivative from ONE exponential:
+//   Phi(z) = 1/2 (1 + erf(z / sqrt 2)),  phi(z) = exp(-z^2 / 2) / sqrt(2 pi),  gelu = z Phi,  gelu' = Phi + z phi
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute) on t = 1 / (1 + p |x|), sharing exp(-x^2) with phi.
+__device__ __forceinline__ void gelu_pair(float z, float& g, float& dg) {
+  const float x = z * 0.70710678118654752f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-x * x);                                     // = exp(-z^2 / 2)
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = fmaf(-poly, e, 1.f);
+  const float Phi = 0.5f * (1.f + copysignf(erf_abs, x));
+  g = z * Phi;
+  dg = fmaf(z * 0.39894228040143268f, e, Phi);
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- the GEMM kernel
+enum { EPI_F32 = 0, EPI_FWD = 1, EPI_BWD = 2 };
+struct GemmArgs {
+  const u16* A; const u16* B;     // packed H4L4: A [M x 2K] halves, B [N x 2K] halves
+  int M, N, K;                    // K = contraction length in elements (multiple of 32)
+  int kt_per_split;               // K stages (of 32) handled by one block (split-K over blockIdx.y)
+  const int* exps;                // device: scale exponents of the tensor slots
+  float* amax;                    // device: running max |value| per tensor slot (float bits, atomicMax on uint)
+  int ea, eb, eo;                 // slots of A, B and of the packed output
+  float extra_scale;              // multiplies alpha (e.g. 1 / loss scale is folded into the exponents instead; 1.0)
+  // EPI_F32
+  float* C; long long c_split_stride;     // [M x N] float32 (+ slab stride per split)
+  // EPI_FWD / EPI_BWD
+  const float* bias;              // [N] (FWD)
+  const float* Gin;               // [M x N] float32: GELU'(z) of the layer whose pre-activation gradient is formed (BWD)
+  float* Gout;                    // [M x N] float32 GELU'(z) (FWD)
+  float* Hf32;                    // optional [M x N] float32 copy of the output
+  u16* P;                         // optional packed output [M x 2N]
+  u16* PT;                        // optional packed transposed output [N x 2M]
+};
+
+template <int BN> struct Cfg {
+  static constexpr int WM = (BN == 256) ? 2 : 4;       // wavefronts along m / n
+  static constexpr int WN = 8 / WM;
+  static constexpr int TM = 256 / WM / 32;               // 32 x 32 MFMA tiles per wavefront along m / n
+  static constexpr int TN = BN / WN / 32;
+  static constexpr int STAGE = (256 + BN) * 128;         // bytes per LDS stage
+};
+
+// stage one K step (32 elements = 128 bytes per row) of `rows` rows into LDS: chunk q (16 B) of the image belongs to
+// row q >> 3, and holds source chunk (q & 7) ^ ((row >> 1) & 7) of that row's 128-byte segment
+template <int ROWS> __device__ __forceinline__ void stage_rows(const char* g, size_t rowbytes, char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; i++) {
+    const int q = (i * 8 + wave) * 64 + lane, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)row * rowbytes + c * 16), LDS_PTR(lds + (i * 8 + wave) * 1024), 16, 0, 0);
+  }
+}
+// the two 16-byte groups holding k = 16 s + 8 hf ... + 7 of `row`
+__device__ __forceinline__ void read_frag(const char* tile, int row, int s, int hf, h8& hi, h8& lo) {
+  const int sw = (row >> 1) & 7, b0 = 4 * s + 2 * hf;
+  const u32x4 c0 = *(const u32x4*)(tile + row * 128 + ((b0 ^ sw) << 4));
+  const u32x4 c1 = *(const u32x4*)(tile + row * 128 + (((b0 + 1) ^ sw) << 4));
+  const u32x4 h = {c0.x, c0.y, c1.x, c1.y}, l = {c0.z, c0.w, c1.z, c1.w};
+  hi = __builtin_bit_cast(h8, h); lo = __builtin_bit_cast(h8, l);
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_kernel(GemmArgs a) {
+  typedef Cfg<BN> C;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * C::STAGE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of tiles so that the tiles
+  // sharing an A row panel are resident on one L2 at the same time
+  const int ntn = a.N / BN, ntiles = (a.M / 256) * ntn;
+  int g = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = g & 7, idx = g >> 3;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = g / ntn, nt_ = g % ntn;
+  const int m0 = mt * 256, n0 = nt_ * BN;
+  const int split = blockIdx.y;
+  const int kt0 = split * a.kt_per_split;
+  const int nkt = min(a.kt_per_split, a.K / 32 - kt0);
+  const size_t rowbytes = (size_t)a.K * 4;
+  const char* Ag = (const char*)a.A + (size_t)m0 * rowbytes + (size_t)kt0 * 128;
+  const char* Bg = (const char*)a.B + (size_t)n0 * rowbytes + (size_t)kt0 * 128;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int mw = wm * (C::TM * 32), nw = wn * (C::TN * 32);      // wavefront tile origin inside the block tile
+
+  f32x16 acc[C::TM][C::TN];
+#pragma unroll
+  for (int i = 0; i < C::TM; i++)
+#pragma unroll
+    for (int j = 0; j < C::TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    stage_rows<256>(Ag, rowbytes, smem, wave, lane);
+    stage_rows<BN>(Bg, rowbytes, smem + 256 * 128, wave, lane);
+  }
+  for (int t = 0; t < nkt; t++) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wavefront's share of stage t has landed
+    __syncthreads();                         // ... everyone's has, and nobody still reads the other buffer
+    char* cur = smem + (t & 1) * C::STAGE;
+    if (t + 1 < nkt) {
+      char* nxt = smem + ((t + 1) & 1) * C::STAGE;
+      stage_rows<256>(Ag + (size_t)(t + 1) * 128, rowbytes, nxt, wave, lane);
+      stage_rows<BN>(Bg + (size_t)(t + 1) * 128, rowbytes, nxt + 256 * 128, wave, lane);
+    }
+    const char* At = cur;
+    const char* Bt = cur + 256 * 128;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      h8 ah[C::TM], al[C::TM], bh[C::TN], bl[C::TN];
+#pragma unroll
+      for (int j = 0; j < C::TN; j++) read_frag(Bt, nw + j * 32 + l31, s, hf, bh[j], bl[j]);
+#pragma unroll
+      for (int i = 0; i < C::TM; i++) read_frag(At, mw + i * 32 + l31, s, hf, ah[i], al[i]);
+      // D[n][m]: the weight-side fragment is the MFMA's A operand, so a lane ends up with 4 consecutive n of one m
+#pragma unroll
+      for (int i = 0; i < C::TM; i++)
+#pragma unroll
+        for (int j = 0; j < C::TN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------ epilogue
+  // acc[i][j][reg]: m = m0 + mw + 32 i + (lane & 31), n = n0 + nw + 32 j + 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3)
+  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
+  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
+  if (EPI == EPI_F32) {
+    float* Cp = a.C + (size_t)split * a.c_split_stride;
+#pragma unroll
+    for (int i = 0; i < C::TM; i++)
+#pragma unroll
+      for (int j = 0; j < C::TN; j++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int m = m0 + mw + 32 * i + l31, n = n0 + nw + 32 * j + 8 * rg + 4 * hf;
+          f32x4 v = {alpha * acc[i][j][4 * rg], alpha * acc[i][j][4 * rg + 1], alpha * acc[i][j][4 * rg + 2], alpha * acc[i][j][4 * rg + 3]};
+          *(f32x4*)(Cp + (size_t)m * a.N + n) = v;
+        }
+    return;
+  }
+  const int eo = a.exps ? a.exps[a.eo] : 0;
+  const float so = ldexpf(1.f, eo);
+  float vmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < C::TM; i++)
+#pragma unroll
+    for (int j = 0; j < C::TN; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int m = m0 + mw + 32 * i + l31, n = n0 + nw + 32 * j + 8 * rg + 4 * hf;
+        float v[4];
+        if (EPI == EPI_FWD) {
+          const f32x4 b4 = *(const f32x4*)(a.bias + n);
+          f32x4 dg4;
+#pragma unroll
+          for (int r = 0; r < 4; r++) { float gq, dq; gelu_pair(fmaf(alpha, acc[i][j][4 * rg + r], b4[r]), gq, dq); v[r] = gq; dg4[r] = dq; }
+          if (a.Gout) *(f32x4*)(a.Gout + (size_t)m * a.N + n) = dg4;
+        } else {
+          const f32x4 g4 = *(const f32x4*)(a.Gin + (size_t)m * a.N + n);
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][4 * rg + r] * g4[r];
+        }
+        if (a.Hf32) { const f32x4 o = {v[0], v[1], v[2], v[3]}; *(f32x4*)(a.Hf32 + (size_t)m * a.N + n) = o; }
+        unsigned w[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { vmax = fmaxf(vmax, fabsf(v[r])); w[r] = pack_hl(v[r] * so); }
+        if (a.P) {      // one 16-byte group [h0 h1 h2 h3 l0 l1 l2 l3]
+          const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+          *(u32x4*)(a.P + ((size_t)m * a.N + n) * 2) = o;
+        }
+        if (a.PT) {     // transposed: the group of (n, 4 consecutive m) is spread over a quad of lanes; lane q writes dword q
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int wa = __builtin_amdgcn_update_dpp(0, (int)w[r], 0x88, 0xf, 0xf, false);   // quad_perm [0,2,0,2]
+            const int wb = __builtin_amdgcn_update_dpp(0, (int)w[r], 0xdd, 0xf, 0xf, false);   // quad_perm [1,3,1,3]
+            const unsigned o = __builtin_amdgcn_perm((unsigned)wb, (unsigned)wa, (lane & 2) ? 0x07060302u : 0x05040100u);
+            *(unsigned*)(a.PT + ((size_t)(n + r) * a.M + (m & ~3)) * 2 + (lane & 3) * 2) = o;
+          }
+        }
+      }
+  if (a.amax) {
+    vmax = wave_max_f(vmax);
+    if (lane == 0) atomicMax((unsigned*)(a.amax + a.eo), __float_as_uint(vmax));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- pack kernels
+// float32 [R x C] (row stride ld) -> packed [Rp x 2 Cp] (zero padded), scaled by 2^exps[slot]; one thread per 4 columns
+__global__ void hoic_pack_rows_kernel(const float* __restrict__ x, int R, int Cc, long long ld, u16* __restrict__ P, int Rp, int Cp,
+                                      const int* __restrict__ exps, int slot) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = Cp >> 2;
+  if (gid >= (long long)Rp * groups) return;
+  const int r = (int)(gid / groups), c = (int)(gid % groups) * 4;
+  const float s = ldexpf(1.f, exps ? exps[slot] : 0);
+  unsigned w[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = pack_hl((r < R && c + k < Cc) ? x[(long long)r * ld + c + k] * s : 0.f);
+  const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+  *(u32x4*)(P + ((long long)r * Cp + c) * 2) = o;
+}
+// float32 [R x C] -> packed TRANSPOSE [Cp x 2 Rp]; optional elementwise factor y [R x C] (dZ = dH * GELU'); 64 x 64
+// tiles through LDS.  grid (Cp / 64, Rp / 64), 256 threads.
+__global__ __launch_bounds__(256) void hoic_pack_transpose_kernel(const float* __restrict__ x, const float* __restrict__ y, int R, int Cc, long long ld,
+                                                                 u16* __restrict__ PT, int Rp, int Cp, const int* __restrict__ exps, int slot) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+  const float s = ldexpf(1.f, exps ? exps[slot] : 0);
+  for (int k = tid; k < 64 * 64; k += 256) {
+    const int rr = k >> 6, cc = k & 63, r = r0 + rr, c = c0 + cc;
+    float v = 0.f;
+    if (r < R && c < Cc) { v = x[(long long)r * ld + c]; if (y) v *= y[(long long)r * ld + c]; }
+    tile[rr][cc] = v * s;
+  }
+  __syncthreads();
+  for (int k = tid; k < 64 * 16; k += 256) {       // output row c (64 of them), 16 groups of 4 r each
+    const int cc = k >> 4, gq = (k & 15) * 4;
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) w[q] = pack_hl(tile[gq + q][cc]);
+    const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+    *(u32x4*)(PT + ((long long)(c0 + cc) * Rp + r0 + gq) * 2) = o;
+  }
+}
+// dZ = dH * G (float32 [R x C], both row stride C) -> packed rows [Rp x 2C]; C multiple of 4
+__global__ void hoic_pack_rows_mul_kernel(const float* __restrict__ x, const float* __restrict__ y, int R, int Cc, u16* __restrict__ P, int Rp,
+                                          const int* __restrict__ exps, int slot) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = Cc >> 2;
+  if (gid >= (long long)Rp * groups) return;
+  const int r = (int)(gid / groups), c = (int)(gid % groups) * 4;
+  const float s = ldexpf(1.f, exps ? exps[slot] : 0);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (r < R) { const f32x4 a = *(const f32x4*)(x + (long long)r * Cc + c), b = *(const f32x4*)(y + (long long)r * Cc + c); v = a * b; }
+  unsigned w[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = pack_hl(v[k] * s);
+  const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+  *(u32x4*)(P + ((long long)r * Cc + c) * 2) = o;
+}
+// max |x * y| (y optional) over a float32 array -> amax[slot] (atomicMax on the float bits; values are non-negative)
+__global__ void hoic_amax_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float* __restrict__ amax, int slot) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = x[i]; if (y) v *= y[i];
+    m = fmaxf(m, fabsf(v));
+  }
+  m = wave_max_f(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)(amax + slot), __float_as_uint(m));
+}
+// exponent of slot i from its running maximum: 2^e * amax lands in [2^(target-1), 2^target); amax == 0 keeps e; then the
+// maximum is cleared for the next pass.  One thread per slot.  mask bit i set = slot i is updated.
+__global__ void hoic_update_exps_kernel(int* __restrict__ exps, float* __restrict__ amax, int nslots, unsigned long long mask, int target,
+                                        int* __restrict__ overflow) {
+  const int i = threadIdx.x;
+  if (i >= nslots || !((mask >> i) & 1ull)) return;
+  const float m = amax[i];
+  if (m > 0.f && isfinite(m)) {
+    int ex; frexpf(m, &ex);             // m = f * 2^ex, f in [0.5, 1)
+    if (ldexpf(m, exps[i]) > 60000.f && overflow) atomicAdd(overflow, 1);     // the pass just measured overflowed f16
+    exps[i] = target - ex;
+  } else if (!isfinite(m) && overflow) atomicAdd(overflow, 1);
+  amax[i] = 0.f;
+}
+// sum of S float32 slabs [rows x cols] -> out (row stride ldo, only the first out_cols columns), scaled
+__global__ void hoic_slab_reduce_kernel(const float* __restrict__ slabs, int S, long long stride, int rows, int cols, float* __restrict__ out,
+                                        int out_cols, long long ldo, float scale) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)rows * out_cols) return;
+  const int r = (int)(gid / out_cols), c = (int)(gid % out_cols);
+  float s = 0.f;
+  for (int k = 0; k < S; k++) s += slabs[(long long)k * stride + (long long)r * cols + c];
+  out[(long long)r * ldo + c] = s * scale;
+}
+// row sums of a packed [rows x 2 Cp] tensor (hi + lo), unscaled by 2^-exps[slot]: the bias gradient from dZ^T.
+// One 256-thread block per row, fixed summation order.
+__global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __restrict__ P, int Cp, float* __restrict__ out, const int* __restrict__ exps, int slot) {
+  __shared__ float part[256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const u32x4* row = (const u32x4*)(P + (long long)r * Cp * 2);
+  float s = 0.f;
+  for (int gq = tid; gq < (Cp >> 2); gq += 256) {
+    const u32x4 v = row[gq];
+    const h8 h = __builtin_bit_cast(h8, v);
+    s += ((float)h[0] + (float)h[4]) + ((float)h[1] + (float)h[5]) + ((float)h[2] + (float)h[6]) + ((float)h[3] + (float)h[7]);
+  }
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) part[tid] += part[tid + o]; __syncthreads(); }
+  if (tid == 0) out[r] = ldexpf(part[0], -(exps ? exps[slot] : 0));
+}
+
+// ---------------------------------------------------------------------------------------------- C-ABI
+template <int BN, int EPI> static int32_t launch_gemm(const GemmArgs& a, int splits, hipStream_t st) {
+  const int ntiles = (a.M / 256) * (a.N / BN);
+  hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI>), dim3(ntiles, splits), dim3(512), 0, st, a);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps,
+                                 float* d_amax, int32_t slot_a, int32_t slot_b, int32_t slot_out, float extra_scale, int32_t splits,
+                                 float* d_C, const float* d_bias, const float* d_gin, float* d_gout, float* d_hf32, void* d_P, void* d_PT,
+                                 void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M & 255) || (N & 127) || (K & 31) || !d_A || !d_B || splits < 1) {
+    hoic_set_error("hoic_mlp_gemm: M must be a multiple of 256, N of 128, K of 32"); return HOIC_ERR_ARG;
+  }
+  if (epi == EPI_F32 && !d_C) { hoic_set_error("hoic_mlp_gemm: float32 epilogue needs d_C"); return HOIC_ERR_ARG; }
+  if (epi == EPI_FWD && !d_bias) { hoic_set_error("hoic_mlp_gemm: forward epilogue needs the bias"); return HOIC_ERR_ARG; }
+  if (epi == EPI_BWD && !d_gin) { hoic_set_error("hoic_mlp_gemm: backward epilogue needs gin"); return HOIC_ERR_ARG; }
+  if (epi != EPI_F32 && splits != 1) { hoic_set_error("hoic_mlp_gemm: split-K only with the float32 epilogue"); return HOIC_ERR_ARG; }
+  const int nkt = K / 32;
+  GemmArgs a{};
+  a.A = (const u16*)d_A; a.B = (const u16*)d_B; a.M = M; a.N = N; a.K = K;
+  a.kt_per_split = (nkt + splits - 1) / splits;
+  a.exps = d_exps; a.amax = d_amax; a.ea = slot_a; a.eb = slot_b; a.eo = slot_out; a.extra_scale = extra_scale;
+  a.C = d_C; a.c_split_stride = (long long)M * N; a.bias = d_bias; a.Gin = d_gin; a.Gout = d_gout; a.Hf32 = d_hf32;
+  a.P = (u16*)d_P; a.PT = (u16*)d_PT;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = (N % 256) == 0;
+  if (epi == EPI_F32) return wide ? launch_gemm<256, EPI_F32>(a, splits, st) : launch_gemm<128, EPI_F32>(a, splits, st);
+  if (epi == EPI_FWD) return wide ? launch_gemm<256, EPI_FWD>(a, 1, st) : launch_gemm<128, EPI_FWD>(a, 1, st);
+  if (epi == EPI_BWD) return wide ? launch_gemm<256, EPI_BWD>(a, 1, st) : launch_gemm<128, EPI_BWD>(a, 1, st);
+  hoic_set_error("hoic_mlp_gemm: unknown epilogue"); return HOIC_ERR_ARG;
+}
+
+extern "C" int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R, int32_t C, int64_t ld, void* d_P, void* d_PT, int32_t Rp,
+                                 int32_t Cp, const int32_t* d_exps, int32_t slot, void* stream) {
+  if (!d_x || R <= 0 || C <= 0 || Rp < R || Cp < C || (Cp & 3) || (Rp & 3)) { hoic_set_error("hoic_mlp_pack: bad arguments (padded sizes must be multiples of 4)"); return HOIC_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (d_P) {
+    const long long n = (long long)Rp * (Cp >> 2);
+    if (d_mul) {
+      if (ld != C || Cp != C) { hoic_set_error("hoic_mlp_pack: the product form needs contiguous unpadded columns"); return HOIC_ERR_ARG; }
+      hipLaunchKernelGGL(hoic_pack_rows_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, d_mul, R, C, (u16*)d_P, Rp, d_exps, slot);
+    } else {
+      hipLaunchKernelGGL(hoic_pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, R, C, (long long)ld, (u16*)d_P, Rp, Cp, d_exps, slot);
+    }
+  }
+  if (d_PT) {
+    if ((Rp & 63) || (Cp & 63)) { hoic_set_error("hoic_mlp_pack: the transposed form needs padded sizes that are multiples of 64"); return HOIC_ERR_ARG; }
+    hipLaunchKernelGGL(hoic_pack_transpose_kernel, dim3(Cp / 64, Rp / 64), dim3(256), 0, st, d_x, d_mul, R, C, (long long)ld, (u16*)d_PT, Rp, Cp, d_exps, slot);
+  }
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_mlp_amax(const float* d_x, const float* d_mul, int64_t n, float* d_amax, int32_t slot, void* stream) {
+  if (!d_x || n <= 0 || !d_amax) { hoic_set_error("hoic_mlp_amax: bad arguments"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_amax_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, d_x, d_mul, (long long)n, d_amax, slot);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream) {
+  if (!d_exps || !d_amax || nslots <= 0 || nslots > 64) { hoic_set_error("hoic_mlp_update_exps: bad arguments"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_update_exps_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_exps, d_amax, nslots, (unsigned long long)mask, target, d_overflow);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
+                                        float scale, void* stream) {
+  if (!d_slabs || !d_out || S <= 0 || rows <= 0 || cols <= 0 || out_cols <= 0 || out_cols > cols) { hoic_set_error("hoic_mlp_slab_reduce: bad arguments"); return HOIC_ERR_ARG; }
+  const long long n = (long long)rows * out_cols;
+  hipLaunchKernelGGL(hoic_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_slabs, S, (long long)rows * cols, rows, cols,
+                     d_out, out_cols, (long long)ldo, scale);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+extern "C" int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot, void* stream) {
+  if (!d_P || !d_out || rows <= 0 || Cp <= 0 || (Cp & 3)) { hoic_set_error("hoic_mlp_rowsum_packed: bad arguments"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_rowsum_packed_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const u16*)d_P, Cp, d_out, d_exps, slot);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}

@@ -1,0 +1,283 @@
+"""The policy / value MLPs of the PPO update on the f16x3 matrix-core GEMMs (``hoic_amd/csrc/hoic_mlp.hip``).
+
+``SplitMLP`` runs forward and backward of one ``rl.MLP`` (617 -> 2048 -> 1024 -> 512, GELU; uhc/khrylib/models/mlp.py:5-27)
+for a fixed batch through ``hoic_mlp_gemm``: every float32 operand is carried as an error-free pair of halves
+(x 2^e = hi + lo, 22 significand bits) and every product sum is three f16 MFMAs into one float32 accumulator, so the
+result has float32-class accuracy at 16/3 of the f32 MFMA rate.  Bias + GELU + GELU' + the split of the next operand are
+fused into the forward epilogue, ``* GELU'`` + split into the backward one; weight gradients are split-K GEMMs over
+the batch with a fixed-order slab reduction (deterministic).  The small heads (512 -> 32, 512 -> 1), the losses and the
+optimisers stay in PyTorch: ``forward()`` returns the last hidden activation as a float32 leaf, ``backward(dH)``
+consumes its gradient and fills ``.grad`` of the MLP's parameters.
+
+There is no fallback in here: without the HIP library / a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib
+
+EPI_F32, EPI_FWD, EPI_BWD = 0, 1, 2
+NSLOT = 16
+TARGET_LOG2 = 10           # 2^e * amax lands in [2^9, 2^10): 64x headroom below the f16 maximum for delayed exponents
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- NumPy statement of the storage format
+def pack_h4l4_numpy(x, e=0):
+    """[R, C] float -> [R, 2C] float16 in the H4L4 layout (groups of 4 columns: 4 hi halves, then 4 lo halves);
+    C must be a multiple of 4.  Reference for the tests."""
+    y = np.asarray(x, dtype=np.float32) * np.float32(2.0 ** e)
+    hi = y.astype(np.float16)
+    lo = (y - hi.astype(np.float32)).astype(np.float16)
+    R, Cc = y.shape
+    out = np.empty((R, Cc // 4, 8), np.float16)
+    out[:, :, :4] = hi.reshape(R, Cc // 4, 4); out[:, :, 4:] = lo.reshape(R, Cc // 4, 4)
+    return out.reshape(R, 2 * Cc)
+
+
+def unpack_h4l4_numpy(p, e=0):
+    p = np.asarray(p, dtype=np.float16)
+    R = p.shape[0]
+    g = p.reshape(R, -1, 8).astype(np.float64)
+    return ((g[:, :, :4] + g[:, :, 4:]).reshape(R, -1) * 2.0 ** (-e))
+
+
+class _Kernels:
+    """ctypes signatures of the hoic_mlp_* entry points (include/hoic.h)."""
+
+    def __init__(self):
+        L = lib.load()
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        L.hoic_mlp_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.hoic_mlp_pack.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, i32, vp, i32, vp]
+        L.hoic_mlp_amax.argtypes = [vp, vp, i64, vp, i32, vp]
+        L.hoic_mlp_update_exps.argtypes = [vp, vp, i32, C.c_uint64, i32, vp, vp]
+        L.hoic_mlp_slab_reduce.argtypes = [vp, i32, i32, i32, vp, i32, i64, f32, vp]
+        L.hoic_mlp_rowsum_packed.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+        for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed"):
+            getattr(L, n).restype = i32
+        self.L = L
+
+    def chk(self, rc, what):
+        if rc != 0:
+            raise lib.HoicError(f"{what} failed ({rc}): {self.L.hoic_last_error().decode()}")
+
+
+_K = None
+
+
+def kernels():
+    global _K
+    if _K is None:
+        _K = _Kernels()
+    return _K
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class ScaleTable:
+    """Per-tensor power-of-two scale exponents, their running |max| and the f16-overflow counter, all on the device."""
+
+    def __init__(self, device):
+        self.exps = torch.zeros(NSLOT, dtype=torch.int32, device=device)
+        self.amax = torch.zeros(NSLOT, dtype=torch.float32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.device = device
+
+    def update(self, slots, target=TARGET_LOG2):
+        mask = 0
+        for s in slots:
+            mask |= 1 << s
+        K = kernels()
+        K.chk(K.L.hoic_mlp_update_exps(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target, _ptr(self.overflow),
+                                       _stream(self.device)), "hoic_mlp_update_exps")
+
+    def measure(self, slot, x, mul=None):
+        K = kernels()
+        K.chk(K.L.hoic_mlp_amax(_ptr(x), _ptr(mul), x.numel(), _ptr(self.amax), slot, _stream(self.device)), "hoic_mlp_amax")
+
+
+def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None, measure=True):
+    """float32 [R, C] (optionally times ``mul`` elementwise) -> packed tensors (uint16 views of float16 pairs):
+    ``rows``: [Rp, 2 Cp], ``transposed``: [Cp, 2 Rp].  ``measure``: set the slot's exponent from this tensor's own maximum
+    first (exact; used for inputs, weights and the loss-side gradient)."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    Rp = R if Rp is None else Rp
+    Cp = _rup(Cc, 4) if Cp is None else Cp
+    dev = x.device
+    K = kernels()
+    if measure:
+        assert x.is_contiguous()
+        table.measure(slot, x, mul)
+        table.update([slot])
+    P = torch.empty(Rp, 2 * Cp, dtype=torch.float16, device=dev) if rows else None
+    PT = torch.empty(Cp, 2 * Rp, dtype=torch.float16, device=dev) if transposed else None
+    K.chk(K.L.hoic_mlp_pack(_ptr(x), _ptr(mul), R, Cc, x.stride(0), _ptr(P), _ptr(PT), Rp, Cp, _ptr(table.exps), slot, _stream(dev)),
+          "hoic_mlp_pack")
+    return P, PT
+
+
+def gemm(epi, M, N, K_, A, B, table, sa, sb, so=0, extra_scale=1.0, splits=1, C_out=None, bias=None, gin=None, gout=None, hf32=None,
+         P=None, PT=None):
+    Kn = kernels()
+    dev = A.device
+    Kn.chk(Kn.L.hoic_mlp_gemm(epi, M, N, K_, _ptr(A), _ptr(B), _ptr(table.exps), _ptr(table.amax), sa, sb, so, float(extra_scale), splits,
+                              _ptr(C_out), _ptr(bias), _ptr(gin), _ptr(gout), _ptr(hf32), _ptr(P), _ptr(PT), _stream(dev)), "hoic_mlp_gemm")
+
+
+def matmul_nt(a, b, splits=1):
+    """a [M, K] @ b [N, K]^T in float32 through the f16x3 kernel (test / diagnostic entry; pads to the tile sizes)."""
+    M, K_ = a.shape
+    N = b.shape[0]
+    Mp, Np, Kp = _rup(M, 256), _rup(N, 128), _rup(K_, 32)
+    t = ScaleTable(a.device)
+    Ap, _ = pack(a.contiguous(), t, 0, Mp, Kp)
+    Bp, _ = pack(b.contiguous(), t, 1, Np, Kp)
+    out = torch.empty(splits, Mp, Np, dtype=torch.float32, device=a.device)
+    gemm(EPI_F32, Mp, Np, Kp, Ap, Bp, t, 0, 1, splits=splits, C_out=out)
+    return out.sum(0)[:M, :N] if splits > 1 else out[0, :M, :N]
+
+
+class PackedInput:
+    """The batch's network input, packed once per PPO iteration and shared by both networks: rows [Mp, 2 Kp] for the
+    forward pass, transposed [Kp, 2 Mp] for the first layer's weight gradient."""
+
+    def __init__(self, x, table=None):
+        assert x.is_cuda and x.dtype == torch.float32
+        self.M, self.K = x.shape
+        self.Mp, self.Kp = _rup(self.M, 256), _rup(self.K, 128)
+        self.table = table if table is not None else ScaleTable(x.device)
+        self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=True)
+
+
+class SplitMLP:
+    SLOT_X, SLOT_W0, SLOT_H0, SLOT_DZ0 = 0, 1, 4, 8        # W: 1..3, H (hidden activations): 4..6, dZ: 8..10
+
+    def __init__(self, mlp, wgrad_splits=16):
+        from .rl import MLP
+        assert isinstance(mlp, MLP) and isinstance(mlp.activation, torch.nn.GELU), "SplitMLP needs a GELU rl.MLP"
+        self.layers = list(mlp.affine_layers)
+        assert len(self.layers) >= 1
+        self.dev = self.layers[0].weight.device
+        if self.dev.type != "cuda":
+            raise lib.HoicError("SplitMLP: the f16x3 GEMMs run on the GPU only")
+        self.dims_in = [l.in_features for l in self.layers]
+        self.dims_out = [l.out_features for l in self.layers]
+        for n in self.dims_out:
+            assert n % 256 == 0, "hidden sizes must be multiples of 256 for the f16x3 path"
+        self.Kp = [_rup(k, 128) for k in self.dims_in]
+        self.splits = wgrad_splits
+        self.M = None
+        self.first = True
+
+    # ------------------------------------------------------------------ buffers for a batch size
+    def _alloc(self, inp: PackedInput):
+        if self.M == inp.Mp:
+            return
+        Mp, dev = inp.Mp, self.dev
+        L = len(self.layers)
+        h = lambda r, c: torch.empty(r, 2 * c, dtype=torch.float16, device=dev)
+        self.M = Mp
+        self.G = [torch.empty(Mp, n, dtype=torch.float32, device=dev) for n in self.dims_out]
+        self.Hp = [h(Mp, n) for n in self.dims_out[:-1]]
+        self.HpT = [h(n, Mp) for n in self.dims_out[:-1]]
+        self.Hlast = torch.empty(Mp, self.dims_out[-1], dtype=torch.float32, device=dev)
+        self.dZp = [None] + [h(Mp, n) for n in self.dims_out[1:]]          # rows: operand of the data-gradient GEMM (layers >= 1)
+        self.dZpT = [h(n, Mp) for n in self.dims_out]
+        nslab = max(n * k for n, k in zip(self.dims_out, self.Kp))
+        self.slabs = torch.empty(self.splits * nslab, dtype=torch.float32, device=dev)
+        self.first = True
+
+    def _pack_weights(self, table):
+        self.Wp, self.WpT = [], []
+        for i, l in enumerate(self.layers):
+            W = l.weight.detach()
+            P, PT = pack(W, table, self.SLOT_W0 + i, W.shape[0], self.Kp[i], rows=True, transposed=(i > 0))
+            self.Wp.append(P); self.WpT.append(PT)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inp: PackedInput, need_grad=True):
+        """-> float32 [M, out] last hidden activation (a leaf that requires grad when ``need_grad``)."""
+        self._alloc(inp)
+        t = self.table = inp.table
+        self.inp = inp
+        L = len(self.layers)
+        if self.first:
+            with torch.no_grad():
+                for i in range(L - 1):
+                    t.exps[self.SLOT_H0 + i] = 4
+                self.first_bwd = True
+            self.first = False
+        else:
+            t.update([self.SLOT_H0 + i for i in range(L - 1)])         # exponents of the hidden activations from the last pass
+        self._pack_weights(t)
+        A, sa = inp.P, self.SLOT_X
+        for i, l in enumerate(self.layers):
+            last = i == L - 1
+            gemm(EPI_FWD, self.M, self.dims_out[i], self.Kp[i], A, self.Wp[i], t, sa, self.SLOT_W0 + i, self.SLOT_H0 + i,
+                 bias=l.bias.detach(), gout=self.G[i] if need_grad else None, hf32=self.Hlast if last else None,
+                 P=None if last else self.Hp[i], PT=None if (last or not need_grad) else self.HpT[i])
+            if not last:
+                A, sa = self.Hp[i], self.SLOT_H0 + i
+        out = self.Hlast[:inp.M]
+        if need_grad:
+            out = out.detach().requires_grad_(True)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dH):
+        """dH: float32 [M, out] gradient of the loss w.r.t. the last hidden activation.  Fills ``.grad`` of the layers."""
+        t, inp, L, Mp = self.table, self.inp, len(self.layers), self.M
+        M = inp.M
+        if dH.shape[0] != Mp:
+            pad = torch.zeros(Mp, dH.shape[1], dtype=torch.float32, device=self.dev); pad[:M] = dH; dH = pad
+        dH = dH.contiguous()
+        s_last = self.SLOT_DZ0 + L - 1
+        # dZ_last = dH * GELU'(z_last): exponent from its own maximum, then rows (data gradient) and transpose (weights)
+        t.measure(s_last, dH, self.G[-1]); t.update([s_last])
+        P, PT = self.dZp[L - 1], self.dZpT[L - 1]
+        Kn = kernels()
+        Kn.chk(Kn.L.hoic_mlp_pack(_ptr(dH), _ptr(self.G[-1]), Mp, self.dims_out[-1], self.dims_out[-1], _ptr(P if L > 1 else None), _ptr(PT), Mp,
+                                  self.dims_out[-1], _ptr(t.exps), s_last, _stream(self.dev)), "hoic_mlp_pack")
+        if self.first_bwd:      # first backward pass: the hidden-layer gradients start at the loss-side exponent
+            with torch.no_grad():
+                for i in range(L - 1):
+                    t.exps[self.SLOT_DZ0 + i] = t.exps[s_last]
+            self.first_bwd = False
+        else:
+            t.update([self.SLOT_DZ0 + i for i in range(L - 1)])
+        for i in range(L - 1, 0, -1):          # dZ_{i-1} = (dZ_i W_i) * GELU'(z_{i-1})
+            gemm(EPI_BWD, Mp, self.dims_out[i - 1], self.dims_out[i], self.dZp[i], self.WpT[i], t, self.SLOT_DZ0 + i, self.SLOT_W0 + i,
+                 self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1])
+        for i, l in enumerate(self.layers):    # dW_i = dZ_i^T H_{i-1}, db_i = column sums of dZ_i
+            Bt, sb = (inp.PT, self.SLOT_X) if i == 0 else (self.HpT[i - 1], self.SLOT_H0 + i - 1)
+            n, kp = self.dims_out[i], self.Kp[i]
+            gemm(EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=self.splits, C_out=self.slabs)
+            if l.weight.grad is None:
+                l.weight.grad = torch.empty_like(l.weight)
+                l.bias.grad = torch.empty_like(l.bias)
+            Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(self.slabs), self.splits, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
+                                             _stream(self.dev)), "hoic_mlp_slab_reduce")
+            Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
+                   "hoic_mlp_rowsum_packed")
+
+    def check_overflow(self):
+        n = int(self.table.overflow.item())
+        if n:
+            self.table.overflow.zero_()
+            raise lib.HoicError(f"f16x3 GEMM path: {n} tensor(s) exceeded the float16 range under their delayed scale exponent; "
+                                "the update is not valid (use update_dtype='f32')")

@@ -53,8 +53,13 @@ class PolicyGaussian(nn.Module):
             return mean if out is None else out.copy_(mean)
         return torch.addcmul(mean, torch.exp(log_std), torch.randn_like(mean), out=out)     # mean + std * eps
 
-    def get_log_prob(self, x, action):
-        mean, log_std = self.forward(x)
+    def get_log_prob(self, x, action, hidden=None):
+        """``hidden``: the MLP's output for ``x`` when it was computed elsewhere (the f16x3 GEMM path)"""
+        if hidden is None:
+            mean, log_std = self.forward(x)
+        else:
+            mean = self.action_mean(hidden)
+            log_std = self.action_log_std.expand_as(mean)
         var = torch.exp(2 * log_std)
         lp = -((action - mean) ** 2) / (2 * var) - log_std - 0.5 * math.log(2 * math.pi)
         return lp.sum(1, keepdim=True)
@@ -128,9 +133,9 @@ def _gae_device(rewards, masks, values, gamma, tau, next_values):
     return adv, returns
 
 
-def ppo_loss(policy, states, actions, advantages, fixed_log_probs, clip_epsilon):
+def ppo_loss(policy, states, actions, advantages, fixed_log_probs, clip_epsilon, hidden=None):
     """agent_ppo.py:58-64 (exps is all-ones in the release configs, so `ind` selects everything)."""
-    log_probs = policy.get_log_prob(states, actions)
+    log_probs = policy.get_log_prob(states, actions, hidden)
     ratio = torch.exp(log_probs - fixed_log_probs)
     surr1 = ratio * advantages
     surr2 = torch.clamp(ratio, 1.0 - clip_epsilon, 1.0 + clip_epsilon) * advantages

@@ -166,6 +166,38 @@ int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, const int32_t
 int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64_t* solver_cap_hits,
                              int32_t* envs_with_overflow, int32_t reset);
 
+/* ---- the dense GEMMs of the PPO update (AgentPPO.update_policy / AgentPG.update_value: forward + backward of the two
+ * GELU MLPs, uhc/khrylib/rl/agents/agent_ppo.py:16-56, agent_pg.py:18-25, models/mlp.py:24-27) at float32 accuracy on
+ * the f16 matrix cores; no handle needed.  Operands are "packed" tensors: a float32 matrix [R x C] scaled by a power of
+ * two 2^e and split error-free into float16 pairs x 2^e = hi + lo, stored as R rows of 2 C halves in groups of four
+ * columns [h0 h1 h2 h3 l0 l1 l2 l3].  Per-tensor exponents live in a device int32 table d_exps (slot indices are
+ * arguments), running maxima in d_amax (float32 per slot).
+ *
+ * hoic_mlp_pack: float32 d_x [R x C] (row stride ld; optional elementwise factor d_mul of the same layout) -> d_P
+ *   [Rp x 2 Cp] and / or the transpose d_PT [Cp x 2 Rp], zero padded, scaled by 2^d_exps[slot].
+ * hoic_mlp_amax / hoic_mlp_update_exps: d_amax[slot] = max(d_amax[slot], max |x (* mul)|); then for the slots of `mask`
+ *   e = target - ceil(log2 amax) (2^e amax in [2^(target-1), 2^target)), amax cleared; *d_overflow += 1 for a slot whose
+ *   measured maximum exceeded the float16 range under its previous exponent.
+ * hoic_mlp_gemm: C[m][n] = extra_scale 2^-(e_a + e_b) sum_k A[m][k] B[n][k], A [M x 2K], B [N x 2K] packed (M % 256 ==
+ *   N % 128 == K % 32 == 0), three f16 MFMAs (hi.hi + hi.lo + lo.hi) into one float32 accumulator.  epi 0: float32 d_C
+ *   [splits][M x N] (split-K slabs over blockIdx.y);  epi 1 (forward layer): v = gelu(C + bias[n]) -> optional
+ *   float32 d_hf32, packed d_P [M x 2N] and transposed d_PT [N x 2M] at 2^d_exps[slot_out], gelu'(.) -> d_gout;
+ *   epi 2 (data gradient): v = C * d_gin[m][n] -> d_P / d_PT likewise.  Epilogues 1, 2 fold max |v| into d_amax[slot_out].
+ * hoic_mlp_slab_reduce: out[r][c] = scale * sum_s slabs[s][r][c] for c < out_cols (fixed order: deterministic).
+ * hoic_mlp_rowsum_packed: out[r] = 2^-e * sum_c (hi + lo)[r][c] of a packed [rows x 2 Cp] tensor (bias gradients). */
+int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R, int32_t C, int64_t ld, void* d_P, void* d_PT, int32_t Rp,
+                      int32_t Cp, const int32_t* d_exps, int32_t slot, void* stream);
+int32_t hoic_mlp_amax(const float* d_x, const float* d_mul, int64_t n, float* d_amax, int32_t slot, void* stream);
+int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow,
+                             void* stream);
+int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps,
+                      float* d_amax, int32_t slot_a, int32_t slot_b, int32_t slot_out, float extra_scale, int32_t splits, float* d_C,
+                      const float* d_bias, const float* d_gin, float* d_gout, float* d_hf32, void* d_P, void* d_PT, void* stream);
+int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
+                             float scale, void* stream);
+int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot,
+                               void* stream);
+
 /* hoic_step is two launches: the substep kernel (15 fused substeps, the dominant kernel) and the post-step
  * kernel (contact averaging, residual-force QP, termination, reward, observation).  Durations in milliseconds of
  * the most recent launches, measured with HIP events on the launch stream (negative if timing was not enabled

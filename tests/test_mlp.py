@@ -1,0 +1,165 @@
+"""The f16x3 matrix-core GEMM path of the PPO update (hoic_amd/mlp.py, hoic_amd/csrc/hoic_mlp.hip) against plain PyTorch
+float32 / float64 references of the same ops.
+
+Tolerances: an operand split into two halves keeps 22 significand bits, the dropped lo.lo products are < 2^-22 of a
+product, accumulation is float32 — so a GEMM result agrees with the exact (float64) product to a few 1e-7 of
+sum |a||b| (the float32 library GEMM is no closer), and a 5-epoch Adam update agrees with the float32 path to 1e-6
+relative on the parameters (stated per assertion below).
+"""
+import numpy as np
+import pytest
+import torch
+
+from hoic_amd import mlp as M
+
+
+def test_h4l4_format_roundtrip_numpy():
+    """The storage format, stated in NumPy: error-free split into two halves, groups of 4 columns [h h h h l l l l]."""
+    rng = np.random.default_rng(0)
+    x = (rng.normal(size=(6, 16)) * np.exp(rng.normal(size=(6, 16)) * 2)).astype(np.float32)
+    p = M.pack_h4l4_numpy(x, e=3)
+    assert p.shape == (6, 32) and p.dtype == np.float16
+    back = M.unpack_h4l4_numpy(p, e=3)
+    assert np.abs(back - x).max() <= 2.0 ** -21 * np.abs(x).max()
+    g = p.reshape(6, 4, 8)
+    np.testing.assert_array_equal(g[:, :, :4].reshape(6, 16), (x * 8).astype(np.float16))
+
+
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_pack_kernels_match_the_numpy_format():
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(300, 617, device=dev, generator=g) * 3
+    t = M.ScaleTable(dev)
+    P, PT = M.pack(x, t, 2, Rp=320, Cp=640, rows=True, transposed=True)
+    e = int(t.exps[2])
+    amax = float(x.abs().max())
+    assert 2.0 ** (M.TARGET_LOG2 - 1) <= amax * 2.0 ** e < 2.0 ** M.TARGET_LOG2
+    xp = np.zeros((320, 640), np.float32); xp[:300, :617] = x.cpu().numpy()
+    np.testing.assert_array_equal(P.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(xp, e).view(np.uint16))
+    np.testing.assert_array_equal(PT.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(xp.T.copy(), e).view(np.uint16))
+    # product form (dZ = dH * G)
+    y = torch.rand(256, 512, device=dev, generator=g)
+    z = torch.randn(256, 512, device=dev, generator=g) * 1e-5
+    P2, PT2 = M.pack(z, t, 3, Rp=256, Cp=512, rows=True, transposed=True, mul=y)
+    e3 = int(t.exps[3])
+    ref = (z * y).cpu().numpy()
+    np.testing.assert_array_equal(P2.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(ref, e3).view(np.uint16))
+    np.testing.assert_array_equal(PT2.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(ref.T.copy(), e3).view(np.uint16))
+    assert int(t.overflow) == 0
+
+
+@gpu
+@pytest.mark.parametrize("shape", [(256, 256, 32), (512, 128, 64), (768, 640, 2048), (300, 200, 617), (1024, 2048, 1024)])
+def test_gemm_f16x3_accuracy(shape):
+    """C = A B^T against the float64 product: error within a few 1e-7 of sum |a||b| (and not worse than 4x the float32
+    library GEMM's own error); asymmetric operands so that a transposed or permuted tile cannot pass."""
+    Mm, N, K = shape
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(7)
+    a = torch.randn(Mm, K, device=dev, generator=g) * torch.exp(torch.randn(Mm, 1, device=dev, generator=g))
+    b = torch.randn(N, K, device=dev, generator=g) * 0.05 + 0.01
+    c = M.matmul_nt(a, b)
+    ref = a.double() @ b.double().T
+    bound = a.double().abs() @ b.double().abs().T
+    err = ((c.double() - ref).abs() / bound).max().item()
+    err32 = (((a @ b.T).double() - ref).abs() / bound).max().item()
+    print(f"shape {shape}: f16x3 max err / sum|a||b| = {err:.2e}, torch float32 = {err32:.2e}")
+    assert err < 6e-7 and err < max(4 * err32, 3e-7)
+    if K >= 64:         # split-K slabs give the same sum
+        c2 = M.matmul_nt(a, b, splits=2)
+        assert ((c2.double() - ref).abs() / bound).max().item() < 6e-7
+
+
+def _nets(hidden, seed=0):
+    from hoic_amd.rl import MLP
+    torch.manual_seed(seed)
+    net = MLP(617, hidden, "gelu").cuda()
+    head = torch.nn.Linear(hidden[-1], 32).cuda()
+    return net, head
+
+
+@gpu
+def test_split_mlp_forward_backward_matches_autograd():
+    """SplitMLP.forward / backward against torch autograd in float64 on the same network and batch: activations to 2e-6,
+    every parameter gradient to 2e-6 of its largest entry; the batch is not a multiple of the tile (padding path)."""
+    import copy
+    hidden = (512, 256, 256)
+    net, head = _nets(hidden)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Mb = 1000
+    x = torch.clamp(torch.randn(Mb, 617, device="cuda", generator=g) * 1.5, -5, 5)
+    tgt = torch.randn(Mb, 32, device="cuda", generator=g)
+    # float64 reference
+    net64, head64 = copy.deepcopy(net).double(), copy.deepcopy(head).double()
+    out64 = head64(net64(x.double()))
+    loss64 = ((out64 - tgt.double()) ** 2).mean() * 1e-3          # small gradients, as a mean over 50k samples gives
+    loss64.backward()
+    # f16x3 path
+    eng = M.SplitMLP(net)
+    inp = M.PackedInput(x)
+    for rep in range(2):            # the second pass runs with exponents delayed from the first
+        h = eng.forward(inp)
+        assert h.shape == (Mb, hidden[-1]) and h.requires_grad
+        loss = ((head(h) - tgt) ** 2).mean() * 1e-3
+        for p in head.parameters():
+            p.grad = None
+        loss.backward()
+        eng.backward(h.grad)
+        h64 = net64(x.double())
+        assert (h.detach().double() - h64).abs().max().item() < 2e-6 * max(1.0, h64.abs().max().item())
+        for l, l64 in zip(net.affine_layers, net64.affine_layers):
+            for pn in ("weight", "bias"):
+                ga, gr = getattr(l, pn).grad.double(), getattr(l64, pn).grad
+                assert (ga - gr).abs().max().item() < 2e-6 * gr.abs().max().item(), (rep, pn, (ga - gr).abs().max().item(), gr.abs().max().item())
+        eng.check_overflow()
+    # no-grad forward gives the same activations
+    h2 = eng.forward(inp, need_grad=False)
+    assert not h2.requires_grad and torch.equal(h2, h.detach())
+
+
+@gpu
+def test_ppo_update_f16x3_is_as_accurate_as_float32():
+    """PPOLearner.update_params (full-size networks, 4096 samples, the config's 5 epochs of Adam steps) with
+    update_dtype='f16x3' and 'f32' against the same update in float64 from identical weights and batch: the f16x3
+    parameters are as close to the float64 ones as the float32 library path's are (Adam divides by sqrt(v), so entries
+    whose gradient is rounding noise differ between ANY two float32-class computations; the yardstick is float64), the
+    losses agree to 1e-5, and the f16x3 update is deterministic (two runs give identical bits)."""
+    from types import SimpleNamespace
+    from hoic_amd.agent import PPOLearner
+    from hoic_amd.config import Config
+    cfg = Config("box_future5_light_add_geom")
+    dev = torch.device("cuda")
+
+    def run(update_dtype, dtype=torch.float32):
+        torch.manual_seed(0)
+        L = PPOLearner(cfg, 617, 32, dev, update_dtype=update_dtype)
+        if dtype != torch.float32:
+            L.policy_net.to(dtype); L.value_net.to(dtype)
+            L.optimizer_policy = torch.optim.Adam(L.policy_net.parameters(), lr=cfg.policy_lr)
+            L.optimizer_value = torch.optim.Adam(L.value_net.parameters(), lr=cfg.value_lr)
+        g = torch.Generator(device=dev).manual_seed(5)
+        T, N = 16, 256
+        mk = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+        b = SimpleNamespace(states=torch.clamp(mk(T, N, 617), -5, 5).to(dtype), actions=(mk(T, N, 32) * 0.1).to(dtype),
+                            rewards=torch.rand(T, N, device=dev, generator=g).to(dtype),
+                            masks=(torch.rand(T, N, device=dev, generator=g) > 0.05).to(dtype),
+                            next_values=torch.zeros(N, device=dev, dtype=dtype), valid=None)
+        L.update_params(b)
+        return L
+
+    ref64, ref32, a, b = run("f32", torch.float64), run("f32"), run("f16x3"), run("f16x3")
+    for net in ("policy_net", "value_net"):
+        sd64, sd32, sda, sdb = [getattr(x, net).state_dict() for x in (ref64, ref32, a, b)]
+        e32 = ea = nrm = 0.0
+        for k in sd64:
+            assert torch.equal(sda[k], sdb[k]), (net, k)
+            e32 += float(((sd32[k].double() - sd64[k]) ** 2).sum()); ea += float(((sda[k].double() - sd64[k]) ** 2).sum())
+            nrm += float((sd64[k] ** 2).sum())
+        print(f"{net}: |f32 - f64| / |p| = {(e32 / nrm) ** 0.5:.3e}   |f16x3 - f64| / |p| = {(ea / nrm) ** 0.5:.3e}")
+        assert ea ** 0.5 <= 4 * e32 ** 0.5 + 1e-7 * nrm ** 0.5
+    for i in range(2):
+        assert abs(ref64.last_losses[i] - a.last_losses[i]) < 1e-5 * abs(ref64.last_losses[i]) + 1e-7
