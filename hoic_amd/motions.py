@@ -262,3 +262,36 @@ def action_tape(n_steps: int, n_envs: int = 1, seed: int = 123, scale: float = 0
     """Parity-run action tape: U(-1,1) * 0.2, seed 123."""
     rng = np.random.default_rng(seed)
     return (rng.uniform(-1, 1, (n_steps, n_envs, 32)) * scale).astype(np.float64)
+
+
+def mujoco_probe_inputs(model: mjcf.CompiledModel, n_probe: int = 24, n_roll: int = 4, n_sub: int = 45, seed: int = 2024):
+    """Seeded inputs of the MuJoCo pin (tools/capture_mujoco_trace.py writes what MuJoCo 2.1.0 makes of them,
+    tests/test_oracle_mujoco.py feeds the same arrays to the oracle): ``n_probe`` single mj_forward states
+    (qpos / qvel / ctrl / qfrc_applied, expert frames before and after the pick-up plus joint noise, so hand-object,
+    object-table and hand-hand contacts, active joint limits and both friction-loss regimes occur) and ``n_roll``
+    open-loop rollouts of ``n_sub`` mj_steps from expert frames under a fixed torque tape."""
+    rng = np.random.default_rng(seed)
+    A = model.arrays
+    nq, nv, nu, nh = model.scalar("nq"), model.scalar("nv"), model.scalar("nu"), model.scalar("hand_nq")
+    ex = synthetic_expert(model, 4, 300)
+    lo, hi = A["jnt_range"][:nh, 0], A["jnt_range"][:nh, 1]
+    qpos = np.zeros((n_probe, nq)); qvel = np.zeros((n_probe, nv)); ctrl = np.zeros((n_probe, nu)); applied = np.zeros((n_probe, nv))
+    for i in range(n_probe):
+        e = ex[i % 4]; t = int(rng.integers(0, 290)) if i % 3 else int(rng.integers(100, 290))
+        q = np.r_[e["hand_dof_seq"][t], e["obj_pose_seq"][t]]
+        q[6:nh] += rng.normal(size=nh - 6) * (0.02 if i % 2 else 0.15)
+        if i % 4 == 0:
+            q[6:nh] = np.where(rng.random(nh - 6) < 0.3, lo[6:] + 0.003 * rng.random(nh - 6), q[6:nh])      # inside the limit margin
+        q[:nh] = np.clip(q[:nh], lo - 0.005, hi + 0.005)
+        q[nh:nh + 3] += rng.normal(size=3) * (0.001 if i % 2 else 0.004)
+        qpos[i] = q
+        qvel[i] = np.r_[e["hand_dof_vel_seq"][t], e["obj_vel_seq"][t], e["obj_angle_vel_seq"][t]] + rng.normal(size=nv) * (0.002 if i % 5 == 0 else 0.2)
+        ctrl[i] = rng.normal(size=nu) * 0.3
+        applied[i] = rng.normal(size=nv) * 0.05
+    r_qpos = np.zeros((n_roll, nq)); r_qvel = np.zeros((n_roll, nv))
+    for r in range(n_roll):
+        e = ex[r % 4]; t = [0, 95, 140, 220][r % 4]
+        r_qpos[r] = np.r_[e["hand_dof_seq"][t], e["obj_pose_seq"][t]]
+        r_qvel[r] = np.r_[e["hand_dof_vel_seq"][t], e["obj_vel_seq"][t], e["obj_angle_vel_seq"][t]]
+    tape = rng.normal(size=(n_roll, n_sub, nu)) * 0.1
+    return {"qpos": qpos, "qvel": qvel, "ctrl": ctrl, "qfrc_applied": applied, "roll_qpos": r_qpos, "roll_qvel": r_qvel, "roll_ctrl": tape}

@@ -572,6 +572,9 @@ int hoo_get_contacts(const ho_env* e, double* out, int maxcon) {
   return n;
 }
 void hoo_forward(ho_env* e) { ho_forward(&e->m, &e->d); }
+int hoo_solve_dual_pgs(ho_env* e, int max_sweeps, double tol, double* qacc_out, double* force_out) {
+  return ho_solve_dual_pgs(&e->m, &e->d, max_sweeps, tol, qacc_out, force_out);
+}
 void hoo_step(ho_env* e) { ho_step(&e->m, &e->d); }
 void hoo_fwd_position(ho_env* e) { ho_fwd_position(&e->m, &e->d); }
 void hoo_do_simulation(ho_env* e, const double* action) { do_simulation(e, action); }

@@ -662,6 +662,57 @@ void ho_solve(const ho_model* m, ho_data* d) {
   memcpy(d->qacc, qacc, sizeof(double) * nv);
 }
 
+/* ------------------------------------------------------------------ independent second solver (dual PGS)
+ * The same constraint problem in its DUAL form, which is what a projected Gauss-Seidel kernel iterates and what the
+ * north-star text names [MJ-doc: Computation chapter, "PGS solver"]:
+ *     find f in the per-row box  ([-eta, eta] friction loss, [0, inf) limits and pyramidal contact edges)  with
+ *     (A + diag R) f + b  complementary,   A = J M^-1 J',  b = J a0 - aref,   then  qacc = a0 + M^-1 J' f.
+ * Shares nothing with ho_solve but the rows: no cost function, no Hessian, no line search.  The primal problem is
+ * strictly convex, so both must reach the same qacc; tests/test_oracle_physics.py asserts it — protection against a
+ * common-mode error in the Newton solver that every other parity test would inherit.
+ * Call after ho_forward (rows, aref, qacc_smooth, qL are taken from d).  Returns the number of sweeps used. */
+int ho_solve_dual_pgs(const ho_model* m, const ho_data* d, int max_sweeps, double tol, double* qacc_out, double* force_out) {
+  int nv = m->nv, ne = d->nefc;
+  static double A[HO_MAXEFC][HO_MAXEFC], MinvJt[HO_MAXEFC][NV];
+  double b[HO_MAXEFC], f[HO_MAXEFC];
+  memcpy(qacc_out, d->qacc_smooth, sizeof(double) * nv);
+  if (ne == 0) return 0;
+  for (int i = 0; i < ne; i++) {
+    memcpy(MinvJt[i], d->efc_J[i], sizeof(double) * NV);
+    ho_cholsolve(d->qL, nv, NV, MinvJt[i]);
+    double s = -d->efc_aref[i];
+    for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * d->qacc_smooth[k];
+    b[i] = s; f[i] = 0;
+  }
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * MinvJt[j][k];
+      A[i][j] = A[j][i] = s;
+    }
+  int sweep = 0;
+  for (; sweep < max_sweeps; sweep++) {
+    double change = 0, mag = 0;
+    for (int i = 0; i < ne; i++) {
+      double r = b[i] + d->efc_R[i] * f[i];
+      for (int j = 0; j < ne; j++) r += A[i][j] * f[j];
+      double fn = f[i] - r / (A[i][i] + d->efc_R[i]);
+      if (d->efc_type[i] == HO_EFC_FRICTION) {
+        double eta = d->efc_frictionloss[i];
+        fn = fn < -eta ? -eta : (fn > eta ? eta : fn);
+      } else if (fn < 0) fn = 0;
+      change = fmax(change, fabs(fn - f[i])); mag = fmax(mag, fabs(fn));
+      f[i] = fn;
+    }
+    if (change <= tol * (1e-300 + mag)) { sweep++; break; }
+  }
+  for (int i = 0; i < ne; i++) {
+    if (force_out) force_out[i] = f[i];
+    for (int k = 0; k < nv; k++) qacc_out[k] += MinvJt[i][k] * f[i];
+  }
+  return sweep;
+}
+
 /* ------------------------------------------------------------------ forward / step */
 static int finite_vec(const double* v, int n) {
   for (int i = 0; i < n; i++) if (!isfinite(v[i]) || fabs(v[i]) > 1e10) return 0;

@@ -52,6 +52,8 @@ def lib():
         L.hoo_env_compute_torque.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hoo_env_calc_ho_diff.argtypes = [C.c_void_p, C.c_void_p]
         L.hoo_do_simulation.argtypes = [C.c_void_p, C.c_void_p]
+        L.hoo_solve_dual_pgs.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.hoo_solve_dual_pgs.restype = C.c_int
         L.hoo_nnqp_dual.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
@@ -165,6 +167,12 @@ class OracleEnv:
 
     def forward(self):
         self.L.hoo_forward(self.h)
+
+    def solve_dual_pgs(self, max_sweeps=200000, tol=1e-13):
+        """the constraint problem of the last forward() by dual projected Gauss-Seidel -> (qacc, efc_force, sweeps)"""
+        qacc = np.zeros(32); force = np.zeros(640)
+        n = self.L.hoo_solve_dual_pgs(self.h, int(max_sweeps), float(tol), _p(qacc), _p(force))
+        return qacc, force[:int(self.get('nefc')[0])], n
 
     def sim_step(self):
         self.L.hoo_step(self.h)

@@ -129,6 +129,36 @@ def test_solver_kkt(oracle_lib, box_blob, box_model):
     np.testing.assert_allclose(e.get("qfrc_constraint"), J.T @ f, atol=1e-12)
 
 
+@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
+def test_dual_pgs_reaches_the_newton_optimum(oracle_lib, obj):
+    """An independent second solver on the same rows — dual projected Gauss-Seidel on (J M^-1 J' + R) f + b, the
+    formulation north_star names — must land on the qacc of the primal Newton solver (the problem is strictly convex):
+    protection against a common-mode error in the solver every parity test compares against.  States: hand around the
+    object with contacts, friction-loss rows saturated and unsaturated, joint limits active."""
+    from hoic_amd import mjcf
+    blob = open(mjcf.packaged_model_path(obj), "rb").read()
+    A = mjcf.CompiledModel.from_blob(blob).arrays
+    rng = np.random.default_rng(11)
+    e = oracle_lib.OracleEnv(blob)
+    seen_contacts = 0
+    for case in range(6):
+        q = np.zeros(33); q[:26] = 0.5 * (A["jnt_range"][:26, 0] + A["jnt_range"][:26, 1]); q[2] = 0.62
+        q[6:26] += 0.35 * rng.normal(size=20)
+        q[6:26] = np.clip(q[6:26], A["jnt_range"][6:26, 0] + (0.002 if case % 2 else -0.002), A["jnt_range"][6:26, 1])   # some limits active
+        q[26:29] = [0.0, 0.05 - 0.004 * case, 0.56]; q[29:] = [np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0]
+        e.set("qpos", q); e.set("qvel", rng.normal(size=32) * (0.02 if case < 2 else 0.5))
+        e.set("ctrl", rng.normal(size=26) * 0.2); e.set("qacc_warmstart", np.zeros(32))
+        e.forward()
+        nefc = int(e.get("nefc")[0]); seen_contacts += int(e.get("ncon")[0])
+        qacc_newton = e.get("qacc")[:32].copy(); f_newton = e.get("efc_force")[:nefc].copy()
+        qacc_pgs, f_pgs, sweeps = e.solve_dual_pgs(max_sweeps=400000, tol=1e-14)
+        scale = np.abs(qacc_newton).max()
+        assert np.abs(qacc_pgs - qacc_newton).max() < 2e-6 * scale, (obj, case, sweeps, np.abs(qacc_pgs - qacc_newton).max(), scale)
+        # the dual variables are the row forces of the primal optimum (unique where R > 0)
+        np.testing.assert_allclose(f_pgs, f_newton, atol=2e-6 * max(np.abs(f_newton).max(), 1e-9))
+    assert seen_contacts > 0
+
+
 def test_momentum_of_hand_object_contact(oracle_lib, box_blob, box_model):
     """Contact forces are internal: with gravity off and no other constraints, J'f on the object's translational
     dofs equals minus the net force the hand receives (checked through the contact frame sums)."""
