@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the Box hand-mimic rollout + PPO update at 4096 envs per GPU.
 
-    python bench.py --gpus 1 --steps 26 --warmup 13
+    python bench.py --gpus 1 --steps 130 --warmup 26
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over the whole batch: running observation filter + policy forward + one
-fused HIP env step (15 physics substeps, reward, observation) for every env of every rank.  The PPO update
-(GAE + 5 full-batch epochs of value and policy steps, as the reference) runs every ceil(50000/envs) steps
-INSIDE the timed region, so `value` is whole-loop throughput (rollout + update); rollout-only and update times
-are reported next to it.  Weak scaling: every rank owns `--envs` environments; only gradients, three
+A "step" is one pass of the hot path over the whole batch: running observation filter + policy forward + one fused HIP
+env step (15 physics substeps, reward, observation) for every env of every rank.  The PPO update (GAE + 5 full-batch
+epochs of value and policy steps, as the reference) runs every T = ceil(50000 / envs) steps INSIDE the timed region, so
+`value` is whole-loop throughput (rollout + update); rollout-only and update times are reported next to it.  The timed
+region is a whole number of PPO iterations: --steps / --warmup are rounded UP to multiples of T (the requested numbers
+are reported as steps_requested / warmup_requested) so that every timed step carries its exact share of update work.
+
+Scaling: `--scaling weak` (default) every rank owns `--envs` environments and collects 50000 samples per iteration (the
+batch grows with the GPUs); `--scaling strong` the ranks share the reference's 50000-sample batch.  Only gradients, three
 advantage-normalisation scalars and the ZFilter moments cross ranks (RCCL).
 
-One JSON line on rank 0 (contract of the task statement) with `roofline` (dynamics kernel, HBM-bound, algorithmic
-bytes per env-step from SURVEY.md §8(d)) and `cpu_baseline` (the float64 CPU oracle timed on this box's cores).
+One JSON line on rank 0 (contract of the task statement) with `roofline` (dynamics kernel against HBM, algorithmic bytes
+per env-step from SURVEY.md §8(d)), `roofline_valu` (the same kernel against the vector-issue peak, the bound that
+matters, from the committed SQ counter pass) and `cpu_baseline` (the float64 CPU oracle timed on this box's cores, with
+and without the reference's per-step batch-1 float64 policy forward).
 """
 import argparse
 import json
@@ -27,46 +33,57 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 3432 + 520   # 858 words + 130 words of persisted lagged state
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-operations / s
 
 
-def traffic_from_profile(envs):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/sim_only.py, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside this process, so the number is only
-    reported when the profile was taken at the same env count; otherwise null."""
+def _latest_profile(pattern, pred=lambda d: True):
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("envs") == envs and d.get("kernel") == "hoic_substep_kernel":
-            best = d
-    return None if best is None else best["traffic_bytes_per_launch"]
+        if pred(d):
+            best = (os.path.basename(f), d)
+    return best
 
 
-def issue_profile():
-    """Where the dominant kernel's wave time goes, from the committed SQ counter pass (profiles/*_substep_sq_counters.json):
-    the kernel is instruction-issue / dependency-latency bound, which neither roofline the contract names can express."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_substep_sq_counters.json")))
-    if not files:
+def traffic_from_profile(envs, obj):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/sim_only.py, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  Counters cannot be read inside this process, so the number is only reported when a
+    profile was taken at the same env count and object; otherwise null."""
+    p = _latest_profile("*_hbm_traffic.json", lambda d: d.get("envs") == envs and d.get("kernel") == "hoic_substep_kernel" and d.get("obj", "box") == obj)
+    return None if p is None else p[1]["traffic_bytes_per_launch"]
+
+
+def valu_roofline(kernel_ms, envs_per_launch):
+    """The dominant kernel against the vector-issue peak: VALU instructions per wavefront (= per env-step) from the
+    committed SQ counter pass (profiles/*_substep_sq_counters.json) x 64 lanes x envs per launch / the launch time
+    measured here."""
+    p = _latest_profile("*_substep_sq_counters.json")
+    if p is None or kernel_ms <= 0:
         return None
-    try:
-        c = json.load(open(files[-1]))["per_env_step"]
-        wc = float(c["SQ_WAVE_CYCLES"])
-        return {"source": os.path.basename(files[-1]), "wave_quad_cycles_per_env_step": wc,
-                "issuing_frac": c["SQ_ACTIVE_INST_ANY"] / wc, "waitcnt_frac": c["SQ_WAIT_ANY"] / wc,
-                "issue_stall_frac": c["SQ_WAIT_INST_ANY"] / wc, "valu_insts_per_env_step": c["SQ_INSTS_VALU"],
-                "lds_insts_per_env_step": c["SQ_INSTS_LDS"], "waves_per_simd": 2}
-    except Exception:
-        return None
+    name, d = p
+    c = d["per_env_step"]
+    lane_ops = float(c["SQ_INSTS_VALU"]) * 64.0
+    achieved = lane_ops * envs_per_launch / (kernel_ms * 1e-3)
+    wc = float(c.get("SQ_WAVE_CYCLES", 0)) or None
+    out = {"bound": "valu-issue", "achieved": achieved, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-ops/s", "frac": achieved / VALU_PEAK_LANE_OPS,
+           "valu_insts_per_env_step": c["SQ_INSTS_VALU"], "source": name,
+           "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)) if ("SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU")) else None}
+    if wc:
+        out.update({"wave_quad_cycles_per_env_step": wc, "issuing_frac": c.get("SQ_ACTIVE_INST_ANY", 0) / wc, "waitcnt_frac": c.get("SQ_WAIT_ANY", 0) / wc,
+                    "issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0) / wc})
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_worker(args):
-    """Time the CPU oracle (float64, scalar) on one core for ~`seconds`; returns env-steps done."""
-    seed, seconds = args
+    """Time the CPU oracle (float64, scalar) on one core for ~`seconds`; with_policy adds the reference's batch-1
+    float64 policy forward per step (agent_handmimic.py:463-465).  Returns (env-steps done, seconds)."""
+    seed, seconds, with_policy = args
     import numpy as np
     from hoic_amd import mjcf, motions
     from hoic_amd.config import Config
@@ -78,16 +95,27 @@ def cpu_worker(args):
     env = hoo.OracleEnv(blob)
     env.set_cfg(cfg.jkp, cfg.jkd, cfg.torque_lim, (cfg.pos_diff_thresh, cfg.rot_diff_thresh, cfg.jpos_diff_thresh,
                                                    cfg.obj_pos_diff_thresh, cfg.obj_rot_diff_thresh))
+    policy = None
+    if with_policy:
+        import torch
+        torch.set_num_threads(1)                       # OMP_NUM_THREADS=1, scripts/train_hand_mimic.py:2-3
+        from hoic_amd.rl import PolicyGaussian
+        torch.manual_seed(seed)
+        policy = PolicyGaussian(cfg, 32, 617).double()
     rng = np.random.default_rng(seed)
     wk = cfg.reward_wk()
     steps = 0
     t0 = time.time()
     while time.time() - t0 < seconds:
         env.set_expert(ex[int(rng.integers(0, 2))])
-        env.reset(int(rng.integers(0, 200)))
+        obs = env.reset(int(rng.integers(0, 200)))
         for _ in range(10000):
-            a = rng.normal(size=32) * 0.1      # sigma = e^-2.3 around a zero-mean policy at init
-            _, info = env.step(a)
+            if policy is not None:
+                with torch.no_grad():
+                    a = policy.select_action(torch.as_tensor(np.clip(obs, -5, 5)[None]))[0].numpy()
+            else:
+                a = rng.normal(size=32) * 0.1          # sigma = e^-2.3 around a zero-mean policy at init
+            obs, info = env.step(a)
             env.reward(wk)
             steps += 1
             if info["done"] or time.time() - t0 >= seconds:
@@ -95,32 +123,46 @@ def cpu_worker(args):
     return steps, time.time() - t0
 
 
-def cpu_baseline(seconds=12.0):
+def cpu_baseline(seconds=24.0):
+    """B0 (1 process), B1 (min(32, cores) processes), B2 (with the per-step policy forward), all on this
+    box's host cores; `value` = B2 at min(32, cores) processes, the closest stand-in for the reference's
+    --num_threads 32 sampler."""
     import multiprocessing as mp
     cores = min(32, os.cpu_count() or 1)
     ctx = mp.get_context("fork")   # called before anything touches the GPU (no exec from a GPU process)
-    with ctx.Pool(cores) as pool:
-        t0 = time.time()
-        res = pool.map(cpu_worker, [(s, seconds) for s in range(cores)])
-        wall = time.time() - t0
-    steps = sum(r[0] for r in res)
-    per_proc = max(r[1] for r in res)
-    return {"value": steps / per_proc, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} processes x {seconds:.0f}s of the float64 CPU oracle (oracle/, one Box env each, "
-                      f"synthetic motions, N(0,0.1) actions, whole episodes incl. reward+RFC QP; no policy net); "
-                      f"{steps} env-steps, pool wall {wall:.1f}s. The literal reference (MuJoCo 2.1.0 + mujoco_py, "
-                      f"--num_threads 32) cannot run here: MuJoCo is not in the image"}
+    leg = seconds / 4.0
+
+    def run(n, with_policy):
+        with ctx.Pool(n) as pool:
+            res = pool.map(cpu_worker, [(s, leg, with_policy) for s in range(n)])
+        return sum(r[0] for r in res) / max(r[1] for r in res), sum(r[0] for r in res)
+
+    b0, n0 = run(1, False)
+    b2_1, n2 = run(1, True)
+    b1, n1 = run(cores, False)
+    b2, n3 = run(cores, True)
+    return {"value": b2, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "b0_one_process_no_policy": b0, "b1_processes_no_policy": b1, "b2_one_process_with_policy": b2_1, "b2_processes_with_policy": b2,
+            "host_cores_present": os.cpu_count(),
+            "sample": f"4 legs x {leg:.0f}s of the float64 CPU oracle (oracle/, one Box env per process, synthetic motions, whole episodes "
+                      f"incl. reward + RFC QP): 1 process / {cores} processes, without and with the reference's batch-1 float64 policy "
+                      f"forward per step (policy sampled, sigma e^-2.3; N(0, 0.1) actions otherwise); {n0}+{n2}+{n1}+{n3} env-steps. `value` = "
+                      f"{cores} processes with the policy forward. The literal reference (MuJoCo 2.1.0 + mujoco_py, --num_threads 32) "
+                      f"cannot run here: MuJoCo is not in the image"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=26)
-    ap.add_argument("--warmup", type=int, default=13)
+    ap.add_argument("--steps", type=int, default=130)
+    ap.add_argument("--warmup", type=int, default=26)
     ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--obj", default="box")
-    ap.add_argument("--update-dtype", default="f32", choices=["f32", "bf16"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--obj", default="box", choices=["box", "bottle", "banana"])
+    ap.add_argument("--update-dtype", default="f16x3", choices=["f32", "bf16", "f16x3"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="train", choices=["train", "grasp"],
+                    help="train: the sampler's own episode draws; grasp: episodes start at frames >= 100 (object in the hand: contact-rich)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=8)
     ap.add_argument("--groups", type=int, default=None, help="env ranges pipelined on separate streams during the rollout (default: 2 at >= 4096 envs)")
@@ -152,9 +194,11 @@ def main():
     expert = motions.synthetic_expert(model, 17, 600)         # 17 sequences x 600 frames
     agent = AgentHandMimic(cfg, device=torch.device("cuda", local_rank), n_envs=args.envs, model=args.obj,
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
-                           solver_iterations=args.solver_iterations, n_groups=args.groups)
-    steps_per_iter = int(math.ceil(cfg.min_batch_size / args.envs))
-    n_warm_it = max(1, int(math.ceil(args.warmup / steps_per_iter))) if args.warmup > 0 else 0
+                           solver_iterations=args.solver_iterations, n_groups=args.groups, scaling=args.scaling,
+                           start_min=100 if args.workload == "grasp" else 0)
+    share = world if args.scaling == "strong" else 1
+    steps_per_iter = int(math.ceil(math.ceil(cfg.min_batch_size / share) / args.envs))
+    n_warm_it = int(math.ceil(args.warmup / steps_per_iter)) if args.warmup > 0 else 0
     n_it = max(1, int(math.ceil(args.steps / steps_per_iter)))
     K = n_it * steps_per_iter
     W = n_warm_it * steps_per_iter
@@ -168,6 +212,7 @@ def main():
     for _ in range(n_warm_it):
         agent.optimize_policy(epoch, save_model=False); epoch += 1
     agent.env.sim.enable_timing(True)
+    agent.env.sim.diagnostics(reset=True)
     kernel_ms = []
     post_ms = []
     barrier()
@@ -193,29 +238,43 @@ def main():
         n_groups = len(agent._groups())
         envs_per_launch = args.envs // n_groups          # the rollout steps the batch as n_groups env ranges (hoic_step_range)
         achieved = ALGO_BYTES_PER_ENV_STEP * envs_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        diag = agent.env.sim.diagnostics()
+        # fraction of envs with a hand-object contact right now (one probe launch on the current states)
+        q, v, _ = agent.env.sim.get_state()
+        pr = agent.env.sim.probe_forward(q[:1024].cpu().numpy(), v[:1024].cpu().numpy(), kinematics_only=True)
+        hg0, hg1, og0, og1 = [model.scalar(k) for k in ("hand_geom0", "hand_geom1", "obj_geom0", "obj_geom1")]
+        cc = pr["contacts"]
+        ho = (cc[:, :, 13] >= hg0) & (cc[:, :, 13] <= hg1) & (cc[:, :, 14] >= og0) & (cc[:, :, 14] <= og1) & (cc[:, :, 15] > 0)
+        dtype_txt = {"f32": "f32", "bf16": "f32 dynamics + bf16 update GEMMs (f64 RFC QP)",
+                     "f16x3": "f32 (dynamics f32, RFC QP f64; update GEMMs = float32 operands split error-free into f16 pairs, "
+                              "3 f16 MFMAs per product sum into f32 accumulators: 22-bit operands, float32-class accuracy)"}[args.update_dtype]
         out = {
             "metric": "env-steps/sec (whole node), Box hand-mimic PPO @4096 envs/GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.update_dtype == "f32" else "f32 dynamics + bf16 update GEMMs (f64 RFC QP)",
-            "data": "synthetic",
+            "steps_requested": args.steps, "warmup_requested": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": dtype_txt, "data": "synthetic",
             "config": {"workload": f"{args.obj.capitalize()}, {args.envs} parallel envs per GPU, HIP batched sim "
-                                   f"+ PyTorch-ROCm PPO (whole loop: rollout + GAE + {cfg.num_optim_epoch} full-batch epochs)",
-                       "envs_per_gpu": args.envs, "steps_per_iteration": steps_per_iter,
+                                   f"+ PyTorch-ROCm PPO (whole loop: rollout + GAE + {cfg.num_optim_epoch} full-batch epochs)"
+                                   + ("; episodes start at frames >= 100 (grasp phase, contact-rich)" if args.workload == "grasp" else ""),
+                       "envs_per_gpu": args.envs, "steps_per_iteration": steps_per_iter, "timed_iterations": n_it,
                        "samples_per_iteration": steps_per_iter * args.envs * world, "parallelism": f"env-dp{world}",
-                       "rollout_env_ranges": n_groups,
+                       "rollout_env_ranges": n_groups, "update_gemms": args.update_dtype,
                        "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
                                                 if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,
-            "update_s_per_iteration": t_update / n_it,
+            "update_s_per_iteration": t_update / n_it, "rollout_s_per_iteration": t_sample / n_it,
             "avg_episode_len": float(last_log.avg_episode_len), "avg_c_reward": float(last_log.avg_c_reward),
+            "workload_stats": {"hand_object_contact_env_fraction": float(ho.any(1).mean()), "mean_contacts_per_env": float((cc[:, :, 15] > 0).sum(1).mean()),
+                               "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"],
+                               "solver_cap_hit_fraction_of_substeps": diag["solver_cap_hits"] / float(K * args.envs * cfg.sim_step)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(envs_per_launch), "kernel": "hoic_substep_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(envs_per_launch, args.obj), "kernel": "hoic_substep_kernel",
                          "kernel_ms": k_ms, "poststep_kernel_ms": sum(post_ms) / max(len(post_ms), 1),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * envs_per_launch, "envs_per_launch": envs_per_launch,
-                         "issue_profile": issue_profile(),
                          "note": "launch durations are HIP-event times on each range's own stream; with 2 ranges in flight a launch "
                                  "shares the GPU with the other range's kernels" if n_groups > 1 else None},
+            "roofline_valu": valu_roofline(k_ms, envs_per_launch),
         }
         out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -252,8 +252,13 @@ class PPOLearner:
 class AgentHandMimic:
     def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
-                 strict_reference=True, solver_iterations=8, n_groups=None, sample_mode="fixed", eval_envs=None):
-        assert sample_mode in ("fixed", "episodes")
+                 strict_reference=True, solver_iterations=8, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
+                 start_min=0):
+        assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
+        # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
+        # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
+        self.scaling = scaling
+        self.start_min = int(start_min)      # episodes start at frame >= start_min (benchmark workloads; the reference draws from 0)
         self.cfg = self.cc_cfg = cfg
         self.sample_mode = sample_mode
         # rollout pipelining: 2 half-batches once a half still fills the GPU's 2048 wavefront slots
@@ -322,7 +327,11 @@ class AgentHandMimic:
         hi = max(self.seq_num - 1, 1)                        # never the last (held-out) sequence
         seq = torch.randint(0, hi, (n,), device=self.device, generator=self.gen, dtype=torch.int64)
         u = torch.rand(n, device=self.device, generator=self.gen)
-        start = (u * self._max_start[seq].to(u.dtype)).to(torch.int32)
+        if self.start_min > 0:
+            lo = torch.clamp(torch.full_like(self._max_start[seq], self.start_min), max=self._max_start[seq] - 1)
+            start = (lo + u * (self._max_start[seq] - lo).to(u.dtype)).to(torch.int32)
+        else:
+            start = (u * self._max_start[seq].to(u.dtype)).to(torch.int32)
         return seq.to(torch.int32), start
 
     def _make_log(self, steps, rewards, end_flags, done_flags, rinfo, valid, t0):
@@ -494,7 +503,8 @@ class AgentHandMimic:
         self.epoch = epoch
         t0 = time.time()
         self.per_epoch_update(epoch)
-        batch, log = self.sample(self.cfg.min_batch_size)
+        share = self.world if (self.scaling == "strong" and self.distributed) else 1
+        batch, log = self.sample(int(math.ceil(self.cfg.min_batch_size / share)))
         if self.cfg.end_reward:
             self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
         t1 = time.time()
