@@ -778,10 +778,8 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     if (mva.size() > HOIC_MAX_MESH || mv.size() > (size_t)MAXMESHV * 3 || mpl.size() > (size_t)MAXMESHP * 4) {
       set_err("model blob: mesh tables exceed compiled capacities"); return false;
     }
-    for (size_t i = 0; i < mva.size(); i++)
-      if (mvn[i] > 64 || mpn[i] > 128) { set_err("model blob: a convex hull has more than 64 vertices or 128 faces (one vertex / two faces per lane)"); return false; }
     for (size_t i = 0; i < mva.size(); i++) { m.mesh_vertadr[i] = mva[i]; m.mesh_vertnum[i] = mvn[i]; m.mesh_planeadr[i] = mpa[i]; m.mesh_planenum[i] = mpn[i]; }
-    for (size_t i = 0; i < mv.size(); i++) m.mesh_vert[i / 3][i % 3] = (float)mv[i];
+    for (size_t i = 0; i < mv.size(); i++) m.mesh_vert[i / 3][i % 3] = (float)mv[i];     // [.][3] stays 0
     for (size_t i = 0; i < mpl.size(); i++) m.mesh_plane[i / 4][i % 4] = (float)mpl[i];
   } else { set_err("model blob: mesh tables missing"); return false; }
   return true;

@@ -342,43 +342,35 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
 }
 
 // ---- convex mesh (hull vertices + face planes in the geom frame) vs plane / capsule / box, wave-cooperative: the
-// whole wave works on one pair at a time (like box-box).  Lane l keeps face planes l and l + 64 and vertex l of the hull
-// in registers (hulls have at most 64 vertices and 128 faces: checked at model load), so "the face of largest signed
-// distance at a point" - the kernel of all three routines - is two plane evaluations per lane and one wave maximum
-// instead of a 120-trip loop over tables in global memory, and the vertex loops run one vertex per lane.  The logic
-// around it is the sequential formulation of oracle/ho_collide.c, evaluated uniformly by all lanes; results that
-// depend on an order (first maximum, keep-the-deepest-four, three-lowest) are produced in that order.
-struct HullLane { float p0[4], p1[4], v[3]; int np, nv; };
-HD void hull_lane_load(const DevModel& m, int mesh, HullLane& h) {
-  const int lane = threadIdx.x;
+// whole wave works on one pair at a time (like box-box).  The hull tables stay in global memory (L1 / L2 resident, a few
+// tens of KB per model) and are streamed 64 entries per pass, one per lane, so a hull may have any size up to the
+// compiled capacities (the reference's full hulls: 130 / 258 vertices for the bottle, 231 / 707 / 939 for the banana).
+// "The face of largest signed distance at a point" - the kernel of all three routines - is one coalesced float4 load
+// and 4 FMAs per lane and pass plus one wave maximum, and the vertex loops run one vertex per lane.  The logic around it
+// is the sequential formulation of oracle/ho_collide.c, evaluated uniformly by all lanes; results that depend on an
+// order (first maximum, keep-the-deepest-four, three-lowest) are produced in that order.
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct HullRef { GPTR(const f4v) pl; GPTR(const f4v) vv; int np, nv; };
+HD HullRef hull_ref(const DevModel& m, int mesh) {
+  HullRef h;
   h.np = m.mesh_planenum[mesh]; h.nv = m.mesh_vertnum[mesh];
-  const float (*pl)[4] = &m.mesh_plane[m.mesh_planeadr[mesh]];
-  const float (*vv)[3] = &m.mesh_vert[m.mesh_vertadr[mesh]];
-  const bool a0 = lane < h.np, a1 = lane + 64 < h.np, av = lane < h.nv;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {       // a face that does not exist evaluates to -1e30 everywhere
-    h.p0[i] = a0 ? pl[lane][i] : (i == 3 ? 1e30f : 0.f);
-    h.p1[i] = a1 ? pl[lane + 64][i] : (i == 3 ? 1e30f : 0.f);
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++) h.v[i] = av ? vv[lane][i] : 0.f;
+  h.pl = (GPTR(const f4v))(GPTR(const void))&m.mesh_plane[m.mesh_planeadr[mesh]][0];
+  h.vv = (GPTR(const f4v))(GPTR(const void))&m.mesh_vert[m.mesh_vertadr[mesh]][0];
+  return h;
 }
 // max over the faces of n.x - d at the point (x, y, z) (hull frame); pl = that face (the first one in face order on ties)
-HD float hull_max_wave(const HullLane& h, float x, float y, float z, float* pl) {
+HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
   const int lane = threadIdx.x;
-  const float v0 = h.p0[0] * x + h.p0[1] * y + h.p0[2] * z - h.p0[3];
-  const float v1 = h.p1[0] * x + h.p1[1] * y + h.p1[2] * z - h.p1[3];
-  const bool second = v1 > v0;
-  const float bv = second ? v1 : v0;
-  const int bi = second ? lane + 64 : lane;
+  float bv = -1e30f; int bi = 0x00ffffff;
+  for (int t = lane; t < h.np; t += NT) {          // ascending index per lane: '>' keeps the lane's first maximum
+    const f4v p = h.pl[t];
+    const float v = fmaf(p.x, x, fmaf(p.y, y, fmaf(p.z, z, -p.w)));
+    if (v > bv) { bv = v; bi = t; }
+  }
   const float mx = wave_max(bv);
-  const unsigned long long tied = __ballot(bv == mx);
-  int idx = 0;
-  if (__popcll(tied) > 1) idx = (int)wave_min(bv == mx ? (float)bi : 1e9f);
-  else if (tied) idx = __builtin_amdgcn_readlane(bi, __ffsll((long long)tied) - 1);
-  const int wl = idx & 63;
-#pragma unroll
-  for (int i = 0; i < 4; i++) pl[i] = rl(second ? h.p1[i] : h.p0[i], wl);
+  const int idx = (int)wave_min(bv == mx ? (float)bi : 1e9f);     // indices < 2^24 are exact in float32
+  const f4v w = h.pl[idx];                                         // wave-uniform address
+  pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
   return mx;
 }
 // the sequential "keep the four deepest" of one pair's contact list, state held uniformly: n, the four distances
@@ -397,36 +389,53 @@ HD void deep4_add(Deep4& k, const LaneContacts& owner, float dist, const float* 
   k.d0 = slot == 0 ? dist : k.d0; k.d1 = slot == 1 ? dist : k.d1; k.d2 = slot == 2 ? dist : k.d2; k.d3 = slot == 3 ? dist : k.d3;
   if (threadIdx.x == 0) { LaneContacts o = owner; lc_put(o, slot, dist, pos, nrm); }
 }
-__device__ __forceinline__ int col_plane_mesh_wave(const HullLane& h, const float* pp, const float* pR, const float* mp,
+__device__ __forceinline__ int col_plane_mesh_wave(const HullRef& h, const float* pp, const float* pR, const float* mp,
                                                 const float* mR, const LaneContacts& owner) {
   const int lane = threadIdx.x;
-  float n[3], wv[3];
+  float n[3];
   matcol(pR, 2, n);
-  matvec(mR, h.v, wv);
-  for (int i = 0; i < 3; i++) wv[i] += mp[i];
-  const float dist = (wv[0] - pp[0]) * n[0] + (wv[1] - pp[1]) * n[1] + (wv[2] - pp[2]) * n[2];
-  unsigned long long neg = __ballot(lane < h.nv && dist < 0.f);
-  float best[3] = {0.f, 0.f, 0.f}; int bi[3] = {-1, -1, -1};
-  while (neg) {                       // the three lowest vertices, inserted in vertex order
-    const int v = __ffsll((long long)neg) - 1;
-    neg &= neg - 1;
-    const float dv = rl(dist, v);
-    if (bi[0] < 0 || dv < best[0]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = best[0]; bi[1] = bi[0]; best[0] = dv; bi[0] = v; }
-    else if (bi[1] < 0 || dv < best[1]) { best[2] = best[1]; bi[2] = bi[1]; best[1] = dv; bi[1] = v; }
-    else if (bi[2] < 0 || dv < best[2]) { best[2] = dv; bi[2] = v; }
+  float best[3] = {0.f, 0.f, 0.f}, bpos[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  int nb = 0;
+  for (int base = 0; base < h.nv; base += NT) {       // 64 vertices per pass, the three lowest inserted in vertex order
+    const int vi = base + lane;
+    const f4v q = h.vv[vi < h.nv ? vi : 0];
+    const float lv[3] = {q.x, q.y, q.z};
+    float wv[3];
+    matvec(mR, lv, wv);
+    for (int i = 0; i < 3; i++) wv[i] += mp[i];
+    const float dist = (wv[0] - pp[0]) * n[0] + (wv[1] - pp[1]) * n[1] + (wv[2] - pp[2]) * n[2];
+    unsigned long long neg = __ballot(vi < h.nv && dist < 0.f);
+    while (neg) {
+      const int v = __ffsll((long long)neg) - 1;
+      neg &= neg - 1;
+      const float dv = rl(dist, v), px = rl(wv[0], v), py = rl(wv[1], v), pz = rl(wv[2], v);
+      int at = -1;
+      if (nb < 1 || dv < best[0]) at = 0;
+      else if (nb < 2 || dv < best[1]) at = 1;
+      else if (nb < 3 || dv < best[2]) at = 2;
+      if (at < 0) continue;
+      if (at <= 1) { best[2] = best[1]; for (int i = 0; i < 3; i++) bpos[2][i] = bpos[1][i]; }
+      if (at == 0) { best[1] = best[0]; for (int i = 0; i < 3; i++) bpos[1][i] = bpos[0][i]; }
+      const int a_ = at;
+      best[0] = a_ == 0 ? dv : best[0]; best[1] = a_ == 1 ? dv : best[1]; best[2] = a_ == 2 ? dv : best[2];
+      bpos[0][0] = a_ == 0 ? px : bpos[0][0]; bpos[0][1] = a_ == 0 ? py : bpos[0][1]; bpos[0][2] = a_ == 0 ? pz : bpos[0][2];
+      bpos[1][0] = a_ == 1 ? px : bpos[1][0]; bpos[1][1] = a_ == 1 ? py : bpos[1][1]; bpos[1][2] = a_ == 1 ? pz : bpos[1][2];
+      bpos[2][0] = a_ == 2 ? px : bpos[2][0]; bpos[2][1] = a_ == 2 ? py : bpos[2][1]; bpos[2][2] = a_ == 2 ? pz : bpos[2][2];
+      if (nb < 3) nb++;
+    }
   }
   int cnt = 0;
 #pragma unroll
   for (int s = 0; s < 3; s++) {
-    if (bi[s] < 0) continue;
+    if (s >= nb) continue;
     float pos[3];
-    for (int i = 0; i < 3; i++) pos[i] = rl(wv[i], bi[s]) - 0.5f * best[s] * n[i];
+    for (int i = 0; i < 3; i++) pos[i] = bpos[s][i] - 0.5f * best[s] * n[i];
     if (lane == 0) { LaneContacts o = owner; lc_put(o, cnt, best[s], pos, n); }
     cnt++;
   }
   return cnt;
 }
-__device__ __forceinline__ int col_capsule_mesh_wave(const HullLane& h, const float* cp, const float* cR, const float* cs,
+__device__ __forceinline__ int col_capsule_mesh_wave(const HullRef& h, const float* cp, const float* cR, const float* cs,
                                                   const float* mp, const float* mR, const LaneContacts& owner) {
   float ax[3], rel[3], pc[3], al[3], a[3], d[3];
   matcol(cR, 2, ax);
@@ -481,13 +490,16 @@ __device__ __forceinline__ int col_capsule_mesh_wave(const HullLane& h, const fl
   }
   return cnt;
 }
-__device__ __forceinline__ int col_box_mesh_wave(const HullLane& h, const float* bp, const float* bR, const float* bh,
+__device__ __forceinline__ int col_box_mesh_wave(const HullRef& h, const float* bp, const float* bR, const float* bh,
                                               const float* mp, const float* mR, float mesh_rbound, const LaneContacts& owner) {
   const int lane = threadIdx.x;
   Deep4 keep{0, 0.f, 0.f, 0.f, 0.f};
-  {                                   // hull vertices inside the box: one vertex per lane, kept in vertex order
+  for (int base = 0; base < h.nv; base += NT) {   // hull vertices inside the box: 64 per pass, one per lane, kept in vertex order
+    const int vi = base + lane;
+    const f4v q = h.vv[vi < h.nv ? vi : 0];
+    const float lv[3] = {q.x, q.y, q.z};
     float wv[3], rel[3], p[3];
-    matvec(mR, h.v, wv);
+    matvec(mR, lv, wv);
     for (int i = 0; i < 3; i++) { wv[i] += mp[i]; rel[i] = wv[i] - bp[i]; }
     mattvec(bR, rel, p);
     float depth = 1e30f; int k = 0;
@@ -497,7 +509,7 @@ __device__ __forceinline__ int col_box_mesh_wave(const HullLane& h, const float*
     float nl[3] = {k == 0 ? sg : 0.f, k == 1 ? sg : 0.f, k == 2 ? sg : 0.f}, nw[3], pos[3];
     matvec(bR, nl, nw);
     for (int i = 0; i < 3; i++) pos[i] = wv[i] + nw[i] * 0.5f * depth;
-    unsigned long long pen = __ballot(lane < h.nv && depth > 0.f);
+    unsigned long long pen = __ballot(vi < h.nv && depth > 0.f);
     while (pen) {
       const int v = __ffsll((long long)pen) - 1;
       pen &= pen - 1;
@@ -603,15 +615,14 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
       }
       wsync();
     }
-    // mesh pairs: likewise one after the other; the hull stays in the lanes' registers while consecutive pairs share it
+    // mesh pairs: likewise one after the other, the hull tables streamed from the cache hierarchy
     {
       unsigned long long mm = __ballot(ismesh);
-      HullLane hull; int cur = -1;
       while (mm) {
         const int L = __ffsll((long long)mm) - 1;
         mm &= mm - 1;
         const int pp = ps * NT + L, ga = m.pair_geom1[pp], gb = m.pair_geom2[pp], ta = m.pair_type1[pp], mesh = m.pair_mesh[pp];
-        if (mesh != cur) { hull_lane_load(m, mesh, hull); cur = mesh; }
+        const HullRef hull = hull_ref(m, mesh);
         float Pa[3], RA[9], Sa[3], Pb[3], RB[9];
         for (int i = 0; i < 3; i++) { Pa[i] = w.gxpos[ga][i]; Pb[i] = w.gxpos[gb][i]; Sa[i] = m.pair_size1[pp][i]; }
         for (int i = 0; i < 9; i++) { RA[i] = w.gxmat[ga][i]; RB[i] = w.gxmat[gb][i]; }

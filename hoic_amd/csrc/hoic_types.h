@@ -30,7 +30,7 @@
 #define LD 33            // padded leading dimension of 32-wide LDS matrices (bank-conflict free)
 #define NHB HOIC_NHANDBODY
 #define NHG 19
-#define MAXMESHV 256
+#define MAXMESHV HOIC_MAX_MESHVERT
 #define MAXMESHP HOIC_MAX_MESHPLANE
 #define MAXROUND 3       // pointer-jumping rounds of the kinematics (tree depth <= 8)
 
@@ -73,8 +73,8 @@ struct DevModel {
   float pair_Rscale[NPAIR];  // R = max(MINVAL,(1-imp)/imp) * Rscale  (pyramidal: 2 mu^2 tran (1+mu^2); condim 1: tran)
   // convex meshes (hull vertices and face planes in the geom frame)
   int mesh_vertadr[HOIC_MAX_MESH], mesh_vertnum[HOIC_MAX_MESH], mesh_planeadr[HOIC_MAX_MESH], mesh_planenum[HOIC_MAX_MESH];
-  float mesh_vert[MAXMESHV][3];
-  float mesh_plane[MAXMESHP][4];   // hull faces n.x <= d in the geom frame
+  __attribute__((aligned(16))) float mesh_vert[MAXMESHV][4];    // hull vertices (x, y, z, 0), geom frame; float4 loads
+  __attribute__((aligned(16))) float mesh_plane[MAXMESHP][4];   // hull faces n.x <= d in the geom frame
 };
 
 struct DevConfig {

@@ -52,8 +52,8 @@ enum {
   HOIC_MAX_GEOM = 28,
   HOIC_MAX_PAIR = 128,
   HOIC_MAX_MESH = 4,
-  HOIC_MAX_MESHVERT = 256,
-  HOIC_MAX_MESHPLANE = 512,  /* hull face planes n.x <= d, mesh frame */
+  HOIC_MAX_MESHVERT = 2048,  /* all hull vertices of a model's meshes (banana: 231 + 707 + 939) */
+  HOIC_MAX_MESHPLANE = 4096, /* hull face planes n.x <= d, mesh frame */
   HOIC_OBS_DIM = 617,  /* get_full_obs_v5(w=5), uhc/envs/ho_im4.py:280-356 */
   HOIC_ACT_DIM = 32,   /* 26 PD targets + 3 residual force + 3 residual torque, ho_im4.py:145-156 */
   HOIC_NHANDBODY = 21, /* bodies named link*, ho_im4.py:77-78 */
