@@ -444,7 +444,7 @@ class AgentHandMimic:
         """The reference's batch (sample / sample_process, :430-535): every env is one sampler worker that collects WHOLE
         episodes until it holds ``thread_batch_size = floor(min_batch_size / n_envs)`` steps (:509, :437); a worker
         that has its quota idles (its env keeps being stepped by the launch, its rows are marked invalid).  Nothing is
-        bootstrapped: every episode in the batch ends with mask 0.  The observation filter sees every row of an active
+        bootstrapped: every episode in the batch ends with mask 0.  The observation filter sees every observation of every
         worker (the reference keeps only worker 0's updates)."""
         t0 = time.time()
         self.env.set_mode("train")
@@ -458,10 +458,9 @@ class AgentHandMimic:
         S, A, R, RI, FL, VA = [], [], [], [], [], []
         max_steps = quota + int(self.env.seq_len.max()) + sync_every + 1
         for t in range(max_steps):
-            rows = obs if t == 0 else obs[active]      # t == 0: everyone is active (no sync needed)
-            if rows.shape[0] > 0:
-                self.running_state.push(rows)
-            state = self.running_state(obs, update=False).to(dt)
+            # every env's observation updates the filter, idle workers' included (they keep running the same policy, so
+            # the statistics are those of the same state distribution; one fused launch instead of a gather + ~30 kernels)
+            state = self.running_state(obs).to(dt)
             action = self.policy_net.select_action(state)
             nseq, nstart = self._draw_episodes(N)
             self.env.step(action, nseq, nstart)

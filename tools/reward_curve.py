@@ -279,6 +279,7 @@ def run_cpu_arm(args, arm, seed):
                       "avg_episode_len": float(C.size / max(n_ep, 1)), "sample_s": t_sample})
         if it % 10 == 0:
             print(arm, seed, curve[-1], flush=True)
+            _dump_partial(args, {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "workers": W, "partial": True})
     for c in pipes:
         c.send(None)
     return {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "workers": W}
@@ -314,8 +315,16 @@ def run_hip_arm(args, arm, seed):
                       "sample_s": float(info["T_sample"])})
         if it % 10 == 0:
             print(arm, seed, curve[-1], flush=True)
+            _dump_partial(args, {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "envs": n_envs,
+                                 "sample_mode": mode, "partial": True})
     return {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "envs": n_envs,
             "sample_mode": mode}
+
+
+def _dump_partial(args, res):
+    """progress file next to the run's output: a run cut short by a time limit still leaves its curve behind"""
+    if args.run_one:
+        json.dump(res, open(args.run_one[2] + ".partial", "w"))
 
 
 # ----------------------------------------------------------------------------------------------- driver
@@ -324,14 +333,16 @@ def bands(runs):
     out = {}
     for arm in sorted({r["arm"] for r in runs}):
         rs = [r for r in runs if r["arm"] == arm]
-        its = [e["iter"] for e in rs[0]["eval"]]
+        nev = min(len(r["eval"]) for r in rs)          # runs cut short contribute the iterations they reached
+        its = [e["iter"] for e in rs[0]["eval"][:nev]]
         rows = []
         for k, it in enumerate(its):
             rp = np.array([r["eval"][k]["on_hip"]["reward_per_step"] for r in rs])
             pc = np.array([r["eval"][k]["on_hip"]["mean_percent"] for r in rs])
             rows.append({"iter": it, "reward_per_step_mean": float(rp.mean()), "reward_per_step_std": float(rp.std(ddof=1)) if len(rp) > 1 else 0.0,
                          "tracked_mean": float(pc.mean()), "tracked_std": float(pc.std(ddof=1)) if len(pc) > 1 else 0.0, "seeds": len(rs)})
-        cr = np.array([[c["avg_c_reward"] for c in r["curve"]] for r in rs])
+        ncv = min(len(r["curve"]) for r in rs)
+        cr = np.array([[c["avg_c_reward"] for c in r["curve"][:ncv]] for r in rs])
         out[arm] = {"eval": rows, "avg_c_reward_mean": cr.mean(0).tolist(), "avg_c_reward_std": (cr.std(0, ddof=1) if len(rs) > 1 else np.zeros(cr.shape[1])).tolist()}
     return out
 
@@ -349,6 +360,8 @@ def main():
     ap.add_argument("--episode-workers", type=int, default=64, help="n_envs of the hip_episodes arm (plays num_threads)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_reward_curve.json"))
     ap.add_argument("--run-one", nargs=3, metavar=("ARM", "SEED", "OUTFILE"), default=None)
+    ap.add_argument("--time-limit", type=float, default=0, help="seconds after which unfinished runs are stopped and their partial curves used")
+    ap.add_argument("--tmp", default=None, help="directory of the per-run result files (kept; default: a fresh temp dir)")
     args = ap.parse_args()
 
     if args.run_one:
@@ -358,7 +371,8 @@ def main():
         return
 
     arms = [a for a in args.arms.split(",") if a]
-    tmp = tempfile.mkdtemp(prefix="rcurve_")
+    tmp = args.tmp or tempfile.mkdtemp(prefix="rcurve_")
+    os.makedirs(tmp, exist_ok=True)
     jobs = []
     for arm in arms:
         ns = args.cpu_fixed_seeds if (arm == "cpu_fixed" and args.cpu_fixed_seeds is not None) else args.seeds
@@ -379,11 +393,17 @@ def main():
         procs.append((arm, seed, f, p))
     runs = []
     for arm, seed, f, p in procs:
-        p.wait()
-        if p.returncode != 0 or not os.path.exists(f):
+        try:
+            p.wait(timeout=max(1.0, args.time_limit - (time.time() - t0)) if args.time_limit > 0 else None)
+        except subprocess.TimeoutExpired:
+            p.kill(); p.wait()
+        if os.path.exists(f):
+            runs.append(json.load(open(f)))
+        elif os.path.exists(f + ".partial"):
+            print(f"run {arm} seed {seed} did not finish (exit {p.returncode}): using its partial curve", flush=True)
+            runs.append(json.load(open(f + ".partial")))
+        else:
             print(f"run {arm} seed {seed} failed (exit {p.returncode})", flush=True)
-            continue
-        runs.append(json.load(open(f)))
     out = {"what": "deterministic (mean-action) episodes from frame 0 of all 17 sequences on the HIP simulator, reward per step and "
                    "tracked fraction, every `eval_every` PPO iterations; avg_c_reward = LoggerRL.avg_c_reward of the collected "
                    "batch (without the end bonus); the same PPOLearner / schedule / synthetic motions in every arm",
