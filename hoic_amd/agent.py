@@ -152,8 +152,11 @@ class PPOLearner:
         if self.update_dtype == "f16x3" and states.is_cuda and states.dtype == torch.float32:
             from .mlp import PackedInput
             states = PackedInput(states)            # split once per iteration, shared by both networks and all epochs
+            # this forward pass is also the value network's first training pass (the weights do not change in between)
+            veng = self._split_engines()[0]
+            self._v_first = veng.forward(states)
             with torch.no_grad():
-                values = self.value_net.value_head(self._split_engines()[0].forward(states, need_grad=False))
+                values = self.value_net.value_head(self._v_first.detach())
         else:
             with torch.no_grad(), self._autocast():
                 values = self.value_net(states).float()
@@ -178,11 +181,12 @@ class PPOLearner:
         """optimize() with both MLP bodies on the f16x3 GEMMs: the bodies' forward returns the last hidden activation as
         a leaf, PyTorch runs head + loss + their backward, the bodies' backward fills the MLP gradients."""
         veng, peng = self._split_engines()
-        with torch.no_grad():
-            fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=peng.forward(inp, need_grad=False))
+        fixed_log_probs = None
+        v_first, self._v_first = getattr(self, "_v_first", None), None
         p_pending, p_waiting = None, False
-        for _ in range(self.opt_num_epochs):
-            h = veng.forward(inp)
+        for ep in range(self.opt_num_epochs):
+            # epoch 0 reuses the forward pass update_params made for the returns (same weights, same input)
+            h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
             value_loss = (self.value_net.value_head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
             self.optimizer_value.zero_grad(set_to_none=True)
             (value_loss * weight if weight != 1.0 else value_loss).backward()
@@ -191,6 +195,9 @@ class PPOLearner:
             if p_waiting:
                 policy_step(p_pending); p_waiting = False
             h = peng.forward(inp)
+            if fixed_log_probs is None:      # the old policy's log-probabilities are epoch 0's own (ratio = 1 there, agent_ppo.py:18-20)
+                with torch.no_grad():
+                    fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
             surr = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
             self.optimizer_policy.zero_grad(set_to_none=True)
             (surr * weight if weight != 1.0 else surr).backward()
@@ -205,14 +212,15 @@ class PPOLearner:
     def optimize(self, states, actions, advantages, returns, weight=1.0):
         """The 5 full-batch epochs of value and policy steps (agent_ppo.py:16-56) on flat [M, .] tensors.  ``weight``
         scales both losses (ranks with unequal sample counts, see update_params)."""
-        with torch.no_grad(), self._autocast():
-            fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
         vparams = list(self.value_net.parameters())
         pparams = [p for p in self.policy_net.parameters() if p.requires_grad]
         f16x3 = self.update_dtype == "f16x3" and actions.is_cuda and actions.dtype == torch.float32
         if f16x3 and torch.is_tensor(states):
             from .mlp import PackedInput
             states = PackedInput(states)
+        if not f16x3:
+            with torch.no_grad(), self._autocast():
+                fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
 
         def policy_step(pending):
             self._allreduce_finish(pending)

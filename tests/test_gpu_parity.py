@@ -116,7 +116,9 @@ def test_forward_dynamics_parity(obj, oracle_lib):
         worst["state"] = max(worst["state"], _rel(out["qpos_out"][i], e.get("qpos")[:33]), _rel(out["qvel_out"][i], e.get("qvel")))
     assert with_contacts > N // 3 and ncon_mismatch <= 2 and face_ties <= N // 12, (ncon_mismatch, face_ties)
     assert worst["kin"] < 2e-6 and worst["M"] < 2e-6 and worst["bias"] < 2e-6, worst
-    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < 6e-5, worst
+    # (mesh objects: hundreds of hull faces, so more selections sit within float32 rounding of a tie; the contact frame
+    #  then differs by up to the 2e-5 admitted above and the state after the substep follows it)
+    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < (6e-5 if obj == "box" else 2e-4), worst
 
 
 def test_box_box_contact_sets(box_blob, oracle_lib, setup):
@@ -213,7 +215,8 @@ def test_env_step_parity_short_horizon(obj, oracle_lib):
             if info["done"]:
                 alive[i] = False
     assert compared > N * 3
-    assert diverged <= max(2, compared // (20 if obj == "box" else 10)), (diverged, compared)
+    print(f"{obj}: {compared} env-steps compared, {diverged} envs diverged")
+    assert diverged <= max(2, compared // 20), (diverged, compared)
 
 
 def test_ragged_sequences_and_window_clamping(box_blob, oracle_lib, setup):
