@@ -10,10 +10,10 @@
 // 2^-24) at 16/3 of the f32 MFMA rate.  Power-of-two scales 2^e keep every tensor inside the f16 range and are undone
 // exactly in the epilogue.
 //
-// Storage format "H4L4": a packed tensor [R x C] is R rows of 2C halves; columns come in groups of four,
-// [h0 h1 h2 h3 l0 l1 l2 l3] (16 bytes).  A lane's MFMA fragment (8 consecutive k) is then two 16-byte reads whose
-// first / second halves are the hi / lo fragments, and an epilogue lane that owns 4 consecutive columns writes one
-// 16-byte group.
+// Storage format "H8L8": a packed tensor [R x C] is R rows of 2C halves; columns come in groups of eight,
+// [h0 .. h7 l0 .. l7] (32 bytes).  A lane's MFMA fragment (8 consecutive k) is then ONE 16-byte read for the hi halves
+// and one for the lo halves, straight into the operand registers; an epilogue lane that owns 4 consecutive columns
+// writes two 8-byte pieces.
 //
 // One GEMM kernel, "NT" form:  C[m][n] = alpha * sum_k A[m][k] B[n][k]  with A [M x K], B [N x K] packed, K contiguous.
 //   forward      A = activations [M x K_in],  B = W [N_out x K_in]            epilogue: + bias, GELU, GELU', pack
@@ -36,6 +36,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -72,7 +73,7 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // ---------------------------------------------------------------------------------------------- the GEMM kernel
 enum { EPI_F32 = 0, EPI_FWD = 1, EPI_BWD = 2 };
 struct GemmArgs {
-  const u16* A; const u16* B;     // packed H4L4: A [M x 2K] halves, B [N x 2K] halves
+  const u16* A; const u16* B;     // packed H8L8: A [M x 2K] halves, B [N x 2K] halves
   int M, N, K;                    // K = contraction length in elements (multiple of 32)
   int kt_per_split;               // K stages (of 32) handled by one block (split-K over blockIdx.y)
   const int* exps;                // device: scale exponents of the tensor slots
@@ -107,16 +108,14 @@ template <int ROWS> __device__ __forceinline__ void stage_rows(const char* g, si
     __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)row * rowbytes + c * 16), LDS_PTR(lds + (i * 8 + wave) * 1024), 16, 0, 0);
   }
 }
-// the two 16-byte groups holding k = 16 s + 8 hf ... + 7 of `row`
+// hi and lo halves of k = 16 s + 8 hf ... + 7 of `row`: group g = 2 s + hf of the row's four groups, chunks 2g and 2g + 1
 __device__ __forceinline__ void read_frag(const char* tile, int row, int s, int hf, h8& hi, h8& lo) {
-  const int sw = (row >> 1) & 7, b0 = 4 * s + 2 * hf;
-  const u32x4 c0 = *(const u32x4*)(tile + row * 128 + ((b0 ^ sw) << 4));
-  const u32x4 c1 = *(const u32x4*)(tile + row * 128 + (((b0 + 1) ^ sw) << 4));
-  const u32x4 h = {c0.x, c0.y, c1.x, c1.y}, l = {c0.z, c0.w, c1.z, c1.w};
-  hi = __builtin_bit_cast(h8, h); lo = __builtin_bit_cast(h8, l);
+  const int sw = (row >> 1) & 7, c = 2 * (2 * s + hf);
+  hi = *(const h8*)(tile + row * 128 + ((c ^ sw) << 4));
+  lo = *(const h8*)(tile + row * 128 + (((c + 1) ^ sw) << 4));
 }
 
-template <int BN, int EPI>
+template <int BN, int EPI, bool PIPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_kernel(GemmArgs a) {
   typedef Cfg<BN> C;
   __shared__ __attribute__((aligned(1024))) char smem[2 * C::STAGE];
@@ -148,37 +147,79 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  if (nkt > 0) {
-    stage_rows<256>(Ag, rowbytes, smem, wave, lane);
-    stage_rows<BN>(Bg, rowbytes, smem + 256 * 128, wave, lane);
-  }
-  for (int t = 0; t < nkt; t++) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wavefront's share of stage t has landed
-    __syncthreads();                         // ... everyone's has, and nobody still reads the other buffer
-    char* cur = smem + (t & 1) * C::STAGE;
-    if (t + 1 < nkt) {
-      char* nxt = smem + ((t + 1) & 1) * C::STAGE;
-      stage_rows<256>(Ag + (size_t)(t + 1) * 128, rowbytes, nxt, wave, lane);
-      stage_rows<BN>(Bg + (size_t)(t + 1) * 128, rowbytes, nxt + 256 * 128, wave, lane);
+  // fragments of one K16 substep: the weight-side (n) and activation-side (m) hi / lo halves
+  struct Frags { h8 ah[C::TM], al[C::TM], bh[C::TN], bl[C::TN]; };
+  auto load_frags = [&](const char* stg, int s_, Frags& f) {
+#pragma unroll
+    for (int j = 0; j < C::TN; j++) read_frag(stg + 256 * 128, nw + j * 32 + l31, s_, hf, f.bh[j], f.bl[j]);
+#pragma unroll
+    for (int i = 0; i < C::TM; i++) read_frag(stg, mw + i * 32 + l31, s_, hf, f.ah[i], f.al[i]);
+  };
+  // D[n][m]: the weight-side fragment is the MFMA's A operand, so a lane ends up with 4 consecutive n of one m
+  auto mma = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < C::TM; i++)
+#pragma unroll
+      for (int j = 0; j < C::TN; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+      }
+  };
+  auto stage = [&](int t_) {
+    char* dst = smem + (t_ & 1) * C::STAGE;
+    stage_rows<256>(Ag + (size_t)t_ * 128, rowbytes, dst, wave, lane);
+    stage_rows<BN>(Bg + (size_t)t_ * 128, rowbytes, dst + 256 * 128, wave, lane);
+  };
+  if (PIPE) {
+    // Software pipeline over the K16 substeps: while the matrix core works on one substep's fragments, the LDS reads of
+    // the next one are in flight (two fragment sets in registers), and the stage hand-over (wait for the LDS-DMA of
+    // stage t+1, barrier, issue the DMA of stage t+2 into the buffer just released) sits between the two MFMA groups of
+    // a stage instead of in front of both.
+    if (nkt > 0) {
+      stage(0);
+      __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0) lgkmcnt(0)
+      __syncthreads();
+      if (nkt > 1) stage(1);
+      Frags F0, F1;
+      load_frags(smem, 0, F0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0): F0 is in registers when the loop is entered
+      for (int t = 0; t + 1 < nkt; t++) {           // every stage but the last (peeled below: no branch inside the pipeline)
+        const char* cur = smem + (t & 1) * C::STAGE;
+        load_frags(cur, 1, F1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(F0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0): stage t+1 landed; F1 arrived, `cur` is read out
+        __syncthreads();
+        if (t + 2 < nkt) stage(t + 2);                                   // into `cur`, which nobody reads any more
+        load_frags(smem + ((t + 1) & 1) * C::STAGE, 0, F0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(F1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the next substep's fragments had 24 MFMAs to arrive: settle the counter here, so that the loop header knows F0 is
+        // ready and the reads of F1 issued there stay in flight under the MFMAs on F0
+        __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0)
+      }
+      load_frags(smem + ((nkt - 1) & 1) * C::STAGE, 1, F1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(F0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(F1);
     }
-    const char* At = cur;
-    const char* Bt = cur + 256 * 128;
+  } else {
+    if (nkt > 0) stage(0);
+    for (int t = 0; t < nkt; t++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's share of stage t has landed
+      __syncthreads();                                       // ... everyone's has, and nobody still reads the other buffer
+      if (t + 1 < nkt) stage(t + 1);
+      const char* cur = smem + (t & 1) * C::STAGE;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      h8 ah[C::TM], al[C::TM], bh[C::TN], bl[C::TN];
-#pragma unroll
-      for (int j = 0; j < C::TN; j++) read_frag(Bt, nw + j * 32 + l31, s, hf, bh[j], bl[j]);
-#pragma unroll
-      for (int i = 0; i < C::TM; i++) read_frag(At, mw + i * 32 + l31, s, hf, ah[i], al[i]);
-      // D[n][m]: the weight-side fragment is the MFMA's A operand, so a lane ends up with 4 consecutive n of one m
-#pragma unroll
-      for (int i = 0; i < C::TM; i++)
-#pragma unroll
-        for (int j = 0; j < C::TN; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-        }
+      for (int s_ = 0; s_ < 2; s_++) {
+        Frags f;
+        load_frags(cur, s_, f);
+        mma(f);
+      }
     }
   }
 
@@ -226,17 +267,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         unsigned w[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { vmax = fmaxf(vmax, fabsf(v[r])); w[r] = pack_hl(v[r] * so); }
-        if (a.P) {      // one 16-byte group [h0 h1 h2 h3 l0 l1 l2 l3]
-          const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
-          *(u32x4*)(a.P + ((size_t)m * a.N + n) * 2) = o;
+        if (a.P) {      // 4 of the 8 columns of a group: 8 bytes of hi halves, 8 bytes of lo halves 16 bytes further
+          u16* g8 = a.P + ((size_t)m * a.N + (n & ~7)) * 2 + (n & 4);
+          const u32x2 oh = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16)};
+          const u32x2 ol = {(w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+          *(u32x2*)g8 = oh; *(u32x2*)(g8 + 8) = ol;
         }
-        if (a.PT) {     // transposed: the group of (n, 4 consecutive m) is spread over a quad of lanes; lane q writes dword q
+        if (a.PT) {     // transposed: 4 consecutive m of a column n are spread over a quad of lanes; lane q writes one dword:
+                        // q = 0: (h0,h1)  1: (h2,h3)  2: (l0,l1)  3: (l2,l3) of the quad's half of the 8-group
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int wa = __builtin_amdgcn_update_dpp(0, (int)w[r], 0x88, 0xf, 0xf, false);   // quad_perm [0,2,0,2]
             const int wb = __builtin_amdgcn_update_dpp(0, (int)w[r], 0xdd, 0xf, 0xf, false);   // quad_perm [1,3,1,3]
             const unsigned o = __builtin_amdgcn_perm((unsigned)wb, (unsigned)wa, (lane & 2) ? 0x07060302u : 0x05040100u);
-            *(unsigned*)(a.PT + ((size_t)(n + r) * a.M + (m & ~3)) * 2 + (lane & 3) * 2) = o;
+            *(unsigned*)(a.PT + ((size_t)(n + r) * a.M + (m & ~7)) * 2 + ((lane & 2) ? 8 : 0) + (m & 4) + ((lane & 1) ? 2 : 0)) = o;
           }
         }
       }
@@ -247,6 +291,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------- pack kernels
+// four consecutive elements (hi | lo << 16 each) of an 8-group: dst = group base + (column & 4) halves
+__device__ __forceinline__ void store_quad(u16* dst, const unsigned (&w)[4]) {
+  const u32x2 oh = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16)};
+  const u32x2 ol = {(w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+  *(u32x2*)dst = oh; *(u32x2*)(dst + 8) = ol;
+}
 // float32 [R x C] (row stride ld) -> packed [Rp x 2 Cp] (zero padded), scaled by 2^exps[slot]; one thread per 4 columns
 __global__ void hoic_pack_rows_kernel(const float* __restrict__ x, int R, int Cc, long long ld, u16* __restrict__ P, int Rp, int Cp,
                                       const int* __restrict__ exps, int slot) {
@@ -258,8 +308,7 @@ __global__ void hoic_pack_rows_kernel(const float* __restrict__ x, int R, int Cc
   unsigned w[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) w[k] = pack_hl((r < R && c + k < Cc) ? x[(long long)r * ld + c + k] * s : 0.f);
-  const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
-  *(u32x4*)(P + ((long long)r * Cp + c) * 2) = o;
+  store_quad(P + ((long long)r * Cp + (c & ~7)) * 2 + (c & 4), w);
 }
 // float32 [R x C] -> packed TRANSPOSE [Cp x 2 Rp]; optional elementwise factor y [R x C] (dZ = dH * GELU'); 64 x 64
 // tiles through LDS.  grid (Cp / 64, Rp / 64), 256 threads.
@@ -280,8 +329,7 @@ __global__ __launch_bounds__(256) void hoic_pack_transpose_kernel(const float* _
     unsigned w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) w[q] = pack_hl(tile[gq + q][cc]);
-    const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
-    *(u32x4*)(PT + ((long long)(c0 + cc) * Rp + r0 + gq) * 2) = o;
+    store_quad(PT + ((long long)(c0 + cc) * Rp + ((r0 + gq) & ~7)) * 2 + ((r0 + gq) & 4), w);
   }
 }
 // dZ = dH * G (float32 [R x C], both row stride C) -> packed rows [Rp x 2C]; C multiple of 4
@@ -297,8 +345,7 @@ __global__ void hoic_pack_rows_mul_kernel(const float* __restrict__ x, const flo
   unsigned w[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) w[k] = pack_hl(v[k] * s);
-  const u32x4 o = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16), (w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
-  *(u32x4*)(P + ((long long)r * Cc + c) * 2) = o;
+  store_quad(P + ((long long)r * Cc + (c & ~7)) * 2 + (c & 4), w);
 }
 // max |x * y| (y optional) over a float32 array -> amax[slot] (atomicMax on the float bits; values are non-negative)
 __global__ void hoic_amax_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float* __restrict__ amax, int slot) {
@@ -341,10 +388,10 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
   const int r = blockIdx.x, tid = threadIdx.x;
   const u32x4* row = (const u32x4*)(P + (long long)r * Cp * 2);
   float s = 0.f;
-  for (int gq = tid; gq < (Cp >> 2); gq += 256) {
-    const u32x4 v = row[gq];
-    const h8 h = __builtin_bit_cast(h8, v);
-    s += ((float)h[0] + (float)h[4]) + ((float)h[1] + (float)h[5]) + ((float)h[2] + (float)h[6]) + ((float)h[3] + (float)h[7]);
+  for (int gq = tid; gq < (Cp >> 3); gq += 256) {      // one 8-group per trip: 16 bytes of hi halves + 16 bytes of lo halves
+    const h8 h = __builtin_bit_cast(h8, row[2 * gq]), l = __builtin_bit_cast(h8, row[2 * gq + 1]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += (float)h[k] + (float)l[k];
   }
   part[tid] = s;
   __syncthreads();
@@ -353,9 +400,13 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
 }
 
 // ---------------------------------------------------------------------------------------------- C-ABI
+static int g_gemm_pipeline = 1;      // 1: software-pipelined main loop (default), 0: the plain two-substep loop (A/B measurements)
+extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode ? 1 : 0; return HOIC_OK; }
+
 template <int BN, int EPI> static int32_t launch_gemm(const GemmArgs& a, int splits, hipStream_t st) {
   const int ntiles = (a.M / 256) * (a.N / BN);
-  hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI>), dim3(ntiles, splits), dim3(512), 0, st, a);
+  if (g_gemm_pipeline) hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI, true>), dim3(ntiles, splits), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI, false>), dim3(ntiles, splits), dim3(512), 0, st, a);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -388,7 +439,7 @@ extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, c
 
 extern "C" int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R, int32_t C, int64_t ld, void* d_P, void* d_PT, int32_t Rp,
                                  int32_t Cp, const int32_t* d_exps, int32_t slot, void* stream) {
-  if (!d_x || R <= 0 || C <= 0 || Rp < R || Cp < C || (Cp & 3) || (Rp & 3)) { hoic_set_error("hoic_mlp_pack: bad arguments (padded sizes must be multiples of 4)"); return HOIC_ERR_ARG; }
+  if (!d_x || R <= 0 || C <= 0 || Rp < R || Cp < C || (Cp & 7) || (Rp & 7)) { hoic_set_error("hoic_mlp_pack: bad arguments (padded sizes must be multiples of 8)"); return HOIC_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   if (d_P) {
     const long long n = (long long)Rp * (Cp >> 2);
@@ -432,7 +483,7 @@ extern "C" int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t
 }
 
 extern "C" int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot, void* stream) {
-  if (!d_P || !d_out || rows <= 0 || Cp <= 0 || (Cp & 3)) { hoic_set_error("hoic_mlp_rowsum_packed: bad arguments"); return HOIC_ERR_ARG; }
+  if (!d_P || !d_out || rows <= 0 || Cp <= 0 || (Cp & 7)) { hoic_set_error("hoic_mlp_rowsum_packed: bad arguments"); return HOIC_ERR_ARG; }
   hipLaunchKernelGGL(hoic_rowsum_packed_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const u16*)d_P, Cp, d_out, d_exps, slot);
   MCHK(hipGetLastError());
   return HOIC_OK;

@@ -34,23 +34,23 @@ def _rup(x, m):
 
 
 # ----------------------------------------------------------------------------- NumPy statement of the storage format
-def pack_h4l4_numpy(x, e=0):
-    """[R, C] float -> [R, 2C] float16 in the H4L4 layout (groups of 4 columns: 4 hi halves, then 4 lo halves);
-    C must be a multiple of 4.  Reference for the tests."""
+def pack_h8l8_numpy(x, e=0):
+    """[R, C] float -> [R, 2C] float16 in the H8L8 layout (groups of 8 columns: 8 hi halves, then 8 lo halves);
+    C must be a multiple of 8.  Reference for the tests."""
     y = np.asarray(x, dtype=np.float32) * np.float32(2.0 ** e)
     hi = y.astype(np.float16)
     lo = (y - hi.astype(np.float32)).astype(np.float16)
     R, Cc = y.shape
-    out = np.empty((R, Cc // 4, 8), np.float16)
-    out[:, :, :4] = hi.reshape(R, Cc // 4, 4); out[:, :, 4:] = lo.reshape(R, Cc // 4, 4)
+    out = np.empty((R, Cc // 8, 16), np.float16)
+    out[:, :, :8] = hi.reshape(R, Cc // 8, 8); out[:, :, 8:] = lo.reshape(R, Cc // 8, 8)
     return out.reshape(R, 2 * Cc)
 
 
-def unpack_h4l4_numpy(p, e=0):
+def unpack_h8l8_numpy(p, e=0):
     p = np.asarray(p, dtype=np.float16)
     R = p.shape[0]
-    g = p.reshape(R, -1, 8).astype(np.float64)
-    return ((g[:, :, :4] + g[:, :, 4:]).reshape(R, -1) * 2.0 ** (-e))
+    g = p.reshape(R, -1, 16).astype(np.float64)
+    return ((g[:, :, :8] + g[:, :, 8:]).reshape(R, -1) * 2.0 ** (-e))
 
 
 class _Kernels:
@@ -65,6 +65,7 @@ class _Kernels:
         L.hoic_mlp_update_exps.argtypes = [vp, vp, i32, C.c_uint64, i32, vp, vp]
         L.hoic_mlp_slab_reduce.argtypes = [vp, i32, i32, i32, vp, i32, i64, f32, vp]
         L.hoic_mlp_rowsum_packed.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+        L.hoic_mlp_set_pipeline.argtypes = [i32]
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed"):
             getattr(L, n).restype = i32
         self.L = L
@@ -72,6 +73,11 @@ class _Kernels:
     def chk(self, rc, what):
         if rc != 0:
             raise lib.HoicError(f"{what} failed ({rc}): {self.L.hoic_last_error().decode()}")
+
+
+def set_pipeline(on: bool):
+    """main loop of the GEMM kernel: software-pipelined (default) or the plain two-substep loop (A/B measurements)"""
+    kernels().L.hoic_mlp_set_pipeline(int(bool(on)))
 
 
 _K = None
@@ -117,7 +123,7 @@ def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
     Rp = R if Rp is None else Rp
-    Cp = _rup(Cc, 4) if Cp is None else Cp
+    Cp = _rup(Cc, 8) if Cp is None else Cp
     dev = x.device
     K = kernels()
     if measure:

@@ -169,8 +169,8 @@ int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64
 /* ---- the dense GEMMs of the PPO update (AgentPPO.update_policy / AgentPG.update_value: forward + backward of the two
  * GELU MLPs, uhc/khrylib/rl/agents/agent_ppo.py:16-56, agent_pg.py:18-25, models/mlp.py:24-27) at float32 accuracy on
  * the f16 matrix cores; no handle needed.  Operands are "packed" tensors: a float32 matrix [R x C] scaled by a power of
- * two 2^e and split error-free into float16 pairs x 2^e = hi + lo, stored as R rows of 2 C halves in groups of four
- * columns [h0 h1 h2 h3 l0 l1 l2 l3].  Per-tensor exponents live in a device int32 table d_exps (slot indices are
+ * two 2^e and split error-free into float16 pairs x 2^e = hi + lo, stored as R rows of 2 C halves in groups of eight
+ * columns [h0 .. h7 l0 .. l7].  Per-tensor exponents live in a device int32 table d_exps (slot indices are
  * arguments), running maxima in d_amax (float32 per slot).
  *
  * hoic_mlp_pack: float32 d_x [R x C] (row stride ld; optional elementwise factor d_mul of the same layout) -> d_P
@@ -193,6 +193,7 @@ int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uin
 int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps,
                       float* d_amax, int32_t slot_a, int32_t slot_b, int32_t slot_out, float extra_scale, int32_t splits, float* d_C,
                       const float* d_bias, const float* d_gin, float* d_gout, float* d_hf32, void* d_P, void* d_PT, void* stream);
+int32_t hoic_mlp_set_pipeline(int32_t mode);   /* 1 (default): software-pipelined main loop; 0: plain loop (measurement aid) */
 int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
                              float scale, void* stream);
 int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot,

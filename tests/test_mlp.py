@@ -14,15 +14,15 @@ from hoic_amd import mlp as M
 
 
 def test_h4l4_format_roundtrip_numpy():
-    """The storage format, stated in NumPy: error-free split into two halves, groups of 4 columns [h h h h l l l l]."""
+    """The storage format, stated in NumPy: error-free split into two halves, groups of 8 columns [h x 8, l x 8]."""
     rng = np.random.default_rng(0)
     x = (rng.normal(size=(6, 16)) * np.exp(rng.normal(size=(6, 16)) * 2)).astype(np.float32)
-    p = M.pack_h4l4_numpy(x, e=3)
+    p = M.pack_h8l8_numpy(x, e=3)
     assert p.shape == (6, 32) and p.dtype == np.float16
-    back = M.unpack_h4l4_numpy(p, e=3)
+    back = M.unpack_h8l8_numpy(p, e=3)
     assert np.abs(back - x).max() <= 2.0 ** -21 * np.abs(x).max()
-    g = p.reshape(6, 4, 8)
-    np.testing.assert_array_equal(g[:, :, :4].reshape(6, 16), (x * 8).astype(np.float16))
+    g = p.reshape(6, 2, 16)
+    np.testing.assert_array_equal(g[:, :, :8].reshape(6, 16), (x * 8).astype(np.float16))
 
 
 gpu = pytest.mark.gpu
@@ -39,16 +39,16 @@ def test_pack_kernels_match_the_numpy_format():
     amax = float(x.abs().max())
     assert 2.0 ** (M.TARGET_LOG2 - 1) <= amax * 2.0 ** e < 2.0 ** M.TARGET_LOG2
     xp = np.zeros((320, 640), np.float32); xp[:300, :617] = x.cpu().numpy()
-    np.testing.assert_array_equal(P.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(xp, e).view(np.uint16))
-    np.testing.assert_array_equal(PT.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(xp.T.copy(), e).view(np.uint16))
+    np.testing.assert_array_equal(P.cpu().numpy().view(np.uint16), M.pack_h8l8_numpy(xp, e).view(np.uint16))
+    np.testing.assert_array_equal(PT.cpu().numpy().view(np.uint16), M.pack_h8l8_numpy(xp.T.copy(), e).view(np.uint16))
     # product form (dZ = dH * G)
     y = torch.rand(256, 512, device=dev, generator=g)
     z = torch.randn(256, 512, device=dev, generator=g) * 1e-5
     P2, PT2 = M.pack(z, t, 3, Rp=256, Cp=512, rows=True, transposed=True, mul=y)
     e3 = int(t.exps[3])
     ref = (z * y).cpu().numpy()
-    np.testing.assert_array_equal(P2.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(ref, e3).view(np.uint16))
-    np.testing.assert_array_equal(PT2.cpu().numpy().view(np.uint16), M.pack_h4l4_numpy(ref.T.copy(), e3).view(np.uint16))
+    np.testing.assert_array_equal(P2.cpu().numpy().view(np.uint16), M.pack_h8l8_numpy(ref, e3).view(np.uint16))
+    np.testing.assert_array_equal(PT2.cpu().numpy().view(np.uint16), M.pack_h8l8_numpy(ref.T.copy(), e3).view(np.uint16))
     assert int(t.overflow) == 0
 
 

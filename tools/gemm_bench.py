@@ -37,15 +37,17 @@ def main():
     ap.add_argument("--splits", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-update", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, help="0: plain main loop, 1: software-pipelined (default)")
     args = ap.parse_args()
     import torch
     from hoic_amd import mlp as M
     dev = torch.device("cuda")
+    M.set_pipeline(args.pipeline)
     Mr = args.rows
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
     t = M.ScaleTable(dev)
-    res = {"rows": Mr, "gemms": []}
+    res = {"rows": Mr, "pipeline": args.pipeline, "gemms": []}
     dims = [(640, 2048), (2048, 1024), (1024, 512)]
 
     def pk(x, slot, Rp, Cp, **kw):
