@@ -425,13 +425,15 @@ def test_config_switches(box_blob, oracle_lib, setup):
             assert abs(float(sim.rfc_score()[i]) - info["rfc_score"]) < 1e-3 * (1 + info["rfc_score"])
 
 
-def test_full_size_properties(box_blob, setup):
-    """4096 envs (BASELINE.json config 1): determinism, finiteness, reset idempotence, auto-reset bookkeeping."""
-    cfg, ex, thresh = setup
+@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
+def test_full_size_properties(obj):
+    """4096 envs of each object config (BASELINE.json configs 1-3): determinism, finiteness, reset idempotence,
+    auto-reset bookkeeping, and no contact-list overflow; starts spread over the approach and the grasp phase."""
+    box_blob, cfg, ex, thresh = _obj_setup(obj)
     N = 4096
     g = torch.Generator().manual_seed(0)
     seqs = torch.randint(0, 3, (N,), generator=g, dtype=torch.int32)
-    starts = torch.randint(0, 200, (N,), generator=g, dtype=torch.int32)
+    starts = torch.randint(0, 300, (N,), generator=g, dtype=torch.int32)
     acts = [(torch.rand(N, 32, generator=g) * 2 - 1) * 0.2 for _ in range(3)]
     nseq = torch.randint(0, 3, (N,), generator=g, dtype=torch.int32); nstart = torch.randint(0, 200, (N,), generator=g, dtype=torch.int32)
 
@@ -443,6 +445,8 @@ def test_full_size_properties(box_blob, setup):
             o, r, ri, fl, pc = sim.step(a, nseq, nstart)
             outs.append((o.clone(), r.clone(), fl.clone()))
         qpos, qvel, cur_t = sim.get_state()
+        d = sim.diagnostics()
+        assert d["contact_overflow"] == 0, d
         return o0, outs, qpos.clone(), qvel.clone(), cur_t.clone()
     a = run(); b = run()
     assert torch.equal(a[0], b[0])

@@ -71,6 +71,7 @@ def worker_main(conn, wid, obj, seed, shared, n_fixed_envs):
     rng = np.random.default_rng(100000 * seed + 1000 + wid)
     torch.manual_seed(100000 * seed + 1000 + wid)
     env = new_env()
+    slot_envs = [env]
     fixed = None                                          # cpu_fixed: persistent envs + their current observations
 
     def draw():
@@ -83,28 +84,41 @@ def worker_main(conn, wid, obj, seed, shared, n_fixed_envs):
             break
         kind = msg[0]
         if kind == "episodes":
-            _, epoch, mean, std, n_steps, end_reward = msg
+            # sample_process (:430-501): whole episodes until the quota is reached.  `slots` > 1 runs that many independent
+            # sampler threads of the reference inside this process in lockstep (each slot has its own env and its own share of
+            # the quota, so the batch is the one `workers x slots` reference threads would collect) and batches their policy
+            # forwards: the batch-1 forward is 2/3 of a CPU env-step
+            _, epoch, mean, std, n_steps, end_reward, slots = msg
             cfg.update_adaptive_params(epoch)
             wk = cfg.reward_wk()
-            S, A, R, C, M, RAW = [], [], [], [], [], []
+            while len(slot_envs) < slots:
+                slot_envs.append(new_env())
+            data = [dict(S=[], A=[], R=[], C=[], M=[], RAW=[]) for _ in range(slots)]
+            obs = [None] * slots
+            for k in range(slots):
+                seq, start = draw(); slot_envs[k].set_expert(ex[seq]); obs[k] = slot_envs[k].reset(start)
+            active = list(range(slots))
             with torch.no_grad():
-                while len(R) < n_steps:
-                    seq, start = draw()
-                    env.set_expert(ex[seq])
-                    obs = env.reset(start)
-                    for _ in range(10000):
-                        st = np.clip((obs - mean) / (std + 1e-8), -5.0, 5.0)
-                        a = policy.select_action(torch.as_tensor(st[None], dtype=torch.float32))[0].numpy().astype(np.float64)
-                        nobs, info = env.step(a)
-                        c, _ = env.reward(wk)
+                while active:
+                    ob = np.stack([obs[k] for k in active])
+                    st = np.clip((ob - mean) / (std + 1e-8), -5.0, 5.0)
+                    act = policy.select_action(torch.as_tensor(st, dtype=torch.float32)).numpy().astype(np.float64)
+                    still = []
+                    for j, k in enumerate(active):
+                        e = slot_envs[k]; d = data[k]
+                        nobs, info = e.step(act[j])
+                        c, _ = e.reward(wk)
                         r = c + end_reward if (end_reward and info["end"]) else c             # (:479-480)
-                        S.append(st.astype(np.float32)); A.append(a.astype(np.float32)); R.append(r); C.append(c)
-                        RAW.append(obs.astype(np.float32)); M.append(0.0 if info["done"] else 1.0)
-                        obs = nobs
+                        d["S"].append(st[j].astype(np.float32)); d["A"].append(act[j].astype(np.float32)); d["R"].append(r); d["C"].append(c)
+                        d["RAW"].append(ob[j].astype(np.float32)); d["M"].append(0.0 if info["done"] else 1.0)
                         if info["done"]:
-                            break
-            conn.send((np.array(S), np.array(A), np.array(R, np.float32), np.array(C, np.float32), np.array(M, np.float32),
-                       np.array(RAW)))
+                            if len(d["R"]) >= n_steps:
+                                continue                                                     # this thread has its quota (:437)
+                            seq, start = draw(); e.set_expert(ex[seq]); nobs = e.reset(start)
+                        obs[k] = nobs; still.append(k)
+                    active = still
+            cat = lambda key, dt: np.concatenate([np.asarray(d[key], dtype=dt).reshape(len(d[key]), -1) for d in data]).squeeze()
+            conn.send((cat("S", np.float32), cat("A", np.float32), cat("R", np.float32), cat("C", np.float32), cat("M", np.float32), cat("RAW", np.float32)))
         elif kind == "fixed":
             _, epoch, mean, std, T, end_reward = msg
             cfg.update_adaptive_params(epoch)
@@ -226,7 +240,7 @@ def run_cpu_arm(args, arm, seed):
 
     curve, evals, end_reward = [], [], 0.0
     T_fixed = int(math.ceil(cfg.min_batch_size / max(n_fixed * W, 1))) if arm == "cpu_fixed" else 0
-    per_worker = int(math.floor(cfg.min_batch_size / W))                   # thread_batch_size (:509)
+    per_worker = int(math.floor(cfg.min_batch_size / (W * args.slots)))    # thread_batch_size (:509) of each sampler thread
     t_start = time.time()
     for it in range(args.iters + 1):
         cfg.update_adaptive_params(min(it, args.iters - 1))
@@ -246,7 +260,7 @@ def run_cpu_arm(args, arm, seed):
         t0 = time.time()
         if arm == "cpu_episodes":
             for c in pipes:
-                c.send(("episodes", it, mean, std, per_worker, end_reward))
+                c.send(("episodes", it, mean, std, per_worker, end_reward, args.slots))
             parts = [c.recv() for c in pipes]
             t_sample = time.time() - t0
             S, A, R, C, M, RAW = [np.concatenate([p[i] for p in parts]) for i in range(6)]
@@ -282,7 +296,7 @@ def run_cpu_arm(args, arm, seed):
             _dump_partial(args, {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "workers": W, "partial": True})
     for c in pipes:
         c.send(None)
-    return {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "workers": W}
+    return {"arm": arm, "seed": seed, "curve": curve, "eval": evals, "wall_s": time.time() - t_start, "workers": W, "slots": args.slots}
 
 
 def run_hip_arm(args, arm, seed):
@@ -355,6 +369,7 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--eval-every", type=int, default=5)
     ap.add_argument("--workers", type=int, default=32, help="sampler processes per CPU run (the reference's --num_threads)")
+    ap.add_argument("--slots", type=int, default=1, help="cpu_episodes: reference sampler threads per worker process, stepped in lockstep with one batched policy forward")
     ap.add_argument("--obj", default="box")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--episode-workers", type=int, default=64, help="n_envs of the hip_episodes arm (plays num_threads)")
@@ -380,7 +395,7 @@ def main():
     # every run is its own process (its own HIP context); CPU runs and whole-episode HIP runs are latency-bound and run
     # side by side, the fixed-horizon HIP runs fill the GPU and go one after the other
     common = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--eval-every", str(args.eval_every),
-              "--workers", str(args.workers), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
+              "--workers", str(args.workers), "--slots", str(args.slots), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
     t0 = time.time()
     side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes")], [j for j in jobs if j[0] in ("hip_fixed", "hip_fixed_long")]
     procs = []

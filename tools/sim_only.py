@@ -1,7 +1,7 @@
 """Run only the two step kernels (hoic_substep_kernel, hoic_poststep_kernel) (no policy / update): development aid for rocprofv3 --kernel-trace / --pmc passes.
 usage: python3 tools/sim_only.py [n_envs] [steps] [obj]"""
 import sys, os
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from hoic_amd import lib, mjcf, motions

@@ -1,8 +1,8 @@
 """Run only PPOLearner.update_params (GAE + 5 epochs of value and policy steps on 53248 synthetic samples): development aid
 for rocprofv3 --kernel-trace --stats passes over the update's kernels.
 usage: python3 tools/update_only.py [f16x3|f32|bf16] [reps] [rows]"""
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
 import torch
 from hoic_amd import tuning
