@@ -115,6 +115,77 @@ __device__ __forceinline__ void read_frag(const char* tile, int row, int s, int 
   lo = *(const h8*)(tile + row * 128 + (((c + 1) ^ sw) << 4));
 }
 
+// ---------------------------------------------------------------------------------------------- epilogue
+// acc[i][j][reg] of a wavefront whose tile starts at (mb, nb): m = mb + 32 i + (lane & 31),
+// n = nb + 32 j + 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3): every lane owns runs of 4 consecutive n of one m
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][TN], int mb, int nb, int split, int lane) {
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
+  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
+  if (EPI == EPI_F32) {
+    float* Cp = a.C + (size_t)split * a.c_split_stride;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int m = mb + 32 * i + l31, n = nb + 32 * j + 8 * rg + 4 * hf;
+          f32x4 v = {alpha * acc[i][j][4 * rg], alpha * acc[i][j][4 * rg + 1], alpha * acc[i][j][4 * rg + 2], alpha * acc[i][j][4 * rg + 3]};
+          *(f32x4*)(Cp + (size_t)m * a.N + n) = v;
+        }
+    return;
+  }
+  const int eo = a.exps ? a.exps[a.eo] : 0;
+  const float so = ldexpf(1.f, eo);
+  float vmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int m = mb + 32 * i + l31, n = nb + 32 * j + 8 * rg + 4 * hf;
+        float v[4];
+        if (EPI == EPI_FWD) {
+          const f32x4 b4 = *(const f32x4*)(a.bias + n);
+          f32x4 dg4;
+#pragma unroll
+          for (int r = 0; r < 4; r++) { float gq, dq; gelu_pair(fmaf(alpha, acc[i][j][4 * rg + r], b4[r]), gq, dq); v[r] = gq; dg4[r] = dq; }
+          if (a.Gout) *(f32x4*)(a.Gout + (size_t)m * a.N + n) = dg4;
+        } else {
+          const f32x4 g4 = *(const f32x4*)(a.Gin + (size_t)m * a.N + n);
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][4 * rg + r] * g4[r];
+        }
+        if (a.Hf32) { const f32x4 o = {v[0], v[1], v[2], v[3]}; *(f32x4*)(a.Hf32 + (size_t)m * a.N + n) = o; }
+        unsigned w[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { vmax = fmaxf(vmax, fabsf(v[r])); w[r] = pack_hl(v[r] * so); }
+        if (a.P) {      // 4 of the 8 columns of a group: 8 bytes of hi halves, 8 bytes of lo halves 16 bytes further
+          u16* g8 = a.P + ((size_t)m * a.N + (n & ~7)) * 2 + (n & 4);
+          const u32x2 oh = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16)};
+          const u32x2 ol = {(w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
+          *(u32x2*)g8 = oh; *(u32x2*)(g8 + 8) = ol;
+        }
+        if (a.PT) {     // transposed: 4 consecutive m of a column n are spread over a quad of lanes; lane q writes one dword:
+                        // q = 0: (h0,h1)  1: (h2,h3)  2: (l0,l1)  3: (l2,l3) of the quad's half of the 8-group
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int wa = __builtin_amdgcn_update_dpp(0, (int)w[r], 0x88, 0xf, 0xf, false);   // quad_perm [0,2,0,2]
+            const int wb = __builtin_amdgcn_update_dpp(0, (int)w[r], 0xdd, 0xf, 0xf, false);   // quad_perm [1,3,1,3]
+            const unsigned o = __builtin_amdgcn_perm((unsigned)wb, (unsigned)wa, (lane & 2) ? 0x07060302u : 0x05040100u);
+            *(unsigned*)(a.PT + ((size_t)(n + r) * a.M + (m & ~7)) * 2 + ((lane & 2) ? 8 : 0) + (m & 4) + ((lane & 1) ? 2 : 0)) = o;
+          }
+        }
+      }
+  if (a.amax) {
+    vmax = wave_max_f(vmax);
+    if (lane == 0) atomicMax((unsigned*)(a.amax + a.eo), __float_as_uint(vmax));
+  }
+}
+
 template <int BN, int EPI, bool PIPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_kernel(GemmArgs a) {
   typedef Cfg<BN> C;
@@ -223,71 +294,112 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
-  // ------------------------------------------------------------------------------------------ epilogue
-  // acc[i][j][reg]: m = m0 + mw + 32 i + (lane & 31), n = n0 + nw + 32 j + 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3)
-  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
-  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
-  if (EPI == EPI_F32) {
-    float* Cp = a.C + (size_t)split * a.c_split_stride;
+  gemm_epilogue<EPI, C::TM, C::TN>(a, acc, m0 + mw, n0 + nw, split, lane);
+}
+
+// ---------------------------------------------------------------------------------------------- second tiling
+// 4 wavefronts, tile 256 x 128 (wavefront tile 128 x 64 as above), K stages of 16, THREE LDS buffers of 24 KB: two
+// workgroups fit on a CU (2 x 72 KB LDS, one wavefront of each per SIMD).  While one workgroup sits in its epilogue
+// (HBM-write bound: packed output, its transpose and GELU' are 12 bytes per element) or at a barrier, the other one
+// keeps the matrix cores busy; with one 8-wavefront workgroup per CU nothing overlaps the epilogue.
+// Pipeline per stage t: [wait for the LDS-DMA of stage t+1 with a COUNTED vmcnt (stage t+2's may stay in flight), raw
+// s_barrier] -> issue the DMA of stage t+3 into the buffer stage t was read from -> LDS reads of stage t+1's fragments
+// -> 24 MFMAs on stage t's fragments (already in registers).
+#define K16_STG ((256 + 128) * 64)
+template <int ROWS> __device__ __forceinline__ void stage_rows16(const char* g, size_t rowbytes, char* lds, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < C::TM; i++)
-#pragma unroll
-      for (int j = 0; j < C::TN; j++)
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int m = m0 + mw + 32 * i + l31, n = n0 + nw + 32 * j + 8 * rg + 4 * hf;
-          f32x4 v = {alpha * acc[i][j][4 * rg], alpha * acc[i][j][4 * rg + 1], alpha * acc[i][j][4 * rg + 2], alpha * acc[i][j][4 * rg + 3]};
-          *(f32x4*)(Cp + (size_t)m * a.N + n) = v;
-        }
-    return;
+  for (int i = 0; i < ROWS / 64; i++) {      // 64-byte rows (16 elements): chunk q belongs to row q >> 2, source chunk (q & 3) ^ ((row >> 2) & 3)
+    const int q = (i * 4 + wave) * 64 + lane, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)row * rowbytes + c * 16), LDS_PTR(lds + (i * 4 + wave) * 1024), 16, 0, 0);
   }
-  const int eo = a.exps ? a.exps[a.eo] : 0;
-  const float so = ldexpf(1.f, eo);
-  float vmax = 0.f;
+}
+__device__ __forceinline__ void read_frag16(const char* tile, int row, int hf, h8& hi, h8& lo) {
+  const int sw = (row >> 2) & 3;
+  hi = *(const h8*)(tile + row * 64 + (((2 * hf) ^ sw) << 4));
+  lo = *(const h8*)(tile + row * 64 + (((2 * hf + 1) ^ sw) << 4));
+}
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_k16_kernel(GemmArgs a) {
+  constexpr int TM = 4, TN = 2;
+  __shared__ __attribute__((aligned(1024))) char smem[3 * K16_STG];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int ntn = a.N / 128, ntiles = (a.M / 256) * ntn;
+  int g = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = g & 7, idx = g >> 3;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (g / ntn) * 256, n0 = (g % ntn) * 128;
+  const int split = blockIdx.y;
+  const int kt0 = split * a.kt_per_split * 2;                       // kt_per_split counts stages of 32
+  const int nkt = min(a.kt_per_split * 2, a.K / 16 - kt0);
+  const size_t rowbytes = (size_t)a.K * 4;
+  const char* Ag = (const char*)a.A + (size_t)m0 * rowbytes + (size_t)kt0 * 64;
+  const char* Bg = (const char*)a.B + (size_t)n0 * rowbytes + (size_t)kt0 * 64;
+  const int mw = (wave >> 1) * 128, nw = (wave & 1) * 64;
+
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < C::TM; i++)
+  for (int i = 0; i < TM; i++)
 #pragma unroll
-    for (int j = 0; j < C::TN; j++)
+    for (int j = 0; j < TN; j++)
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int m = m0 + mw + 32 * i + l31, n = n0 + nw + 32 * j + 8 * rg + 4 * hf;
-        float v[4];
-        if (EPI == EPI_FWD) {
-          const f32x4 b4 = *(const f32x4*)(a.bias + n);
-          f32x4 dg4;
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  struct Frags { h8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto load_frags = [&](int t_, Frags& f) {
+    const char* stg = smem + (t_ % 3) * K16_STG;
 #pragma unroll
-          for (int r = 0; r < 4; r++) { float gq, dq; gelu_pair(fmaf(alpha, acc[i][j][4 * rg + r], b4[r]), gq, dq); v[r] = gq; dg4[r] = dq; }
-          if (a.Gout) *(f32x4*)(a.Gout + (size_t)m * a.N + n) = dg4;
-        } else {
-          const f32x4 g4 = *(const f32x4*)(a.Gin + (size_t)m * a.N + n);
+    for (int j = 0; j < TN; j++) read_frag16(stg + 256 * 64, nw + j * 32 + l31, hf, f.bh[j], f.bl[j]);
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][4 * rg + r] * g4[r];
-        }
-        if (a.Hf32) { const f32x4 o = {v[0], v[1], v[2], v[3]}; *(f32x4*)(a.Hf32 + (size_t)m * a.N + n) = o; }
-        unsigned w[4];
+    for (int i = 0; i < TM; i++) read_frag16(stg, mw + i * 32 + l31, hf, f.ah[i], f.al[i]);
+  };
+  auto mma = [&](const Frags& f) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) { vmax = fmaxf(vmax, fabsf(v[r])); w[r] = pack_hl(v[r] * so); }
-        if (a.P) {      // 4 of the 8 columns of a group: 8 bytes of hi halves, 8 bytes of lo halves 16 bytes further
-          u16* g8 = a.P + ((size_t)m * a.N + (n & ~7)) * 2 + (n & 4);
-          const u32x2 oh = {(w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16)};
-          const u32x2 ol = {(w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u)};
-          *(u32x2*)g8 = oh; *(u32x2*)(g8 + 8) = ol;
-        }
-        if (a.PT) {     // transposed: 4 consecutive m of a column n are spread over a quad of lanes; lane q writes one dword:
-                        // q = 0: (h0,h1)  1: (h2,h3)  2: (l0,l1)  3: (l2,l3) of the quad's half of the 8-group
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int wa = __builtin_amdgcn_update_dpp(0, (int)w[r], 0x88, 0xf, 0xf, false);   // quad_perm [0,2,0,2]
-            const int wb = __builtin_amdgcn_update_dpp(0, (int)w[r], 0xdd, 0xf, 0xf, false);   // quad_perm [1,3,1,3]
-            const unsigned o = __builtin_amdgcn_perm((unsigned)wb, (unsigned)wa, (lane & 2) ? 0x07060302u : 0x05040100u);
-            *(unsigned*)(a.PT + ((size_t)(n + r) * a.M + (m & ~7)) * 2 + ((lane & 2) ? 8 : 0) + (m & 4) + ((lane & 1) ? 2 : 0)) = o;
-          }
-        }
+      for (int j = 0; j < TN; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
       }
-  if (a.amax) {
-    vmax = wave_max_f(vmax);
-    if (lane == 0) atomicMax((unsigned*)(a.amax + a.eo), __float_as_uint(vmax));
+  };
+  auto stage = [&](int t_) {
+    char* dst = smem + (t_ % 3) * K16_STG;
+    stage_rows16<256>(Ag + (size_t)t_ * 64, rowbytes, dst, wave, lane);          // 4 DMA pieces per lane
+    stage_rows16<128>(Bg + (size_t)t_ * 64, rowbytes, dst + 256 * 64, wave, lane);   // 2
+  };
+  if (nkt > 0) {
+    stage(0);
+    if (nkt > 1) stage(1);
+    if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0076); else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(6) / vmcnt(0): stage 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (nkt > 2) stage(2);
+    Frags F[2];
+    load_frags(0, F[0]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0)
+    int t = 0;
+    // two stages per trip so that the two fragment sets are addressed statically
+#define K16_STEP(CUR, NXT)                                                                                              \
+    {                                                                                                                   \
+      if (t + 1 < nkt) {                                                                                                \
+        if (t + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0076); else __builtin_amdgcn_s_waitcnt(0x0070);                  \
+        __builtin_amdgcn_s_barrier();        /* stage t+1 landed everywhere; buffer t % 3 is read out */                \
+        if (t + 3 < nkt) stage(t + 3);       /* into buffer (t + 3) % 3 == t % 3 */                                      \
+        load_frags(t + 1, F[NXT]);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+      }                                                                                                                 \
+      mma(F[CUR]);                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                                \
+      __builtin_amdgcn_s_waitcnt(0xc07f);    /* lgkmcnt(0): the next fragments arrived under the MFMAs */               \
+      t++;                                                                                                              \
+    }
+    while (t < nkt) {
+      K16_STEP(0, 1)
+      if (t < nkt) K16_STEP(1, 0)
+    }
+#undef K16_STEP
   }
+  gemm_epilogue<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, split, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- pack kernels
@@ -400,11 +512,18 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
 }
 
 // ---------------------------------------------------------------------------------------------- C-ABI
-static int g_gemm_pipeline = 1;      // 1: software-pipelined main loop (default), 0: the plain two-substep loop (A/B measurements)
-extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode ? 1 : 0; return HOIC_OK; }
+// 0: plain two-substep loop, 1: software-pipelined 8-wavefront kernel (256 x 256 | 128 tiles, one workgroup per CU),
+// 2: the 4-wavefront 256 x 128 K16 kernel, two workgroups per CU (measurement aid; the default is the fastest measured)
+static int g_gemm_pipeline = 2;
+extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return HOIC_OK; }
 
 template <int BN, int EPI> static int32_t launch_gemm(const GemmArgs& a, int splits, hipStream_t st) {
   const int ntiles = (a.M / 256) * (a.N / BN);
+  if (g_gemm_pipeline == 2) {
+    hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
+    MCHK(hipGetLastError());
+    return HOIC_OK;
+  }
   if (g_gemm_pipeline) hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI, true>), dim3(ntiles, splits), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI, false>), dim3(ntiles, splits), dim3(512), 0, st, a);
   MCHK(hipGetLastError());

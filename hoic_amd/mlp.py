@@ -170,10 +170,26 @@ class PackedInput:
         self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=True)
 
 
+def pick_splits(tiles, nkt, n_cu=256, max_splits=64):
+    """split-K factor of a weight-gradient GEMM: `tiles` output tiles x splits workgroups should fill whole rounds of the
+    256 CUs (one 128 KB-LDS workgroup per CU), every split should get the same number of K stages, and more splits mean
+    more slab traffic.  Smallest waste first, then the fewest splits."""
+    best = None
+    for s_ in range(1, max_splits + 1):
+        if nkt % s_:
+            continue
+        blocks = tiles * s_
+        waste = (-(-blocks // n_cu) * n_cu) / blocks - 1.0
+        key = (round(waste + 0.004 * s_, 4), s_)          # a percent of idle CUs outweighs a few more slabs
+        if best is None or key < best[0]:
+            best = (key, s_)
+    return best[1]
+
+
 class SplitMLP:
     SLOT_X, SLOT_W0, SLOT_H0, SLOT_DZ0 = 0, 1, 4, 8        # W: 1..3, H (hidden activations): 4..6, dZ: 8..10
 
-    def __init__(self, mlp, wgrad_splits=16):
+    def __init__(self, mlp, wgrad_splits=None):
         from .rl import MLP
         assert isinstance(mlp, MLP) and isinstance(mlp.activation, torch.nn.GELU), "SplitMLP needs a GELU rl.MLP"
         self.layers = list(mlp.affine_layers)
@@ -204,8 +220,10 @@ class SplitMLP:
         self.Hlast = torch.empty(Mp, self.dims_out[-1], dtype=torch.float32, device=dev)
         self.dZp = [None] + [h(Mp, n) for n in self.dims_out[1:]]          # rows: operand of the data-gradient GEMM (layers >= 1)
         self.dZpT = [h(n, Mp) for n in self.dims_out]
-        nslab = max(n * k for n, k in zip(self.dims_out, self.Kp))
-        self.slabs = torch.empty(self.splits * nslab, dtype=torch.float32, device=dev)
+        # split-K of the weight gradients: K = Mp rows in stages of 32
+        self.layer_splits = [self.splits or pick_splits((n // 256) * (k // (256 if k % 256 == 0 else 128)), Mp // 32)
+                             for n, k in zip(self.dims_out, self.Kp)]
+        self.slabs = torch.empty(max(sp * n * k for sp, n, k in zip(self.layer_splits, self.dims_out, self.Kp)), dtype=torch.float32, device=dev)
         self.first = True
 
     def _pack_weights(self, table):
@@ -272,11 +290,12 @@ class SplitMLP:
         for i, l in enumerate(self.layers):    # dW_i = dZ_i^T H_{i-1}, db_i = column sums of dZ_i
             Bt, sb = (inp.PT, self.SLOT_X) if i == 0 else (self.HpT[i - 1], self.SLOT_H0 + i - 1)
             n, kp = self.dims_out[i], self.Kp[i]
-            gemm(EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=self.splits, C_out=self.slabs)
+            sp = self.layer_splits[i]
+            gemm(EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=sp, C_out=self.slabs)
             if l.weight.grad is None:
                 l.weight.grad = torch.empty_like(l.weight)
                 l.bias.grad = torch.empty_like(l.bias)
-            Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(self.slabs), self.splits, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
+            Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(self.slabs), sp, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
                                              _stream(self.dev)), "hoic_mlp_slab_reduce")
             Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
                    "hoic_mlp_rowsum_packed")

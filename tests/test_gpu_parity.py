@@ -864,3 +864,34 @@ def test_train_script_runs_two_iterations(tmp_path):
                        "--base_dir", base])
     assert agent3.n_envs == 16 and agent3.sample_mode == "episodes"
     agent3.env.close()
+
+
+def test_reward_curve_band_after_ten_iterations(box_model):
+    """North-star clause "reward-curve parity to the CPU reference at equal step count", as far as it can be asserted in a
+    test: 10 PPO iterations from the config's initial weights, deterministic reward per step of all 17 sequences.
+    profiles/r02_reward_curve.json (tools/reward_curve.py, 5 seeds x 100 iterations per arm on this hardware) holds the
+    bands; at iteration 10 the reference-shaped CPU sampler (float64 oracle, whole episodes) gives 0.752 +- 0.002.
+      * the HIP simulator under the same whole-episode sampler (sample_mode='episodes') must land in that band;
+      * the default fixed-horizon sampler is a different estimator (13-step windows, value bootstrap): it trails over
+        the first ~60 iterations (0.725 +- 0.002 here) and leads after ~75; its known offset is bounded here."""
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config
+    ex = motions.synthetic_expert(box_model, 17, 600)
+    res = {}
+    for mode, n_envs in (("episodes", 32), ("fixed", 4096)):
+        vals = []
+        for seed in (1, 2):
+            cfg = Config("box_future5_light_add_geom"); cfg.seed = seed
+            torch.manual_seed(seed)
+            agent = AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode)
+            for it in range(10):
+                agent.optimize_policy(it, save_model=False)
+            cfg.update_adaptive_params(9)
+            ev = agent.eval_sequences()
+            vals.append(ev["reward_per_step"])
+            assert ev["mean_percent"] > 0.9
+            agent.env.close(); agent._eval_env.close()
+        res[mode] = float(np.mean(vals))
+    print("deterministic reward per step after 10 iterations:", res)
+    assert abs(res["episodes"] - 0.752) < 0.006, res
+    assert -0.04 < res["fixed"] - res["episodes"] < 0.005, res
