@@ -75,9 +75,10 @@ class _Kernels:
             raise lib.HoicError(f"{what} failed ({rc}): {self.L.hoic_last_error().decode()}")
 
 
-def set_pipeline(on: bool):
-    """main loop of the GEMM kernel: software-pipelined (default) or the plain two-substep loop (A/B measurements)"""
-    kernels().L.hoic_mlp_set_pipeline(int(bool(on)))
+def set_pipeline(mode: int):
+    """GEMM kernel variant (A/B measurements): 0 plain loop, 1 software-pipelined 8-wavefront kernel, 2 the 4-wavefront K16
+    kernel with two workgroups per CU.  The library default is the fastest measured; HOIC_GEMM_MODE overrides it."""
+    kernels().L.hoic_mlp_set_pipeline(int(mode))
 
 
 _K = None
@@ -87,6 +88,9 @@ def kernels():
     global _K
     if _K is None:
         _K = _Kernels()
+        import os
+        if os.environ.get("HOIC_GEMM_MODE"):
+            _K.L.hoic_mlp_set_pipeline(int(os.environ["HOIC_GEMM_MODE"]))
     return _K
 
 
