@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="train", choices=["train", "grasp"],
                     help="train: the sampler's own episode draws; grasp: episodes start at frames >= 100 (object in the hand: contact-rich)")
+    ap.add_argument("--overlap", type=int, default=1, help="1: value-network steps on a side stream under the next rollout (f16x3 only); 0: serial")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=8)
@@ -195,7 +196,7 @@ def main():
     agent = AgentHandMimic(cfg, device=torch.device("cuda", local_rank), n_envs=args.envs, model=args.obj,
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
                            solver_iterations=args.solver_iterations, n_groups=args.groups, scaling=args.scaling,
-                           start_min=100 if args.workload == "grasp" else 0)
+                           start_min=100 if args.workload == "grasp" else 0, overlap_value_update=bool(args.overlap))
     share = world if args.scaling == "strong" else 1
     steps_per_iter = int(math.ceil(math.ceil(cfg.min_batch_size / share) / args.envs))
     n_warm_it = int(math.ceil(args.warmup / steps_per_iter)) if args.warmup > 0 else 0
@@ -224,6 +225,7 @@ def main():
         t_sample += info["T_sample"]; t_update += info["T_update"]; last_log = info["log"]
         a, b = agent.env.sim.step_times()       # HIP events on the launch stream, read after the iteration's own sync
         kernel_ms += a; post_ms += b
+    agent.learner.finish_update()            # an asynchronous value phase belongs to the timed region
     barrier()
     elapsed = time.time() - t0
     tmax = torch.tensor([elapsed, t_sample, t_update], device="cuda", dtype=torch.float64)
@@ -260,6 +262,7 @@ def main():
                        "envs_per_gpu": args.envs, "steps_per_iteration": steps_per_iter, "timed_iterations": n_it,
                        "samples_per_iteration": steps_per_iter * args.envs * world, "parallelism": f"env-dp{world}",
                        "rollout_env_ranges": n_groups, "update_gemms": args.update_dtype,
+                       "value_update_overlaps_next_rollout": bool(agent.learner.overlap_value_update),
                        "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
                                                 if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,

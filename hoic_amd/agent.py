@@ -103,7 +103,9 @@ class PPOLearner:
         self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=cfg.value_lr, weight_decay=cfg.value_weightdecay)
         self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
         self.opt_num_epochs = cfg.num_optim_epoch
-        self.last_losses = None
+        self._losses = None
+        self.overlap_value_update = False      # f16x3 only: value phase on a side stream, under the next rollout (AgentHandMimic sets it)
+        self._value_stream = self._value_event = self._value_keep = None
         assert update_dtype in ("f32", "bf16", "f16x3")
         self._engines = None             # f16x3: SplitMLP of (value net, policy net)
 
@@ -141,6 +143,7 @@ class PPOLearner:
 
     def update_params(self, batch):
         t0 = time.time()
+        self.finish_update()                # a value phase still running on the side stream uses the value network
         self.policy_net.train(); self.value_net.train()
         T, N = batch.rewards.shape
         valid = getattr(batch, "valid", None)
@@ -179,35 +182,108 @@ class PPOLearner:
 
     def _optimize_f16x3(self, inp, actions, advantages, returns, weight, policy_step, vparams, pparams):
         """optimize() with both MLP bodies on the f16x3 GEMMs: the bodies' forward returns the last hidden activation as
-        a leaf, PyTorch runs head + loss + their backward, the bodies' backward fills the MLP gradients."""
+        a leaf, PyTorch runs head + loss + their backward, the bodies' backward fills the MLP gradients.
+
+        ``overlap_value_update``: the two networks never feed each other during the epochs (the advantages were formed
+        before them), so the five policy steps run first and the five value steps are enqueued on a side stream: the
+        next rollout needs only the new policy and runs WHILE the value network is updated.  The arithmetic of each
+        chain is what the interleaved loop does; everything that reads the value network waits for the side stream
+        (wait_value_update)."""
         veng, peng = self._split_engines()
-        fixed_log_probs = None
         v_first, self._v_first = getattr(self, "_v_first", None), None
-        p_pending, p_waiting = None, False
-        for ep in range(self.opt_num_epochs):
-            # epoch 0 reuses the forward pass update_params made for the returns (same weights, same input)
-            h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
-            value_loss = (self.value_net.value_head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
-            self.optimizer_value.zero_grad(set_to_none=True)
-            (value_loss * weight if weight != 1.0 else value_loss).backward()
-            veng.backward(h.grad)
-            v_pending = self._allreduce_start(vparams)
-            if p_waiting:
-                policy_step(p_pending); p_waiting = False
-            h = peng.forward(inp)
-            if fixed_log_probs is None:      # the old policy's log-probabilities are epoch 0's own (ratio = 1 there, agent_ppo.py:18-20)
-                with torch.no_grad():
-                    fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
-            surr = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
-            self.optimizer_policy.zero_grad(set_to_none=True)
-            (surr * weight if weight != 1.0 else surr).backward()
-            peng.backward(h.grad)
-            p_pending, p_waiting = self._allreduce_start(pparams), True
-            self._allreduce_finish(v_pending)
-            self.optimizer_value.step()
-        policy_step(p_pending)
-        self.last_losses = (float(value_loss.detach()), float(surr.detach()))
+
+        def value_phase():
+            loss = None
+            for ep in range(self.opt_num_epochs):
+                # epoch 0 reuses the forward pass update_params made for the returns (same weights, same input)
+                h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
+                loss = (self.value_net.value_head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
+                self.optimizer_value.zero_grad(set_to_none=True)
+                (loss * weight if weight != 1.0 else loss).backward()
+                veng.backward(h.grad)
+                self._allreduce_finish(self._allreduce_start(vparams))
+                self.optimizer_value.step()
+            return loss.detach()
+
+        def policy_phase():
+            fixed_log_probs, loss = None, None
+            for ep in range(self.opt_num_epochs):
+                h = peng.forward(inp)
+                if fixed_log_probs is None:      # the old policy's log-probabilities are epoch 0's own (ratio = 1 there, agent_ppo.py:18-20)
+                    with torch.no_grad():
+                        fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
+                loss = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
+                self.optimizer_policy.zero_grad(set_to_none=True)
+                (loss * weight if weight != 1.0 else loss).backward()
+                peng.backward(h.grad)
+                policy_step(self._allreduce_start(pparams))
+            return loss.detach()
+
+        if self.overlap_value_update:
+            surr = policy_phase()
+            cur = torch.cuda.current_stream(self.device)
+            if self._value_stream is None:
+                self._value_stream = torch.cuda.Stream(self.device)
+            self._value_stream.wait_stream(cur)
+            with torch.cuda.stream(self._value_stream):
+                value_loss = value_phase()
+                self._value_event = torch.cuda.Event(); self._value_event.record(self._value_stream)
+            self._value_keep = (inp, actions, advantages, returns, v_first)       # alive until the side stream is done with them
+            self._losses = (value_loss, surr)
+            return
+        if self.distributed:      # several ranks: interleave the chains so that each gradient all-reduce hides under the other network's pass
+            fixed_log_probs = None
+            p_pending, p_waiting = None, False
+            for ep in range(self.opt_num_epochs):
+                h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
+                value_loss = (self.value_net.value_head(h) - returns).pow(2).mean()
+                self.optimizer_value.zero_grad(set_to_none=True)
+                (value_loss * weight if weight != 1.0 else value_loss).backward()
+                veng.backward(h.grad)
+                v_pending = self._allreduce_start(vparams)
+                if p_waiting:
+                    policy_step(p_pending); p_waiting = False
+                h = peng.forward(inp)
+                if fixed_log_probs is None:
+                    with torch.no_grad():
+                        fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
+                surr = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
+                self.optimizer_policy.zero_grad(set_to_none=True)
+                (surr * weight if weight != 1.0 else surr).backward()
+                peng.backward(h.grad)
+                p_pending, p_waiting = self._allreduce_start(pparams), True
+                self._allreduce_finish(v_pending)
+                self.optimizer_value.step()
+            policy_step(p_pending)
+            self._losses = (value_loss.detach(), surr.detach())
+        else:
+            value_loss = value_phase()
+            self._losses = (value_loss, policy_phase())
         veng.check_overflow()
+
+    def wait_value_update(self):
+        """Everything that reads the value network (or needs the update finished) calls this first: makes the current stream
+        wait for an asynchronous value phase (overlap_value_update); no-op otherwise."""
+        ev = getattr(self, "_value_event", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._value_event = None
+            self._overflow_check_due = True
+
+    def finish_update(self):
+        """wait_value_update + host synchronisation + the f16-range check of the asynchronous phase"""
+        self.wait_value_update()
+        if getattr(self, "_overflow_check_due", False):
+            self._overflow_check_due = False
+            torch.cuda.current_stream(self.device).synchronize()
+            self._value_keep = None
+            if self._engines is not None:
+                self._engines[0].check_overflow()
+
+    @property
+    def last_losses(self):
+        l = getattr(self, "_losses", None)
+        return None if l is None else (float(l[0]), float(l[1]))
 
     def optimize(self, states, actions, advantages, returns, weight=1.0):
         """The 5 full-batch epochs of value and policy steps (agent_ppo.py:16-56) on flat [M, .] tensors.  ``weight``
@@ -254,14 +330,14 @@ class PPOLearner:
             self._allreduce_finish(v_pending)
             self.optimizer_value.step()
         policy_step(p_pending)
-        self.last_losses = (float(value_loss.detach()), float(surr.detach()))
+        self._losses = (value_loss.detach(), surr.detach())
 
 
 class AgentHandMimic:
     def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=8, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
-                 start_min=0):
+                 start_min=0, overlap_value_update=False):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
@@ -303,6 +379,8 @@ class AgentHandMimic:
         self.tuned_gemms = tuning.enable_tuned_gemms()      # recorded hipBLASLt kernel selections for the MLP shapes
         self.learner = PPOLearner(cfg, self.state_dim, self.action_dim, self.device, dtype, distributed, update_dtype,
                                   strict_reference)
+        # the value network's five steps on a side stream, under the next iteration's rollout (f16x3 update on the GPU only)
+        self.learner.overlap_value_update = bool(overlap_value_update) and update_dtype == "f16x3" and self.device.type == "cuda"
         self.policy_net, self.value_net = self.learner.policy_net, self.learner.value_net
         self.optimizer_policy, self.optimizer_value = self.learner.optimizer_policy, self.learner.optimizer_value
         self.running_state = BatchZFilter(self.state_dim, clip=5.0, device=self.device)
@@ -441,6 +519,7 @@ class AgentHandMimic:
         if self.distributed:
             self.running_state.sync()          # one observation filter for all ranks from here on
         next_state = self.running_state(obs, update=False)
+        self.learner.wait_value_update()          # the bootstrap below is the first reader of the value network since the update
         next_values = self.value_net(next_state).squeeze(1)
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
                                 exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values, valid=None)
@@ -516,8 +595,8 @@ class AgentHandMimic:
             self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
         t1 = time.time()
         self.update_params(batch)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
+        if self.device.type == "cuda" and not self.learner.overlap_value_update:
+            torch.cuda.synchronize(self.device)      # (with the overlap the value phase keeps running under the next rollout)
         t2 = time.time()
         info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
         if save_model and (epoch + 1) % self.cfg.save_n_epochs == 0 and self.rank == 0:
@@ -632,6 +711,7 @@ class AgentHandMimic:
 
     # ------------------------------------------------------------------ checkpoints (:175-186, :234-245)
     def save_checkpoint(self, epoch):
+        self.learner.finish_update()
         os.makedirs(self.cfg.model_dir, exist_ok=True)
         cp = {"policy_dict": {k: v.detach().cpu() for k, v in self.policy_net.state_dict().items()},
               "value_dict": {k: v.detach().cpu() for k, v in self.value_net.state_dict().items()},

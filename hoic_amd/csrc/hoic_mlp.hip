@@ -579,7 +579,8 @@ extern "C" int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R
 
 extern "C" int32_t hoic_mlp_amax(const float* d_x, const float* d_mul, int64_t n, float* d_amax, int32_t slot, void* stream) {
   if (!d_x || n <= 0 || !d_amax) { hoic_set_error("hoic_mlp_amax: bad arguments"); return HOIC_ERR_ARG; }
-  hipLaunchKernelGGL(hoic_amax_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, d_x, d_mul, (long long)n, d_amax, slot);
+  const long long want = (n + 256LL * 16 - 1) / (256LL * 16);        // ~16 elements per thread: a weight matrix takes a few hundred workgroups, not 1024
+  hipLaunchKernelGGL(hoic_amax_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want))), dim3(256), 0, (hipStream_t)stream, d_x, d_mul, (long long)n, d_amax, slot);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

@@ -209,6 +209,7 @@ class SplitMLP:
         self.splits = wgrad_splits
         self.M = None
         self.first = True
+        self.table = ScaleTable(self.dev)         # this network's own exponents; slot 0 mirrors the shared input's
 
     # ------------------------------------------------------------------ buffers for a batch size
     def _alloc(self, inp: PackedInput):
@@ -241,7 +242,8 @@ class SplitMLP:
     def forward(self, inp: PackedInput, need_grad=True):
         """-> float32 [M, out] last hidden activation (a leaf that requires grad when ``need_grad``)."""
         self._alloc(inp)
-        t = self.table = inp.table
+        t = self.table
+        t.exps[self.SLOT_X:self.SLOT_X + 1].copy_(inp.table.exps[0:1])      # device-side copy, no sync
         self.inp = inp
         L = len(self.layers)
         if self.first:
