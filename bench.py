@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="train", choices=["train", "grasp"],
                     help="train: the sampler's own episode draws; grasp: episodes start at frames >= 100 (object in the hand: contact-rich)")
-    ap.add_argument("--overlap", type=int, default=1, help="1: value-network steps on a side stream under the next rollout (f16x3 only); 0: serial")
+    ap.add_argument("--overlap", type=int, default=0, help="1: value-network steps on a side stream under the next rollout (f16x3 only; measured: no gain, the GEMM workgroups take the CUs' LDS); 0: serial")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=8)
