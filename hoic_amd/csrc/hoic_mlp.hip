@@ -186,6 +186,59 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
   }
 }
 
+// The same epilogue for accumulators in the OTHER orientation, D[m][n] (activation-side fragment = MFMA A operand): a
+// lane owns column n = nb + 32 j + (lane & 31) and, per register, row m = mb + 32 i + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// Every global access is then one dword per lane with 32 lanes on 128 consecutive bytes (full lines): GELU' and the
+// float32 copy directly, the packed row-major output after an exchange inside each group of 8 lanes (lane q of a group
+// writes dword q of the 32-byte H8L8 group: q < 4 the hi halves of columns 2q, 2q + 1, q >= 4 the lo halves).  No
+// transposed output in this form (the weight-gradient kernel below reads row-major operands).
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc)[TM][TN], int mb, int nb, int lane) {
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
+  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
+  const int eo = a.exps ? a.exps[a.eo] : 0;
+  const float so = ldexpf(1.f, eo);
+  const int src0 = ((lane & ~7) + 2 * (lane & 3)) << 2, src1 = src0 + 4;        // ds_bpermute byte addresses of the two source lanes
+  const unsigned sel = (lane & 4) ? 0x07060302u : 0x05040100u;                  // lanes 4..7 of a group assemble the lo halves
+  // addresses: the arrays' base pointers stay in scalar registers, the element offset is ONE 32-bit VGPR chain (outputs are
+  // below 4 GB: asserted on the host)
+  const unsigned N = (unsigned)a.N;
+  const unsigned lane_off = (unsigned)mb * N + (unsigned)(nb + l31) + 4u * (unsigned)hf * N;
+  float vmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const float bj = (EPI == EPI_FWD) ? a.bias[nb + 32 * j + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      __builtin_amdgcn_sched_barrier(0);        // one 32 x 32 tile at a time
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const unsigned o = lane_off + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * N + 32u * j;
+        float v;
+        if (EPI == EPI_FWD) {
+          float dq;
+          gelu_pair(fmaf(alpha, acc[i][j][r], bj), v, dq);
+          if (a.Gout) a.Gout[o] = dq;
+        } else {
+          v = alpha * acc[i][j][r] * a.Gin[o];
+        }
+        if (a.Hf32) a.Hf32[o] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+        if (a.P) {
+          const unsigned w = pack_hl(v * so);
+          const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(src0, (int)w), w1 = (unsigned)__builtin_amdgcn_ds_bpermute(src1, (int)w);
+          ((unsigned*)a.P)[o] = __builtin_amdgcn_perm(w1, w0, sel);
+        }
+      }
+    }
+  }
+  if (a.amax) {
+    vmax = wave_max_f(vmax);
+    if (lane == 0) atomicMax((unsigned*)(a.amax + a.eo), __float_as_uint(vmax));
+  }
+}
+
 template <int BN, int EPI, bool PIPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_kernel(GemmArgs a) {
   typedef Cfg<BN> C;
@@ -318,7 +371,7 @@ __device__ __forceinline__ void read_frag16(const char* tile, int row, int hf, h
   hi = *(const h8*)(tile + row * 64 + (((2 * hf) ^ sw) << 4));
   lo = *(const h8*)(tile + row * 64 + (((2 * hf + 1) ^ sw) << 4));
 }
-template <int EPI>
+template <int EPI, bool MN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_k16_kernel(GemmArgs a) {
   constexpr int TM = 4, TN = 2;
   __shared__ __attribute__((aligned(1024))) char smem[3 * K16_STG];
@@ -358,9 +411,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int j = 0; j < TN; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+        if (MN) {      // D[m][n]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        } else {       // D[n][m]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+        }
       }
   };
   auto stage = [&](int t_) {
@@ -399,7 +458,113 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef K16_STEP
   }
-  gemm_epilogue<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, split, lane);
+  if (MN) gemm_epilogue_mn<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, lane);
+  else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, split, lane);
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradients
+// C[i][j] = alpha sum_m A[m][i] B[m][j]  with BOTH operands row-major over the contraction index m (A = dZ [rows x 2 NA],
+// B = H [rows x 2 NB], packed along their columns): the activations and gradients are used as the forward / data-gradient
+// epilogues wrote them, no transposed copies.  The MFMA wants 8 consecutive m per lane for one column; gfx950's
+// ds_read_b64_tr_b16 delivers exactly that from a row-major LDS image: within 16 lanes, source lane 4a + b supplies the
+// address of [row a][4 halves of column block b] and result lane c receives column c of rows 0..3 (measured with
+// tools/probe/tr_probe.hip).  Tile 256 (i) x BN (j), 8 wavefronts, K stages of 32 rows, two LDS stages by LDS-DMA: a
+// stage row is 1 KB (BN = 128: 512 B) and 16-byte chunk c of row r sits at chunk c ^ ((r & 1) | ((r & 2) << 2)), which
+// puts the 32 lanes of a transposing read on 32 distinct 8-byte slots of the 256-byte bank row.  Output: float32 slabs
+// [split][NA x NB], one dword per lane with 32 lanes on one 128-byte line.
+template <int ROWB> __device__ __forceinline__ void stage_rows_tn(const char* g, size_t ldg, char* lds, int wave, int lane) {
+  constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
+#pragma unroll
+  for (int i = 0; i < 32 * CPR / 512; i++) {
+    const int q = (i * 8 + wave) * 64 + lane, row = q / CPR, c = (q % CPR) ^ ((row & 1) | ((row & 2) << 2));
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)row * ldg + c * 16), LDS_PTR(lds + (i * 8 + wave) * 1024), 16, 0, 0);
+  }
+}
+typedef __fp16 hw4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+template <int ROWB> __device__ __forceinline__ void read_frag_tr(const char* tile, int cb, int s, int lane, h8& hi, h8& lo) {
+  const int g = lane >> 4, il = lane & 15;
+  const int n = cb + 16 * (g & 1) + 4 * (il & 3);               // first of the 4 columns this lane's address covers
+  const int ch = 2 * (n >> 3), ho = (n & 4) ? 8 : 0;
+  const int row0 = 16 * s + 8 * (g >> 1) + (il >> 2);
+  hw4 r[4];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int row = row0 + 4 * p, sw = (row & 1) | ((row & 2) << 2);
+    const char* base = tile + row * ROWB + ho;
+    r[p] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hw4*)LDS_PTR(base + ((ch ^ sw) << 4)));
+    r[2 + p] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hw4*)LDS_PTR(base + (((ch + 1) ^ sw) << 4)));
+  }
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 h = {__builtin_bit_cast(u64, r[0]), __builtin_bit_cast(u64, r[1])}, l = {__builtin_bit_cast(u64, r[2]), __builtin_bit_cast(u64, r[3])};
+  hi = __builtin_bit_cast(h8, h); lo = __builtin_bit_cast(h8, l);
+}
+template <int BN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_tn_kernel(GemmArgs a) {
+  typedef Cfg<BN> C;                      // TM tiles along i (rows of C), TN along j
+  constexpr int RA = 256 * 4, RB = BN * 4, STG = 32 * (RA + RB);
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STG];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int ntn = a.N / BN, ntiles = (a.M / 256) * ntn;
+  int g = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = g & 7, idx = g >> 3;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int i0 = (g / ntn) * 256, j0 = (g % ntn) * BN;
+  const int split = blockIdx.y;
+  const int kt0 = split * a.kt_per_split;
+  const int nkt = min(a.kt_per_split, a.K / 32 - kt0);
+  const size_t lda = (size_t)a.M * 4, ldb = (size_t)a.N * 4;      // bytes per sample row of the packed operands
+  const char* Ag = (const char*)a.A + (size_t)kt0 * 32 * lda + (size_t)i0 * 4;
+  const char* Bg = (const char*)a.B + (size_t)kt0 * 32 * ldb + (size_t)j0 * 4;
+  const int wi = (wave / C::WN) * (C::TM * 32), wj = (wave % C::WN) * (C::TN * 32);
+  f32x16 acc[C::TM][C::TN];
+#pragma unroll
+  for (int i = 0; i < C::TM; i++)
+#pragma unroll
+    for (int j = 0; j < C::TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  auto stage = [&](int t_) {
+    char* dst = smem + (t_ & 1) * STG;
+    stage_rows_tn<RA>(Ag + (size_t)t_ * 32 * lda, lda, dst, wave, lane);
+    stage_rows_tn<RB>(Bg + (size_t)t_ * 32 * ldb, ldb, dst + 32 * RA, wave, lane);
+  };
+  if (nkt > 0) stage(0);
+  for (int t = 0; t < nkt; t++) {
+    __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
+    if (t + 1 < nkt) stage(t + 1);
+    const char* At = smem + (t & 1) * STG;
+    const char* Bt = At + 32 * RA;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; s_++) {
+      h8 ah[C::TM], al[C::TM], bh[C::TN], bl[C::TN];
+#pragma unroll
+      for (int j = 0; j < C::TN; j++) read_frag_tr<RB>(Bt, wj + 32 * j, s_, lane, bh[j], bl[j]);
+#pragma unroll
+      for (int i = 0; i < C::TM; i++) read_frag_tr<RA>(At, wi + 32 * i, s_, lane, ah[i], al[i]);
+#pragma unroll
+      for (int i = 0; i < C::TM; i++)
+#pragma unroll
+        for (int j = 0; j < C::TN; j++) {       // D[i][j]: lane = column j, registers = rows i
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
+  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
+  float* Cp = a.C + (size_t)split * a.c_split_stride;
+#pragma unroll
+  for (int i = 0; i < C::TM; i++)
+#pragma unroll
+    for (int j = 0; j < C::TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        Cp[(size_t)(i0 + wi + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf) * a.N + j0 + wj + 32 * j + l31] = alpha * acc[i][j][r];
 }
 
 // ---------------------------------------------------------------------------------------------- pack kernels
@@ -514,13 +679,18 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
 // ---------------------------------------------------------------------------------------------- C-ABI
 // 0: plain two-substep loop, 1: software-pipelined 8-wavefront kernel (256 x 256 | 128 tiles, one workgroup per CU),
 // 2: the 4-wavefront 256 x 128 K16 kernel, two workgroups per CU (measurement aid; the default is the fastest measured)
-static int g_gemm_pipeline = 2;
-extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return HOIC_OK; }
+//    3: mode 2 with the accumulators in D[m][n] orientation for the forward / data-gradient epilogues (every store a
+//       full line; needs the transposed outputs switched off, i.e. the row-major weight-gradient kernel hoic_mlp_gemm_tn)
+static int g_gemm_pipeline = 3;
+extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return HOIC_OK; }
 
 template <int BN, int EPI> static int32_t launch_gemm(const GemmArgs& a, int splits, hipStream_t st) {
   const int ntiles = (a.M / 256) * (a.N / BN);
-  if (g_gemm_pipeline == 2) {
-    hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
+  if (g_gemm_pipeline >= 2) {
+    if (g_gemm_pipeline == 3 && EPI != EPI_F32 && !a.PT)
+      hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI, true>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI, false>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
     MCHK(hipGetLastError());
     return HOIC_OK;
   }
@@ -554,6 +724,64 @@ extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, c
   if (epi == EPI_FWD) return wide ? launch_gemm<256, EPI_FWD>(a, 1, st) : launch_gemm<128, EPI_FWD>(a, 1, st);
   if (epi == EPI_BWD) return wide ? launch_gemm<256, EPI_BWD>(a, 1, st) : launch_gemm<128, EPI_BWD>(a, 1, st);
   hoic_set_error("hoic_mlp_gemm: unknown epilogue"); return HOIC_ERR_ARG;
+}
+
+extern "C" int32_t hoic_mlp_gemm_tn(int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps, int32_t slot_a,
+                                    int32_t slot_b, float extra_scale, int32_t splits, float* d_C, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M & 255) || (N & 127) || (K & 31) || !d_A || !d_B || !d_C || splits < 1) {
+    hoic_set_error("hoic_mlp_gemm_tn: M must be a multiple of 256, N of 128, K (rows) of 32"); return HOIC_ERR_ARG;
+  }
+  GemmArgs a{};
+  a.A = (const u16*)d_A; a.B = (const u16*)d_B; a.M = M; a.N = N; a.K = K;
+  a.kt_per_split = (K / 32 + splits - 1) / splits;
+  a.exps = d_exps; a.ea = slot_a; a.eb = slot_b; a.extra_scale = extra_scale; a.C = d_C; a.c_split_stride = (long long)M * N;
+  hipStream_t st = (hipStream_t)stream;
+  if ((N % 256) == 0) hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<256>), dim3((M / 256) * (N / 256), splits), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<128>), dim3((M / 256) * (N / 128), splits), dim3(512), 0, st, a);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+// column sums of a packed row-major tensor [R x 2C] (hi + lo), unscaled: two deterministic stages (row chunks, then their sum)
+__global__ __launch_bounds__(256) void hoic_colsum_packed_kernel(const u16* __restrict__ P, int R, int Cc, int rows_per_block, float* __restrict__ part) {
+  // block (x: group of 64 columns = 8 H8L8 groups, y: row chunk); thread = (column group of 8 within x: 0..7) x (row lane 0..31)
+  __shared__ float red[32][65];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3, c8 = blockIdx.x * 8 + cg;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c8 * 8 < Cc)
+    for (int r = r0 + rl; r < r1; r += 32) {
+      const u32x4* gq = (const u32x4*)(P + ((long long)r * Cc + c8 * 8) * 2);
+      const h8 h = __builtin_bit_cast(h8, gq[0]), l = __builtin_bit_cast(h8, gq[1]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] += (float)h[k] + (float)l[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; k++) red[rl][cg * 8 + k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+    for (int q = 0; q < 32; q++) t += red[q][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < Cc) part[(long long)blockIdx.y * Cc + c] = t;
+  }
+}
+__global__ void hoic_colsum_finish_kernel(const float* __restrict__ part, int nchunks, int Cc, float* __restrict__ out, const int* __restrict__ exps, int slot) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cc) return;
+  float t = 0.f;
+  for (int k = 0; k < nchunks; k++) t += part[(long long)k * Cc + c];
+  out[c] = ldexpf(t, -(exps ? exps[slot] : 0));
+}
+extern "C" int32_t hoic_mlp_colsum_packed(const void* d_P, int32_t R, int32_t C, float* d_out, float* d_scratch, const int32_t* d_exps, int32_t slot,
+                                          void* stream) {
+  if (!d_P || !d_out || !d_scratch || R <= 0 || C <= 0 || (C & 7)) { hoic_set_error("hoic_mlp_colsum_packed: bad arguments"); return HOIC_ERR_ARG; }
+  const int rows_per_block = 512, nchunks = (R + rows_per_block - 1) / rows_per_block;      // d_scratch: nchunks * C floats
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(hoic_colsum_packed_kernel, dim3((C + 63) / 64, nchunks), dim3(256), 0, st, (const u16*)d_P, R, C, rows_per_block, d_scratch);
+  hipLaunchKernelGGL(hoic_colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, d_scratch, nchunks, C, d_out, d_exps, slot);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
 }
 
 extern "C" int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R, int32_t C, int64_t ld, void* d_P, void* d_PT, int32_t Rp,

@@ -66,7 +66,10 @@ class _Kernels:
         L.hoic_mlp_slab_reduce.argtypes = [vp, i32, i32, i32, vp, i32, i64, f32, vp]
         L.hoic_mlp_rowsum_packed.argtypes = [vp, i32, i32, vp, vp, i32, vp]
         L.hoic_mlp_set_pipeline.argtypes = [i32]
-        for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed"):
+        L.hoic_mlp_gemm_tn.argtypes = [i32, i32, i32, vp, vp, vp, i32, i32, f32, i32, vp, vp]
+        L.hoic_mlp_colsum_packed.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
+        for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
+                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed"):
             getattr(L, n).restype = i32
         self.L = L
 
@@ -75,9 +78,16 @@ class _Kernels:
             raise lib.HoicError(f"{what} failed ({rc}): {self.L.hoic_last_error().decode()}")
 
 
+GEMM_MODE = 3      # set by kernels() from HOIC_GEMM_MODE when given
+
+
 def set_pipeline(mode: int):
     """GEMM kernel variant (A/B measurements): 0 plain loop, 1 software-pipelined 8-wavefront kernel, 2 the 4-wavefront K16
-    kernel with two workgroups per CU.  The library default is the fastest measured; HOIC_GEMM_MODE overrides it."""
+    kernel with two workgroups per CU, 3 (default) = 2 with D[m][n] accumulators: forward / data-gradient epilogues store
+    full lines and write no transposed copies, the weight gradients come from the row-major kernel (hoic_mlp_gemm_tn).
+    HOIC_GEMM_MODE overrides the default."""
+    global GEMM_MODE
+    GEMM_MODE = int(mode)
     kernels().L.hoic_mlp_set_pipeline(int(mode))
 
 
@@ -89,8 +99,10 @@ def kernels():
     if _K is None:
         _K = _Kernels()
         import os
+        global GEMM_MODE
         if os.environ.get("HOIC_GEMM_MODE"):
-            _K.L.hoic_mlp_set_pipeline(int(os.environ["HOIC_GEMM_MODE"]))
+            GEMM_MODE = int(os.environ["HOIC_GEMM_MODE"])
+        _K.L.hoic_mlp_set_pipeline(GEMM_MODE)
     return _K
 
 
@@ -149,6 +161,26 @@ def gemm(epi, M, N, K_, A, B, table, sa, sb, so=0, extra_scale=1.0, splits=1, C_
                               _ptr(C_out), _ptr(bias), _ptr(gin), _ptr(gout), _ptr(hf32), _ptr(P), _ptr(PT), _stream(dev)), "hoic_mlp_gemm")
 
 
+def gemm_tn(M, N, K_, A, B, table, sa, sb, splits, C_out, extra_scale=1.0):
+    """C[i][j] = sum_m A[m][i] B[m][j]: A [K_, 2M], B [K_, 2N] packed row-major over the contraction (sample) index"""
+    Kn = kernels()
+    Kn.chk(Kn.L.hoic_mlp_gemm_tn(M, N, K_, _ptr(A), _ptr(B), _ptr(table.exps), sa, sb, float(extra_scale), splits, _ptr(C_out), _stream(A.device)),
+           "hoic_mlp_gemm_tn")
+
+
+def matmul_tn(a, b, splits=1):
+    """a [K, M]^T @ b [K, N] in float32 through the row-major weight-gradient kernel (test entry; pads to the tile sizes)"""
+    K_, M = a.shape
+    N = b.shape[1]
+    Mp, Np, Kp = _rup(M, 256), _rup(N, 128), _rup(K_, 32)
+    t = ScaleTable(a.device)
+    Ap, _ = pack(a.contiguous(), t, 0, Kp, Mp)
+    Bp, _ = pack(b.contiguous(), t, 1, Kp, Np)
+    out = torch.empty(splits, Mp, Np, dtype=torch.float32, device=a.device)
+    gemm_tn(Mp, Np, Kp, Ap, Bp, t, 0, 1, splits, out)
+    return out.sum(0)[:M, :N] if splits > 1 else out[0, :M, :N]
+
+
 def matmul_nt(a, b, splits=1):
     """a [M, K] @ b [N, K]^T in float32 through the f16x3 kernel (test / diagnostic entry; pads to the tile sizes)."""
     M, K_ = a.shape
@@ -171,7 +203,8 @@ class PackedInput:
         self.M, self.K = x.shape
         self.Mp, self.Kp = _rup(self.M, 256), _rup(self.K, 128)
         self.table = table if table is not None else ScaleTable(x.device)
-        self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=True)
+        kernels()
+        self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=(GEMM_MODE != 3))
 
 
 def pick_splits(tiles, nkt, n_cu=256, max_splits=64):
@@ -219,12 +252,18 @@ class SplitMLP:
         L = len(self.layers)
         h = lambda r, c: torch.empty(r, 2 * c, dtype=torch.float16, device=dev)
         self.M = Mp
+        self.rows_layout = GEMM_MODE == 3      # no transposed copies: weight gradients by the row-major kernel
         self.G = [torch.empty(Mp, n, dtype=torch.float32, device=dev) for n in self.dims_out]
         self.Hp = [h(Mp, n) for n in self.dims_out[:-1]]
-        self.HpT = [h(n, Mp) for n in self.dims_out[:-1]]
         self.Hlast = torch.empty(Mp, self.dims_out[-1], dtype=torch.float32, device=dev)
-        self.dZp = [None] + [h(Mp, n) for n in self.dims_out[1:]]          # rows: operand of the data-gradient GEMM (layers >= 1)
-        self.dZpT = [h(n, Mp) for n in self.dims_out]
+        if self.rows_layout:
+            self.HpT, self.dZpT = [None] * (L - 1), [None] * L
+            self.dZp = [h(Mp, n) for n in self.dims_out]
+            self.colsum_scratch = torch.empty(((Mp + 511) // 512) * max(self.dims_out), dtype=torch.float32, device=dev)
+        else:
+            self.HpT = [h(n, Mp) for n in self.dims_out[:-1]]
+            self.dZp = [None] + [h(Mp, n) for n in self.dims_out[1:]]      # rows: operand of the data-gradient GEMM (layers >= 1)
+            self.dZpT = [h(n, Mp) for n in self.dims_out]
         # split-K of the weight gradients: K = Mp rows in stages of 32
         self.layer_splits = [self.splits or pick_splits((n // 256) * (k // (256 if k % 256 == 0 else 128)), Mp // 32)
                              for n, k in zip(self.dims_out, self.Kp)]
@@ -281,8 +320,8 @@ class SplitMLP:
         t.measure(s_last, dH, self.G[-1]); t.update([s_last])
         P, PT = self.dZp[L - 1], self.dZpT[L - 1]
         Kn = kernels()
-        Kn.chk(Kn.L.hoic_mlp_pack(_ptr(dH), _ptr(self.G[-1]), Mp, self.dims_out[-1], self.dims_out[-1], _ptr(P if L > 1 else None), _ptr(PT), Mp,
-                                  self.dims_out[-1], _ptr(t.exps), s_last, _stream(self.dev)), "hoic_mlp_pack")
+        Kn.chk(Kn.L.hoic_mlp_pack(_ptr(dH), _ptr(self.G[-1]), Mp, self.dims_out[-1], self.dims_out[-1], _ptr(P if (L > 1 or self.rows_layout) else None),
+                                  _ptr(PT), Mp, self.dims_out[-1], _ptr(t.exps), s_last, _stream(self.dev)), "hoic_mlp_pack")
         if self.first_bwd:      # first backward pass: the hidden-layer gradients start at the loss-side exponent
             with torch.no_grad():
                 for i in range(L - 1):
@@ -292,19 +331,27 @@ class SplitMLP:
             t.update([self.SLOT_DZ0 + i for i in range(L - 1)])
         for i in range(L - 1, 0, -1):          # dZ_{i-1} = (dZ_i W_i) * GELU'(z_{i-1})
             gemm(EPI_BWD, Mp, self.dims_out[i - 1], self.dims_out[i], self.dZp[i], self.WpT[i], t, self.SLOT_DZ0 + i, self.SLOT_W0 + i,
-                 self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1])
+                 self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1])       # (rows layout: dZpT entries are None)
         for i, l in enumerate(self.layers):    # dW_i = dZ_i^T H_{i-1}, db_i = column sums of dZ_i
-            Bt, sb = (inp.PT, self.SLOT_X) if i == 0 else (self.HpT[i - 1], self.SLOT_H0 + i - 1)
             n, kp = self.dims_out[i], self.Kp[i]
             sp = self.layer_splits[i]
-            gemm(EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=sp, C_out=self.slabs)
+            if self.rows_layout:
+                Br, sb = (inp.P, self.SLOT_X) if i == 0 else (self.Hp[i - 1], self.SLOT_H0 + i - 1)
+                gemm_tn(n, kp, Mp, self.dZp[i], Br, t, self.SLOT_DZ0 + i, sb, sp, self.slabs)
+            else:
+                Bt, sb = (inp.PT, self.SLOT_X) if i == 0 else (self.HpT[i - 1], self.SLOT_H0 + i - 1)
+                gemm(EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=sp, C_out=self.slabs)
             if l.weight.grad is None:
                 l.weight.grad = torch.empty_like(l.weight)
                 l.bias.grad = torch.empty_like(l.bias)
             Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(self.slabs), sp, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
                                              _stream(self.dev)), "hoic_mlp_slab_reduce")
-            Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
-                   "hoic_mlp_rowsum_packed")
+            if self.rows_layout:
+                Kn.chk(Kn.L.hoic_mlp_colsum_packed(_ptr(self.dZp[i]), Mp, n, _ptr(l.bias.grad), _ptr(self.colsum_scratch), _ptr(t.exps),
+                                                   self.SLOT_DZ0 + i, _stream(self.dev)), "hoic_mlp_colsum_packed")
+            else:
+                Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
+                       "hoic_mlp_rowsum_packed")
 
     def check_overflow(self):
         n = int(self.table.overflow.item())

@@ -74,6 +74,27 @@ def test_gemm_f16x3_accuracy(shape):
         assert ((c2.double() - ref).abs() / bound).max().item() < 6e-7
 
 
+@gpu
+@pytest.mark.parametrize("shape", [(256, 128, 32), (512, 256, 96), (2048, 640, 4096), (300, 200, 1000)])
+def test_gemm_tn_accuracy(shape):
+    """C = A^T B with both operands row-major over the contraction index (the weight-gradient kernel: LDS transposing
+    reads) against the float64 product; asymmetric operands."""
+    Mm, N, K = shape
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.randn(K, Mm, device=dev, generator=g) * torch.exp(torch.randn(1, Mm, device=dev, generator=g)) * 1e-3
+    b = torch.randn(K, N, device=dev, generator=g) * 0.7 + 0.1
+    c = M.matmul_tn(a, b)
+    ref = a.double().T @ b.double()
+    bound = a.double().abs().T @ b.double().abs()
+    err = ((c.double() - ref).abs() / bound).max().item()
+    print(f"shape {shape}: f16x3 TN max err / sum|a||b| = {err:.2e}")
+    assert err < 6e-7
+    if K >= 64:
+        c2 = M.matmul_tn(a, b, splits=2)
+        assert ((c2.double() - ref).abs() / bound).max().item() < 6e-7
+
+
 def _nets(hidden, seed=0):
     from hoic_amd.rl import MLP
     torch.manual_seed(seed)
@@ -83,10 +104,14 @@ def _nets(hidden, seed=0):
 
 
 @gpu
-def test_split_mlp_forward_backward_matches_autograd():
+@pytest.mark.parametrize("mode", [3, 2, 1])
+def test_split_mlp_forward_backward_matches_autograd(mode):
     """SplitMLP.forward / backward against torch autograd in float64 on the same network and batch: activations to 2e-6,
-    every parameter gradient to 2e-6 of its largest entry; the batch is not a multiple of the tile (padding path)."""
+    every parameter gradient to 2e-6 of its largest entry; the batch is not a multiple of the tile (padding path).
+    Mode 3 = the default layout (row-major operands everywhere, D[m][n] epilogues, transposing-read weight gradients),
+    modes 2 / 1 = the layouts with transposed copies (K16 and 8-wavefront kernels)."""
     import copy
+    M.set_pipeline(mode)
     hidden = (512, 256, 256)
     net, head = _nets(hidden)
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -119,6 +144,7 @@ def test_split_mlp_forward_backward_matches_autograd():
     # no-grad forward gives the same activations
     h2 = eng.forward(inp, need_grad=False)
     assert not h2.requires_grad and torch.equal(h2, h.detach())
+    M.set_pipeline(3)
 
 
 @gpu
