@@ -66,17 +66,19 @@ def main():
         with torch.no_grad():
             t.exps[3] = 4; t.exps[4] = 10
         cases = [
-            ("fwd", Mr, N, K, lambda: M.gemm(M.EPI_FWD, Mr, N, K, Xp, Wp, t, 0, 1, 3, bias=bias, gout=G, P=Hp, PT=HpT),
+            ("fwd", Mr, N, K, lambda: M.gemm(M.EPI_FWD, Mr, N, K, Xp, Wp, t, 0, 1, 3, bias=bias, gout=G, P=Hp, PT=None if args.pipeline == 3 else HpT),
              lambda: torch.nn.functional.gelu(torch.addmm(bias, x, w.t()))),
             ("fwd_plain", Mr, N, K, lambda: M.gemm(M.EPI_F32, Mr, N, K, Xp, Wp, t, 0, 1, C_out=G), lambda: torch.mm(x, w.t())),
-            ("bwd_data", Mr, K, N, lambda: M.gemm(M.EPI_BWD, Mr, K, N, dZp, WpT, t, 2, 1, 4, gin=Gk, P=dXp, PT=dXpT), lambda: torch.mm(dz, w) * Gk),
-            ("bwd_weight", N, K, Mr, lambda: M.gemm(M.EPI_F32, N, K, Mr, dZpT, XpT, t, 2, 0, splits=args.splits, C_out=slabs),
-             lambda: torch.mm(dz.t(), x)),
+            ("bwd_data", Mr, K, N, lambda: M.gemm(M.EPI_BWD, Mr, K, N, dZp, WpT, t, 2, 1, 4, gin=Gk, P=dXp, PT=None if args.pipeline == 3 else dXpT),
+             lambda: torch.mm(dz, w) * Gk),
+            ("bwd_weight", N, K, Mr, (lambda: M.gemm_tn(N, K, Mr, dZp, Xp, t, 2, 0, args.splits, slabs)) if args.pipeline == 3 else
+             (lambda: M.gemm(M.EPI_F32, N, K, Mr, dZpT, XpT, t, 2, 0, splits=args.splits, C_out=slabs)), lambda: torch.mm(dz.t(), x)),
+            ("fwd_nostore", Mr, N, K, lambda: M.gemm(M.EPI_FWD, Mr, N, K, Xp, Wp, t, 0, 1, 3, bias=bias), lambda: None),
         ]
         for name, m_, n_, k_, f_x3, f_32 in cases:
             if name == "bwd_data" and li == 0:
                 continue
-            ms3, ms32 = timeit(f_x3, args.reps), timeit(f_32, args.reps)
+            ms3, ms32 = timeit(f_x3, args.reps), (timeit(f_32, args.reps) if name != "fwd_nostore" else float("nan"))
             fl = 2.0 * m_ * n_ * k_
             row = {"layer": li, "op": name, "M": m_, "N": n_, "K": k_, "f16x3_ms": ms3, "torch_f32_ms": ms32, "f16x3_tflops_f32eq": fl / ms3 / 1e9,
                    "f16x3_mfma_tflops": 3 * fl / ms3 / 1e9, "mfma_frac_of_2500": 3 * fl / ms3 / 1e9 / 2500.0, "torch_f32_tflops": fl / ms32 / 1e9}
