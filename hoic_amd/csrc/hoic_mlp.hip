@@ -206,29 +206,52 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
   const unsigned N = (unsigned)a.N;
   const unsigned lane_off = (unsigned)mb * N + (unsigned)(nb + l31) + 4u * (unsigned)hf * N;
   float vmax = 0.f;
+  const float* __restrict__ Gin = a.Gin;
+  float* __restrict__ Gout = a.Gout;
+  float* __restrict__ Hf = a.Hf32;
+  unsigned* __restrict__ P32 = (unsigned*)a.P;
 #pragma unroll
   for (int j = 0; j < TN; j++) {
     const float bj = (EPI == EPI_FWD) ? a.bias[nb + 32 * j + l31] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
-      __builtin_amdgcn_sched_barrier(0);        // one 32 x 32 tile at a time
+      // half a 32 x 32 tile at a time, in batches: 8 loads in flight, then the arithmetic, then 32 lane exchanges in flight,
+      // then the stores (element by element every access would wait for the one before it)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const unsigned o = lane_off + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * N + 32u * j;
-        float v;
-        if (EPI == EPI_FWD) {
-          float dq;
-          gelu_pair(fmaf(alpha, acc[i][j][r], bj), v, dq);
-          if (a.Gout) a.Gout[o] = dq;
-        } else {
-          v = alpha * acc[i][j][r] * a.Gin[o];
+      for (int hb = 0; hb < 2; hb++) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned o[8];
+        float v[8], gq[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int r = 8 * hb + q;
+          o[q] = lane_off + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * N + 32u * j;
+          if (EPI == EPI_BWD) gq[q] = Gin[o[q]];
         }
-        if (a.Hf32) a.Hf32[o] = v;
-        vmax = fmaxf(vmax, fabsf(v));
-        if (a.P) {
-          const unsigned w = pack_hl(v * so);
-          const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(src0, (int)w), w1 = (unsigned)__builtin_amdgcn_ds_bpermute(src1, (int)w);
-          ((unsigned*)a.P)[o] = __builtin_amdgcn_perm(w1, w0, sel);
+        if (EPI == EPI_BWD) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (EPI == EPI_FWD) gelu_pair(fmaf(alpha, acc[i][j][8 * hb + q], bj), v[q], gq[q]);
+          else v[q] = alpha * acc[i][j][8 * hb + q] * gq[q];
+          vmax = fmaxf(vmax, fabsf(v[q]));
+        }
+        if (P32) {
+          unsigned w0[8], w1[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const unsigned w = pack_hl(v[q] * so);
+            w0[q] = (unsigned)__builtin_amdgcn_ds_bpermute(src0, (int)w); w1[q] = (unsigned)__builtin_amdgcn_ds_bpermute(src1, (int)w);
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++) P32[o[q]] = __builtin_amdgcn_perm(w1[q], w0[q], sel);
+        }
+        if (EPI == EPI_FWD && Gout) {
+#pragma unroll
+          for (int q = 0; q < 8; q++) Gout[o[q]] = gq[q];
+        }
+        if (Hf) {
+#pragma unroll
+          for (int q = 0; q < 8; q++) Hf[o[q]] = v[q];
         }
       }
     }
