@@ -72,7 +72,9 @@ def valu_roofline(kernel_ms, envs_per_launch):
     wc = float(c.get("SQ_WAVE_CYCLES", 0)) or None
     out = {"bound": "valu-issue", "achieved": achieved, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-ops/s", "frac": achieved / VALU_PEAK_LANE_OPS,
            "valu_insts_per_env_step": c["SQ_INSTS_VALU"], "source": name,
-           "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)) if ("SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU")) else None}
+           "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)) if ("SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_INSTS_VALU")) else None}
+    if out["active_lane_fraction"]:      # lanes that carried work: the issue slots above count idle lanes as used
+        out["achieved_active"] = achieved * out["active_lane_fraction"]; out["frac_active"] = out["achieved_active"] / VALU_PEAK_LANE_OPS
     if wc:
         out.update({"wave_quad_cycles_per_env_step": wc, "issuing_frac": c.get("SQ_ACTIVE_INST_ANY", 0) / wc, "waitcnt_frac": c.get("SQ_WAIT_ANY", 0) / wc,
                     "issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0) / wc})
@@ -162,6 +164,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="train", choices=["train", "grasp"],
                     help="train: the sampler's own episode draws; grasp: episodes start at frames >= 100 (object in the hand: contact-rich)")
+    ap.add_argument("--pretrain", type=int, default=0,
+                    help="untimed PPO iterations before the warm-up: the timed region then runs a policy that tracks the motions and holds "
+                         "the object (contact-rich) instead of the random initial policy")
     ap.add_argument("--overlap", type=int, default=0, help="1: value-network steps on a side stream under the next rollout (f16x3 only; measured: no gain, the GEMM workgroups take the CUs' LDS); 0: serial")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,6 +215,8 @@ def main():
         torch.cuda.synchronize()
 
     epoch = 0
+    for _ in range(args.pretrain):
+        agent.optimize_policy(epoch, save_model=False); epoch += 1
     for _ in range(n_warm_it):
         agent.optimize_policy(epoch, save_model=False); epoch += 1
     agent.env.sim.enable_timing(True)
@@ -258,8 +265,9 @@ def main():
             "dtype": dtype_txt, "data": "synthetic",
             "config": {"workload": f"{args.obj.capitalize()}, {args.envs} parallel envs per GPU, HIP batched sim "
                                    f"+ PyTorch-ROCm PPO (whole loop: rollout + GAE + {cfg.num_optim_epoch} full-batch epochs)"
-                                   + ("; episodes start at frames >= 100 (grasp phase, contact-rich)" if args.workload == "grasp" else ""),
-                       "envs_per_gpu": args.envs, "steps_per_iteration": steps_per_iter, "timed_iterations": n_it,
+                                   + ("; episodes start at frames >= 100 (grasp phase, contact-rich)" if args.workload == "grasp" else "")
+                                   + (f"; policy after {args.pretrain} untimed PPO iterations (tracks the motions, holds the object)" if args.pretrain else ""),
+                       "envs_per_gpu": args.envs, "pretrain_iterations": args.pretrain, "steps_per_iteration": steps_per_iter, "timed_iterations": n_it,
                        "samples_per_iteration": steps_per_iter * args.envs * world, "parallelism": f"env-dp{world}",
                        "rollout_env_ranges": n_groups, "update_gemms": args.update_dtype,
                        "value_update_overlaps_next_rollout": bool(agent.learner.overlap_value_update),

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--splits", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-update", action="store_true")
+    ap.add_argument("--ops", default=None, help="comma list of the ops to time (default all)")
+    ap.add_argument("--dims", default="640x2048,2048x1024,1024x512", help="KxN of the layers to time (multiples of 256)")
     ap.add_argument("--pipeline", type=int, default=1, help="0: plain main loop, 1: software-pipelined (default)")
     args = ap.parse_args()
     import torch
@@ -48,7 +50,7 @@ def main():
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
     t = M.ScaleTable(dev)
     res = {"rows": Mr, "pipeline": args.pipeline, "gemms": []}
-    dims = [(640, 2048), (2048, 1024), (1024, 512)]
+    dims = [tuple(int(v) for v in d.split("x")) for d in args.dims.split(",")]
 
     def pk(x, slot, Rp, Cp, **kw):
         return M.pack(x, t, slot, Rp, Cp, **kw)
@@ -76,7 +78,7 @@ def main():
             ("fwd_nostore", Mr, N, K, lambda: M.gemm(M.EPI_FWD, Mr, N, K, Xp, Wp, t, 0, 1, 3, bias=bias), lambda: None),
         ]
         for name, m_, n_, k_, f_x3, f_32 in cases:
-            if name == "bwd_data" and li == 0:
+            if (name == "bwd_data" and li == 0 and args.ops is None) or (args.ops and name not in args.ops.split(",")):
                 continue
             ms3, ms32 = timeit(f_x3, args.reps), (timeit(f_32, args.reps) if name != "fwd_nostore" else float("nan"))
             fl = 2.0 * m_ * n_ * k_
