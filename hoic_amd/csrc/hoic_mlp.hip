@@ -89,6 +89,7 @@ struct GemmArgs {
   float* Hf32;                    // optional [M x N] float32 copy of the output
   u16* P;                         // optional packed output [M x 2N]
   u16* PT;                        // optional packed transposed output [N x 2M]
+  float* colpart;                 // optional (BWD, D[m][n] epilogue): [M / 128][N] column sums of the output per 128-row chunk
 };
 
 template <int BN> struct Cfg {
@@ -213,6 +214,7 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
 #pragma unroll
   for (int j = 0; j < TN; j++) {
     const float bj = (EPI == EPI_FWD) ? a.bias[nb + 32 * j + l31] : 0.f;
+    float csum = 0.f;      // this lane's column over the wavefront's 128 rows (its half of them): the bias gradient's partial sum
 #pragma unroll
     for (int i = 0; i < TM; i++) {
       // half a 32 x 32 tile at a time, in batches: 8 loads in flight, then the arithmetic, then 32 lane exchanges in flight,
@@ -234,6 +236,7 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
           if (EPI == EPI_FWD) gelu_pair(fmaf(alpha, acc[i][j][8 * hb + q], bj), v[q], gq[q]);
           else v[q] = alpha * acc[i][j][8 * hb + q] * gq[q];
           vmax = fmaxf(vmax, fabsf(v[q]));
+          if (EPI == EPI_BWD) csum += v[q];
         }
         if (P32) {
           unsigned w0[8], w1[8];
@@ -254,6 +257,11 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
           for (int q = 0; q < 8; q++) Hf[o[q]] = v[q];
         }
       }
+    }
+    if (EPI == EPI_BWD && a.colpart) {      // TM * 32 = 128 rows per wavefront: chunk mb / 128, fixed order => deterministic
+      static_assert(TM == 4, "column partials are per 128-row chunk");
+      csum += __shfl_xor(csum, 32);
+      if (hf == 0) a.colpart[(size_t)(mb >> 7) * N + nb + 32 * j + l31] = csum;
     }
   }
   if (a.amax) {
@@ -726,7 +734,7 @@ template <int BN, int EPI> static int32_t launch_gemm(const GemmArgs& a, int spl
 extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps,
                                  float* d_amax, int32_t slot_a, int32_t slot_b, int32_t slot_out, float extra_scale, int32_t splits,
                                  float* d_C, const float* d_bias, const float* d_gin, float* d_gout, float* d_hf32, void* d_P, void* d_PT,
-                                 void* stream) {
+                                 float* d_colpart, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (M & 255) || (N & 127) || (K & 31) || !d_A || !d_B || splits < 1) {
     hoic_set_error("hoic_mlp_gemm: M must be a multiple of 256, N of 128, K of 32"); return HOIC_ERR_ARG;
   }
@@ -734,13 +742,17 @@ extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, c
   if (epi == EPI_FWD && !d_bias) { hoic_set_error("hoic_mlp_gemm: forward epilogue needs the bias"); return HOIC_ERR_ARG; }
   if (epi == EPI_BWD && !d_gin) { hoic_set_error("hoic_mlp_gemm: backward epilogue needs gin"); return HOIC_ERR_ARG; }
   if (epi != EPI_F32 && splits != 1) { hoic_set_error("hoic_mlp_gemm: split-K only with the float32 epilogue"); return HOIC_ERR_ARG; }
+  if (d_colpart && !(epi == EPI_BWD && g_gemm_pipeline == 3 && !d_PT)) {
+    hoic_set_error("hoic_mlp_gemm: column partial sums come from the data-gradient epilogue in D[m][n] form (pipeline mode 3, no transposed output)");
+    return HOIC_ERR_ARG;
+  }
   const int nkt = K / 32;
   GemmArgs a{};
   a.A = (const u16*)d_A; a.B = (const u16*)d_B; a.M = M; a.N = N; a.K = K;
   a.kt_per_split = (nkt + splits - 1) / splits;
   a.exps = d_exps; a.amax = d_amax; a.ea = slot_a; a.eb = slot_b; a.eo = slot_out; a.extra_scale = extra_scale;
   a.C = d_C; a.c_split_stride = (long long)M * N; a.bias = d_bias; a.Gin = d_gin; a.Gout = d_gout; a.Hf32 = d_hf32;
-  a.P = (u16*)d_P; a.PT = (u16*)d_PT;
+  a.P = (u16*)d_P; a.PT = (u16*)d_PT; a.colpart = d_colpart;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 256) == 0;
   if (epi == EPI_F32) return wide ? launch_gemm<256, EPI_F32>(a, splits, st) : launch_gemm<128, EPI_F32>(a, splits, st);
@@ -796,6 +808,48 @@ __global__ void hoic_colsum_finish_kernel(const float* __restrict__ part, int nc
   for (int k = 0; k < nchunks; k++) t += part[(long long)k * Cc + c];
   out[c] = ldexpf(t, -(exps ? exps[slot] : 0));
 }
+// max |x * y| and the column sums of x * y per 128-row chunk in ONE pass over the two float32 arrays [R x C] (the last layer's
+// dZ = dH * GELU'): block = 256 columns x one chunk, thread = column, rows in order => deterministic partials
+__global__ __launch_bounds__(256) void hoic_amax_colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, int R, int Cc, float* __restrict__ amax,
+                                                               int slot, float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * 128, r1 = min(R, r0 + 128);
+  float m = 0.f, s = 0.f;
+  if (c < Cc) {
+#pragma unroll 8
+    for (int r = r0; r < r1; r++) {
+      const float v = x[(long long)r * Cc + c] * y[(long long)r * Cc + c];
+      m = fmaxf(m, fabsf(v)); s += v;
+    }
+    part[(long long)blockIdx.y * Cc + c] = s;
+  }
+  m = wave_max_f(m);
+  if ((threadIdx.x & 63) == 0 && amax) atomicMax((unsigned*)(amax + slot), __float_as_uint(m));
+}
+// out[c] = sum over the chunks of part[chunk][c]: 64 columns x 4 chunk phases per block, fixed order
+__global__ __launch_bounds__(256) void hoic_colpart_finish_kernel(const float* __restrict__ part, int nchunks, int Cc, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float t = 0.f;
+  if (c < Cc)
+    for (int k = ph; k < nchunks; k += 4) t += part[(long long)k * Cc + c];
+  red[ph][cl] = t;
+  __syncthreads();
+  if (ph == 0 && c < Cc) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+extern "C" int32_t hoic_mlp_amax_colsum(const float* d_x, const float* d_mul, int32_t R, int32_t C, float* d_amax, int32_t slot, float* d_part,
+                                        void* stream) {
+  if (!d_x || !d_mul || !d_part || R <= 0 || C <= 0) { hoic_set_error("hoic_mlp_amax_colsum: bad arguments"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_amax_colsum_kernel, dim3((C + 255) / 256, (R + 127) / 128), dim3(256), 0, (hipStream_t)stream, d_x, d_mul, R, C, d_amax, slot, d_part);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_mlp_colpart_finish(const float* d_part, int32_t nchunks, int32_t C, float* d_out, void* stream) {
+  if (!d_part || !d_out || nchunks <= 0 || C <= 0) { hoic_set_error("hoic_mlp_colpart_finish: bad arguments"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, d_part, nchunks, C, d_out);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
 extern "C" int32_t hoic_mlp_colsum_packed(const void* d_P, int32_t R, int32_t C, float* d_out, float* d_scratch, const int32_t* d_exps, int32_t slot,
                                           void* stream) {
   if (!d_P || !d_out || !d_scratch || R <= 0 || C <= 0 || (C & 7)) { hoic_set_error("hoic_mlp_colsum_packed: bad arguments"); return HOIC_ERR_ARG; }

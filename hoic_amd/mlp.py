@@ -59,7 +59,7 @@ class _Kernels:
     def __init__(self):
         L = lib.load()
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-        L.hoic_mlp_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.hoic_mlp_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.hoic_mlp_pack.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, i32, vp, i32, vp]
         L.hoic_mlp_amax.argtypes = [vp, vp, i64, vp, i32, vp]
         L.hoic_mlp_update_exps.argtypes = [vp, vp, i32, C.c_uint64, i32, vp, vp]
@@ -68,8 +68,10 @@ class _Kernels:
         L.hoic_mlp_set_pipeline.argtypes = [i32]
         L.hoic_mlp_gemm_tn.argtypes = [i32, i32, i32, vp, vp, vp, i32, i32, f32, i32, vp, vp]
         L.hoic_mlp_colsum_packed.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
+        L.hoic_mlp_amax_colsum.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+        L.hoic_mlp_colpart_finish.argtypes = [vp, i32, i32, vp, vp]
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
-                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed"):
+                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish"):
             getattr(L, n).restype = i32
         self.L = L
 
@@ -154,11 +156,13 @@ def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None
 
 
 def gemm(epi, M, N, K_, A, B, table, sa, sb, so=0, extra_scale=1.0, splits=1, C_out=None, bias=None, gin=None, gout=None, hf32=None,
-         P=None, PT=None):
+         P=None, PT=None, colpart=None):
+    """``colpart``: float32 [M / 128, N] receiving the column sums of the data-gradient output per 128-row chunk (mode 3)"""
     Kn = kernels()
     dev = A.device
     Kn.chk(Kn.L.hoic_mlp_gemm(epi, M, N, K_, _ptr(A), _ptr(B), _ptr(table.exps), _ptr(table.amax), sa, sb, so, float(extra_scale), splits,
-                              _ptr(C_out), _ptr(bias), _ptr(gin), _ptr(gout), _ptr(hf32), _ptr(P), _ptr(PT), _stream(dev)), "hoic_mlp_gemm")
+                              _ptr(C_out), _ptr(bias), _ptr(gin), _ptr(gout), _ptr(hf32), _ptr(P), _ptr(PT), _ptr(colpart), _stream(dev)),
+           "hoic_mlp_gemm")
 
 
 def gemm_tn(M, N, K_, A, B, table, sa, sb, splits, C_out, extra_scale=1.0):
@@ -259,7 +263,8 @@ class SplitMLP:
         if self.rows_layout:
             self.HpT, self.dZpT = [None] * (L - 1), [None] * L
             self.dZp = [h(Mp, n) for n in self.dims_out]
-            self.colsum_scratch = torch.empty(((Mp + 511) // 512) * max(self.dims_out), dtype=torch.float32, device=dev)
+            # bias gradients: column sums of dZ per 128-row chunk, written by the kernel that produces dZ
+            self.colpart = [torch.empty(Mp // 128, n, dtype=torch.float32, device=dev) for n in self.dims_out]
         else:
             self.HpT = [h(n, Mp) for n in self.dims_out[:-1]]
             self.dZp = [None] + [h(Mp, n) for n in self.dims_out[1:]]      # rows: operand of the data-gradient GEMM (layers >= 1)
@@ -317,9 +322,14 @@ class SplitMLP:
         dH = dH.contiguous()
         s_last = self.SLOT_DZ0 + L - 1
         # dZ_last = dH * GELU'(z_last): exponent from its own maximum, then rows (data gradient) and transpose (weights)
-        t.measure(s_last, dH, self.G[-1]); t.update([s_last])
-        P, PT = self.dZp[L - 1], self.dZpT[L - 1]
         Kn = kernels()
+        if self.rows_layout:      # the maximum and the bias gradient's partial sums in one pass over dH and GELU'
+            Kn.chk(Kn.L.hoic_mlp_amax_colsum(_ptr(dH), _ptr(self.G[-1]), Mp, self.dims_out[-1], _ptr(t.amax), s_last, _ptr(self.colpart[-1]),
+                                             _stream(self.dev)), "hoic_mlp_amax_colsum")
+        else:
+            t.measure(s_last, dH, self.G[-1])
+        t.update([s_last])
+        P, PT = self.dZp[L - 1], self.dZpT[L - 1]
         Kn.chk(Kn.L.hoic_mlp_pack(_ptr(dH), _ptr(self.G[-1]), Mp, self.dims_out[-1], self.dims_out[-1], _ptr(P if (L > 1 or self.rows_layout) else None),
                                   _ptr(PT), Mp, self.dims_out[-1], _ptr(t.exps), s_last, _stream(self.dev)), "hoic_mlp_pack")
         if self.first_bwd:      # first backward pass: the hidden-layer gradients start at the loss-side exponent
@@ -331,7 +341,8 @@ class SplitMLP:
             t.update([self.SLOT_DZ0 + i for i in range(L - 1)])
         for i in range(L - 1, 0, -1):          # dZ_{i-1} = (dZ_i W_i) * GELU'(z_{i-1})
             gemm(EPI_BWD, Mp, self.dims_out[i - 1], self.dims_out[i], self.dZp[i], self.WpT[i], t, self.SLOT_DZ0 + i, self.SLOT_W0 + i,
-                 self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1])       # (rows layout: dZpT entries are None)
+                 self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1],       # (rows layout: dZpT entries are None)
+                 colpart=self.colpart[i - 1] if self.rows_layout else None)
         for i, l in enumerate(self.layers):    # dW_i = dZ_i^T H_{i-1}, db_i = column sums of dZ_i
             n, kp = self.dims_out[i], self.Kp[i]
             sp = self.layer_splits[i]
@@ -347,8 +358,7 @@ class SplitMLP:
             Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(self.slabs), sp, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
                                              _stream(self.dev)), "hoic_mlp_slab_reduce")
             if self.rows_layout:
-                Kn.chk(Kn.L.hoic_mlp_colsum_packed(_ptr(self.dZp[i]), Mp, n, _ptr(l.bias.grad), _ptr(self.colsum_scratch), _ptr(t.exps),
-                                                   self.SLOT_DZ0 + i, _stream(self.dev)), "hoic_mlp_colsum_packed")
+                Kn.chk(Kn.L.hoic_mlp_colpart_finish(_ptr(self.colpart[i]), Mp // 128, n, _ptr(l.bias.grad), _stream(self.dev)), "hoic_mlp_colpart_finish")
             else:
                 Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
                        "hoic_mlp_rowsum_packed")

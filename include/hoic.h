@@ -183,6 +183,8 @@ int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64
  *   [splits][M x N] (split-K slabs over blockIdx.y);  epi 1 (forward layer): v = gelu(C + bias[n]) -> optional
  *   float32 d_hf32, packed d_P [M x 2N] and transposed d_PT [N x 2M] at 2^d_exps[slot_out], gelu'(.) -> d_gout;
  *   epi 2 (data gradient): v = C * d_gin[m][n] -> d_P / d_PT likewise.  Epilogues 1, 2 fold max |v| into d_amax[slot_out].
+ *   d_colpart (optional, epi 2 in pipeline mode 3 without d_PT): [M / 128][N] float32, the column sums of v over each
+ *   128-row chunk (the bias gradient's partial sums; every entry written by exactly one wavefront in fixed order).
  * hoic_mlp_slab_reduce: out[r][c] = scale * sum_s slabs[s][r][c] for c < out_cols (fixed order: deterministic).
  * hoic_mlp_rowsum_packed: out[r] = 2^-e * sum_c (hi + lo)[r][c] of a packed [rows x 2 Cp] tensor (bias gradients). */
 int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R, int32_t C, int64_t ld, void* d_P, void* d_PT, int32_t Rp,
@@ -192,13 +194,17 @@ int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uin
                              void* stream);
 int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps,
                       float* d_amax, int32_t slot_a, int32_t slot_b, int32_t slot_out, float extra_scale, int32_t splits, float* d_C,
-                      const float* d_bias, const float* d_gin, float* d_gout, float* d_hf32, void* d_P, void* d_PT, void* stream);
+                      const float* d_bias, const float* d_gin, float* d_gout, float* d_hf32, void* d_P, void* d_PT, float* d_colpart,
+                      void* stream);
 /* hoic_mlp_gemm_tn: C[i][j] = extra_scale 2^-(e_a + e_b) sum_m A[m][i] B[m][j] with BOTH operands row-major over the
  * contraction (sample) index m: A [K x 2M], B [K x 2N] packed along their columns (M % 256 == N % 128 == K % 32 == 0) ->
  * float32 slabs d_C [splits][M x N].  The weight gradient dW = dZ^T H from the activations / gradients as the other
  * epilogues wrote them (LDS transposing reads, ds_read_b64_tr_b16).
  * hoic_mlp_colsum_packed: out[c] = 2^-e sum_r (hi + lo)[r][c] of a packed row-major [R x 2C] tensor (bias gradients);
  * d_scratch holds ceil(R / 512) * C floats; fixed summation order.
+ * hoic_mlp_amax_colsum: one pass over two float32 arrays [R x C]: d_amax[slot] = max(., max |x * mul|) and
+ *   d_part[ceil(R / 128)][C] = column sums of x * mul per 128-row chunk (the last layer's dZ = dH * gelu').
+ * hoic_mlp_colpart_finish: out[c] = sum over the chunks of d_part[chunk][c] (fixed order: deterministic).
  * hoic_mlp_set_pipeline: kernel variant of hoic_mlp_gemm (measurement aid; 3 = default): 0 plain loop, 1 software-pipelined
  * 8-wavefront kernel, 2 4-wavefront 256 x 128 kernel with K stages of 16 and two workgroups per CU, 3 = 2 with D[m][n]
  * accumulators for epilogues 1, 2 when no transposed output is requested (full-line stores). */
@@ -206,6 +212,9 @@ int32_t hoic_mlp_gemm_tn(int32_t M, int32_t N, int32_t K, const void* d_A, const
                          int32_t slot_b, float extra_scale, int32_t splits, float* d_C, void* stream);
 int32_t hoic_mlp_colsum_packed(const void* d_P, int32_t R, int32_t C, float* d_out, float* d_scratch, const int32_t* d_exps,
                                int32_t slot, void* stream);
+int32_t hoic_mlp_amax_colsum(const float* d_x, const float* d_mul, int32_t R, int32_t C, float* d_amax, int32_t slot, float* d_part,
+                             void* stream);
+int32_t hoic_mlp_colpart_finish(const float* d_part, int32_t nchunks, int32_t C, float* d_out, void* stream);
 int32_t hoic_mlp_set_pipeline(int32_t mode);
 int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
                              float scale, void* stream);

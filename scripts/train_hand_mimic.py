@@ -44,7 +44,9 @@ def build_parser():
     p.add_argument("--sample_mode", default="fixed", choices=["fixed", "episodes"])
     p.add_argument("--base_dir", default="", help="checkout of the reference (config/, assets/, sample_data/); default: packaged configs and models")
     p.add_argument("--num_epoch", type=int, default=None, help="override cfg.num_epoch (smoke runs)")
-    p.add_argument("--update_dtype", default="f32")
+    p.add_argument("--update_dtype", default="f16x3", choices=["f16x3", "f32", "bf16"],
+                   help="GEMMs of the PPO update: f16x3 = float32 operands as float16 pairs on the matrix cores (float32-class accuracy, "
+                        "hidden sizes must be multiples of 256), f32 = PyTorch float32, bf16 = autocast")
     return p
 
 
