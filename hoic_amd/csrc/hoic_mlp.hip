@@ -406,7 +406,7 @@ template <int EPI, bool MN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_k16_kernel(GemmArgs a) {
   constexpr int TM = 4, TN = 2;
   __shared__ __attribute__((aligned(1024))) char smem[3 * K16_STG];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
   const int ntn = a.N / 128, ntiles = (a.M / 256) * ntn;
   int g = blockIdx.x;
   {
@@ -430,65 +430,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   struct Frags { h8 ah[TM], al[TM], bh[TN], bl[TN]; };
-  auto load_frags = [&](int t_, Frags& f) {
-    const char* stg = smem + (t_ % 3) * K16_STG;
-#pragma unroll
-    for (int j = 0; j < TN; j++) read_frag16(stg + 256 * 64, nw + j * 32 + l31, hf, f.bh[j], f.bl[j]);
-#pragma unroll
-    for (int i = 0; i < TM; i++) read_frag16(stg, mw + i * 32 + l31, hf, f.ah[i], f.al[i]);
-  };
-  auto mma = [&](const Frags& f) {
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        if (MN) {      // D[m][n]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-        } else {       // D[n][m]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
-        }
-      }
-  };
-  auto stage = [&](int t_) {
-    char* dst = smem + (t_ % 3) * K16_STG;
-    stage_rows16<256>(Ag + (size_t)t_ * 64, rowbytes, dst, wave, lane);          // 4 DMA pieces per lane
-    stage_rows16<128>(Bg + (size_t)t_ * 64, rowbytes, dst + 256 * 64, wave, lane);   // 2
-  };
+  // LDS byte offsets of this lane's first A / B fragment inside a stage (row * 64 + swizzled chunk); the lo halves sit in the
+  // neighbouring chunk (offset ^ 16), fragment q of an operand 32 rows = 2048 bytes further (same swizzle: 32 rows = 8 groups of 4)
+  const int rowA = mw + l31, rowB = nw + l31;
+  const int fA = rowA * 64 + (((2 * hf) ^ ((rowA >> 2) & 3)) << 4), fB = 256 * 64 + rowB * 64 + (((2 * hf) ^ ((rowB >> 2) & 3)) << 4);
+  const int fA1 = fA ^ 16, fB1 = fB ^ 16;
+  // source of DMA piece pc (0..3: A rows, 4, 5: B rows): piece i covers rows (4 i + wave) * 16 + lane / 4 -- everything but
+  // the lane's own part is wave-uniform, so the address is a scalar base + ONE 32-bit per-lane offset shared by all pieces
+  const unsigned voff = (unsigned)(lane >> 2) * (unsigned)rowbytes + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  const size_t piece_rows = (size_t)16 * rowbytes;     // bytes between the row groups of consecutive wavefronts
+#define K16_RD(Fx, Q, STG)                                                                                              \
+  {                                                                                                                     \
+    if ((Q) < TN) {                                                                                                     \
+      Fx.bh[(Q) < TN ? (Q) : 0] = *(const h8*)((STG) + fB + (Q) * 2048); Fx.bl[(Q) < TN ? (Q) : 0] = *(const h8*)((STG) + fB1 + (Q) * 2048);         \
+    } else {                                                                                                            \
+      Fx.ah[(Q) >= TN ? (Q) - TN : 0] = *(const h8*)((STG) + fA + ((Q) - TN) * 2048);                                     \
+      Fx.al[(Q) >= TN ? (Q) - TN : 0] = *(const h8*)((STG) + fA1 + ((Q) - TN) * 2048);                                    \
+    }                                                                                                                   \
+  }
+#define K16_DMA(PC, SRC, BUF)                                                                                           \
+  __builtin_amdgcn_global_load_lds(GLB_PTR(((PC) < 4 ? Ag : Bg) + ((size_t)((((PC) < 4 ? (PC) : (PC) - 4)) * 4 + wave)) * piece_rows + (size_t)(SRC) * 64 + voff), \
+                                   LDS_PTR(smem + (BUF) + ((PC) < 4 ? 0 : 256 * 64) + ((((PC) < 4 ? (PC) : (PC) - 4)) * 4 + wave) * 1024), 16, 0, 0);
+  // MFMA k of a step (0..23): product k / 8 (hi.lo, lo.hi, hi.hi), tile (k % 8) / 2, (k % 8) % 2 -- eight different
+  // accumulators in a row, so no MFMA waits for the one before it
+#define K16_MF(Fx, KK)                                                                                                  \
+  {                                                                                                                     \
+    constexpr int p_ = (KK) / 8, i_ = ((KK) % 8) / 2, j_ = (KK) % 2;                                                    \
+    const h8 av_ = (p_ == 1) ? Fx.al[i_] : Fx.ah[i_], bv_ = (p_ == 0) ? Fx.bl[j_] : Fx.bh[j_];                            \
+    if (MN) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av_, bv_, acc[i_][j_], 0, 0, 0);                          \
+    else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv_, av_, acc[i_][j_], 0, 0, 0);                             \
+  }
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define K16_MMA_ALL(Fx)                                                                                                 \
+  K16_MF(Fx, 0) K16_MF(Fx, 1) K16_MF(Fx, 2) K16_MF(Fx, 3) K16_MF(Fx, 4) K16_MF(Fx, 5) K16_MF(Fx, 6) K16_MF(Fx, 7)         \
+  K16_MF(Fx, 8) K16_MF(Fx, 9) K16_MF(Fx, 10) K16_MF(Fx, 11) K16_MF(Fx, 12) K16_MF(Fx, 13) K16_MF(Fx, 14) K16_MF(Fx, 15)   \
+  K16_MF(Fx, 16) K16_MF(Fx, 17) K16_MF(Fx, 18) K16_MF(Fx, 19) K16_MF(Fx, 20) K16_MF(Fx, 21) K16_MF(Fx, 22) K16_MF(Fx, 23)
+  const int last = nkt - 1;
   if (nkt > 0) {
-    stage(0);
-    if (nkt > 1) stage(1);
-    if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0076); else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(6) / vmcnt(0): stage 0 landed
+#pragma unroll
+    for (int pc = 0; pc < 6; pc++) K16_DMA(pc, 0, 0)
+#pragma unroll
+    for (int pc = 0; pc < 6; pc++) K16_DMA(pc, min(1, last), K16_STG)
+    __builtin_amdgcn_s_waitcnt(0x0076);                                    // vmcnt(6): stage 0 landed
     __builtin_amdgcn_s_barrier();
-    if (nkt > 2) stage(2);
-    Frags F[2];
-    load_frags(0, F[0]);
+#pragma unroll
+    for (int pc = 0; pc < 6; pc++) K16_DMA(pc, min(2, last), 2 * K16_STG)
+    Frags F0, F1;
+    K16_RD(F0, 0, smem) K16_RD(F0, 1, smem) K16_RD(F0, 2, smem) K16_RD(F0, 3, smem) K16_RD(F0, 4, smem) K16_RD(F0, 5, smem)
     __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0)
-    int t = 0;
-    // two stages per trip so that the two fragment sets are addressed statically
-#define K16_STEP(CUR, NXT)                                                                                              \
+    int t = 0, ob = 0;         // ob: byte offset of the LDS buffer that holds stage t (and receives stage t + 3)
+    // One step, written out instruction by instruction (a scheduling fence after each item, so the order below IS the
+    // issue order): the LDS reads of stage t + 1 and the DMA pieces of stage t + 3 (clamped to the last stage: a step past
+    // the end re-fetches it into a free buffer, so every step issues the same 6 pieces and one counted wait fits all)
+    // go out in the shadow of this wavefront's own MFMAs of stage t.  Before, loads and MFMAs were separate phases and
+    // the two wavefronts of a SIMD idled through their load phases together (matrix cores busy 60 % of the loop).
+#define K16_STEP(Fc, Fn)                                                                                                \
     {                                                                                                                   \
-      if (t + 1 < nkt) {                                                                                                \
-        if (t + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0076); else __builtin_amdgcn_s_waitcnt(0x0070);                  \
-        __builtin_amdgcn_s_barrier();        /* stage t+1 landed everywhere; buffer t % 3 is read out */                \
-        if (t + 3 < nkt) stage(t + 3);       /* into buffer (t + 3) % 3 == t % 3 */                                      \
-        load_frags(t + 1, F[NXT]);                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-      }                                                                                                                 \
-      mma(F[CUR]);                                                                                                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                                \
-      __builtin_amdgcn_s_waitcnt(0xc07f);    /* lgkmcnt(0): the next fragments arrived under the MFMAs */               \
-      t++;                                                                                                              \
+      __builtin_amdgcn_s_waitcnt(0x0076);    /* vmcnt(6): stage t+1 landed (t+2's pieces may stay in flight) */         \
+      __builtin_amdgcn_s_barrier();          /* ... everywhere; buffer t % 3 is read out */                             \
+      SB                                                                                                                \
+      const int src_ = min(t + 3, last);                                                                                \
+      const int on_ = (ob == 2 * K16_STG) ? 0 : ob + K16_STG;      /* buffer of stage t + 1 */                             \
+      const char* nx_ = smem + on_;                                                                                     \
+      K16_MF(Fc, 0) SB K16_RD(Fn, 0, nx_) SB K16_MF(Fc, 1) SB K16_RD(Fn, 1, nx_) SB K16_MF(Fc, 2) SB K16_RD(Fn, 2, nx_) SB  \
+      K16_MF(Fc, 3) SB K16_RD(Fn, 3, nx_) SB K16_MF(Fc, 4) SB K16_RD(Fn, 4, nx_) SB K16_MF(Fc, 5) SB K16_RD(Fn, 5, nx_) SB  \
+      K16_MF(Fc, 6) SB K16_DMA(0, src_, ob) SB K16_MF(Fc, 7) K16_MF(Fc, 8) K16_MF(Fc, 9) SB                              \
+      K16_DMA(1, src_, ob) SB K16_MF(Fc, 10) K16_MF(Fc, 11) K16_MF(Fc, 12) SB                                            \
+      K16_DMA(2, src_, ob) SB K16_MF(Fc, 13) K16_MF(Fc, 14) K16_MF(Fc, 15) SB                                            \
+      K16_DMA(3, src_, ob) SB K16_MF(Fc, 16) K16_MF(Fc, 17) K16_MF(Fc, 18) SB                                            \
+      K16_DMA(4, src_, ob) SB K16_MF(Fc, 19) K16_MF(Fc, 20) K16_MF(Fc, 21) SB                                            \
+      K16_DMA(5, src_, ob) SB K16_MF(Fc, 22) K16_MF(Fc, 23) SB                                                          \
+      __builtin_amdgcn_s_waitcnt(0xc07f);    /* lgkmcnt(0): the next fragments arrived long ago */                      \
+      t++; ob = on_;                                                                                                    \
     }
-    while (t < nkt) {
-      K16_STEP(0, 1)
-      if (t < nkt) K16_STEP(1, 0)
+    while (t + 2 <= last) {      // two steps per trip: the two fragment sets are addressed statically
+      K16_STEP(F0, F1)
+      K16_STEP(F1, F0)
+    }
+    if (t < last) {
+      K16_STEP(F0, F1)
+      K16_MMA_ALL(F1)
+    } else {
+      K16_MMA_ALL(F0)
     }
 #undef K16_STEP
+    __builtin_amdgcn_s_waitcnt(0x0070);      // the clamped re-fetches of the last steps
   }
+#undef SB
+#undef K16_MMA_ALL
+#undef K16_MF
+#undef K16_DMA
+#undef K16_RD
   if (MN) gemm_epilogue_mn<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, lane);
   else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, split, lane);
 }
