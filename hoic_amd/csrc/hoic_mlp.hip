@@ -503,16 +503,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_s_waitcnt(0xc07f);    /* lgkmcnt(0): the next fragments arrived long ago */                      \
       t++; ob = on_;                                                                                                    \
     }
-    while (t + 2 <= last) {      // two steps per trip: the two fragment sets are addressed statically
+    // nkt is even (K and the split size are multiples of 32): nkt - 1 steps that prefetch, then the last stage's MFMAs --
+    // ONE tail, so the accumulators keep their registers (two alternative tails met in a join that went through scratch)
+    while (t < last - 1) {       // two steps per trip: the two fragment sets are addressed statically
       K16_STEP(F0, F1)
       K16_STEP(F1, F0)
     }
-    if (t < last) {
-      K16_STEP(F0, F1)
-      K16_MMA_ALL(F1)
-    } else {
-      K16_MMA_ALL(F0)
-    }
+    K16_STEP(F0, F1)
+    K16_MMA_ALL(F1)
 #undef K16_STEP
     __builtin_amdgcn_s_waitcnt(0x0070);      // the clamped re-fetches of the last steps
   }
@@ -568,14 +566,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int RA = 256 * 4, RB = BN * 4, STG = 32 * (RA + RB);
   __shared__ __attribute__((aligned(1024))) char smem[2 * STG];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
-  const int ntn = a.N / BN, ntiles = (a.M / 256) * ntn;
-  int g = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = g & 7, idx = g >> 3;
-    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int ntn = a.N / BN;
+  // XCD-aware order: workgroups go to the XCDs round-robin in launch order, and every block of a sample range (split) reads
+  // the same rows of dZ and H -- so the SPLIT is the fast index: with a split count that is a multiple of 8 all tiles of a
+  // sample range run on one XCD and share its L2 (measured before, tile-major: L2 hit rate 38 %, every B panel fetched by 4 XCDs)
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y, nsplit = gridDim.y;
+  const int split = lin % nsplit, g = lin / nsplit;
   const int i0 = (g / ntn) * 256, j0 = (g % ntn) * BN;
-  const int split = blockIdx.y;
   const int kt0 = split * a.kt_per_split;
   const int nkt = min(a.kt_per_split, a.K / 32 - kt0);
   const size_t lda = (size_t)a.M * 4, ldb = (size_t)a.N * 4;      // bytes per sample row of the packed operands
@@ -690,7 +687,15 @@ __global__ void hoic_pack_rows_mul_kernel(const float* __restrict__ x, const flo
 // max |x * y| (y optional) over a float32 array -> amax[slot] (atomicMax on the float bits; values are non-negative)
 __global__ void hoic_amax_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float* __restrict__ amax, int slot) {
   float m = 0.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+  const long long n4 = ((((size_t)x | (size_t)(y ? y : x)) & 15) == 0) ? (n >> 2) : 0;      // 16-byte aligned: four elements per load
+  const long long stride = (long long)gridDim.x * blockDim.x;
+#pragma unroll 4
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = ((const f32x4*)x)[i];
+    if (y) v = v * ((const f32x4*)y)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (long long i = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float v = x[i]; if (y) v *= y[i];
     m = fmaxf(m, fabsf(v));
   }
@@ -718,7 +723,8 @@ __global__ void hoic_slab_reduce_kernel(const float* __restrict__ slabs, int S, 
   if (gid >= (long long)rows * out_cols) return;
   const int r = (int)(gid / out_cols), c = (int)(gid % out_cols);
   float s = 0.f;
-  for (int k = 0; k < S; k++) s += slabs[(long long)k * stride + (long long)r * cols + c];
+#pragma unroll 8
+  for (int k = 0; k < S; k++) s += slabs[(long long)k * stride + (long long)r * cols + c];      // fixed order; the loads are independent
   out[(long long)r * ldo + c] = s * scale;
 }
 // row sums of a packed [rows x 2 Cp] tensor (hi + lo), unscaled by 2^-exps[slot]: the bias gradient from dZ^T.
@@ -857,16 +863,23 @@ __global__ __launch_bounds__(256) void hoic_amax_colsum_kernel(const float* __re
   m = wave_max_f(m);
   if ((threadIdx.x & 63) == 0 && amax) atomicMax((unsigned*)(amax + slot), __float_as_uint(m));
 }
-// out[c] = sum over the chunks of part[chunk][c]: 64 columns x 4 chunk phases per block, fixed order
-__global__ __launch_bounds__(256) void hoic_colpart_finish_kernel(const float* __restrict__ part, int nchunks, int Cc, float* __restrict__ out) {
-  __shared__ float red[4][64];
+// out[c] = sum over the chunks of part[chunk][c]: 64 columns x 16 chunk phases per block, fixed order
+__global__ __launch_bounds__(1024) void hoic_colpart_finish_kernel(const float* __restrict__ part, int nchunks, int Cc, float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float t = 0.f;
-  if (c < Cc)
-    for (int k = ph; k < nchunks; k += 4) t += part[(long long)k * Cc + c];
+  if (c < Cc) {
+#pragma unroll 4
+    for (int k = ph; k < nchunks; k += 16) t += part[(long long)k * Cc + c];
+  }
   red[ph][cl] = t;
   __syncthreads();
-  if (ph == 0 && c < Cc) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (ph == 0 && c < Cc) {
+    float u = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) u += red[q][cl];
+    out[c] = u;
+  }
 }
 extern "C" int32_t hoic_mlp_amax_colsum(const float* d_x, const float* d_mul, int32_t R, int32_t C, float* d_amax, int32_t slot, float* d_part,
                                         void* stream) {
@@ -877,7 +890,7 @@ extern "C" int32_t hoic_mlp_amax_colsum(const float* d_x, const float* d_mul, in
 }
 extern "C" int32_t hoic_mlp_colpart_finish(const float* d_part, int32_t nchunks, int32_t C, float* d_out, void* stream) {
   if (!d_part || !d_out || nchunks <= 0 || C <= 0) { hoic_set_error("hoic_mlp_colpart_finish: bad arguments"); return HOIC_ERR_ARG; }
-  hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, d_part, nchunks, C, d_out);
+  hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, d_part, nchunks, C, d_out);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -916,7 +929,7 @@ extern "C" int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R
 
 extern "C" int32_t hoic_mlp_amax(const float* d_x, const float* d_mul, int64_t n, float* d_amax, int32_t slot, void* stream) {
   if (!d_x || n <= 0 || !d_amax) { hoic_set_error("hoic_mlp_amax: bad arguments"); return HOIC_ERR_ARG; }
-  const long long want = (n + 256LL * 16 - 1) / (256LL * 16);        // ~16 elements per thread: a weight matrix takes a few hundred workgroups, not 1024
+  const long long want = (n + 256LL * 16 - 1) / (256LL * 16);        // ~16 elements (4 vector loads) per thread: a weight matrix takes a few hundred workgroups, not 1024
   hipLaunchKernelGGL(hoic_amax_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want))), dim3(256), 0, (hipStream_t)stream, d_x, d_mul, (long long)n, d_amax, slot);
   MCHK(hipGetLastError());
   return HOIC_OK;

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--splits", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-update", action="store_true")
+    ap.add_argument("--zero", action="store_true", help="all-zero operands: the same instruction stream at minimum switching power (a lower "
+                    "time than with random data = the kernel runs against the power limit, not against its schedule)")
     ap.add_argument("--ops", default=None, help="comma list of the ops to time (default all)")
     ap.add_argument("--dims", default="640x2048,2048x1024,1024x512", help="KxN of the layers to time (multiples of 256)")
     ap.add_argument("--pipeline", type=int, default=1, help="0: plain main loop, 1: software-pipelined (default)")
@@ -47,7 +49,7 @@ def main():
     M.set_pipeline(args.pipeline)
     Mr = args.rows
     g = torch.Generator(device=dev).manual_seed(0)
-    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    rnd = (lambda *s: torch.zeros(*s, device=dev)) if args.zero else (lambda *s: torch.randn(*s, device=dev, generator=g))
     t = M.ScaleTable(dev)
     res = {"rows": Mr, "pipeline": args.pipeline, "gemms": []}
     dims = [tuple(int(v) for v in d.split("x")) for d in args.dims.split(",")]
