@@ -390,6 +390,69 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // s_barrier] -> issue the DMA of stage t+3 into the buffer stage t was read from -> LDS reads of stage t+1's fragments
 // -> 24 MFMAs on stage t's fragments (already in registers).
 #define K16_STG ((256 + 128) * 64)
+// ---- main loop shared by the 4-wavefront kernels (forward / data gradient: hoic_gemm_f16x3_k16_kernel, weight gradient:
+// hoic_gemm_f16x3_tn16_kernel).  The kernel defines K16_RD(F, q, stage) = LDS reads of fragment q (0, 1: B; 2..5: A) and
+// K16_DMA(piece, source stage, buffer offset) = one LDS-DMA piece (6 per wavefront and stage), declares acc[4][2], Frags,
+// smem, nkt (EVEN: K and the split sizes are multiples of 32) and MN, then expands K16_MAINLOOP.
+// MFMA k of a step (0..23): product k / 8 (hi.lo, lo.hi, hi.hi), tile (k % 8) / 2, (k % 8) % 2 -- eight different
+// accumulators in a row, so no MFMA waits for the one before it
+#define K16_MF(Fx, KK)                                                                                                  \
+  {                                                                                                                     \
+    constexpr int p_ = (KK) / 8, i_ = ((KK) % 8) / 2, j_ = (KK) % 2;                                                    \
+    const h8 av_ = (p_ == 1) ? Fx.al[i_] : Fx.ah[i_], bv_ = (p_ == 0) ? Fx.bl[j_] : Fx.bh[j_];                            \
+    if (MN) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av_, bv_, acc[i_][j_], 0, 0, 0);                          \
+    else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv_, av_, acc[i_][j_], 0, 0, 0);                             \
+  }
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define K16_MMA_ALL(Fx)                                                                                                 \
+  K16_MF(Fx, 0) K16_MF(Fx, 1) K16_MF(Fx, 2) K16_MF(Fx, 3) K16_MF(Fx, 4) K16_MF(Fx, 5) K16_MF(Fx, 6) K16_MF(Fx, 7)         \
+  K16_MF(Fx, 8) K16_MF(Fx, 9) K16_MF(Fx, 10) K16_MF(Fx, 11) K16_MF(Fx, 12) K16_MF(Fx, 13) K16_MF(Fx, 14) K16_MF(Fx, 15)   \
+  K16_MF(Fx, 16) K16_MF(Fx, 17) K16_MF(Fx, 18) K16_MF(Fx, 19) K16_MF(Fx, 20) K16_MF(Fx, 21) K16_MF(Fx, 22) K16_MF(Fx, 23)
+// One step, written out instruction by instruction (a scheduling fence after each item, so the order below IS the issue
+// order): the LDS reads of stage t + 1 and the DMA pieces of stage t + 3 (clamped to the last stage: a step past the end
+// re-fetches it into a free buffer, so every step issues the same 6 pieces and one counted wait fits all) go out in the
+// shadow of this wavefront's own MFMAs of stage t.
+#define K16_STEP(Fc, Fn)                                                                                                \
+    {                                                                                                                   \
+      __builtin_amdgcn_s_waitcnt(0x0076);    /* vmcnt(6): stage t+1 landed (t+2's pieces may stay in flight) */         \
+      __builtin_amdgcn_s_barrier();          /* ... everywhere; buffer t % 3 is read out */                             \
+      SB                                                                                                                \
+      const int src_ = min(t + 3, last);                                                                                \
+      const int on_ = (ob == 2 * K16_STG) ? 0 : ob + K16_STG;      /* buffer of stage t + 1 */                             \
+      const char* nx_ = smem + on_;                                                                                     \
+      K16_MF(Fc, 0) SB K16_RD(Fn, 0, nx_) SB K16_MF(Fc, 1) SB K16_RD(Fn, 1, nx_) SB K16_MF(Fc, 2) SB K16_RD(Fn, 2, nx_) SB  \
+      K16_MF(Fc, 3) SB K16_RD(Fn, 3, nx_) SB K16_MF(Fc, 4) SB K16_RD(Fn, 4, nx_) SB K16_MF(Fc, 5) SB K16_RD(Fn, 5, nx_) SB  \
+      K16_MF(Fc, 6) SB K16_DMA(0, src_, ob) SB K16_MF(Fc, 7) K16_MF(Fc, 8) K16_MF(Fc, 9) SB                              \
+      K16_DMA(1, src_, ob) SB K16_MF(Fc, 10) K16_MF(Fc, 11) K16_MF(Fc, 12) SB                                            \
+      K16_DMA(2, src_, ob) SB K16_MF(Fc, 13) K16_MF(Fc, 14) K16_MF(Fc, 15) SB                                            \
+      K16_DMA(3, src_, ob) SB K16_MF(Fc, 16) K16_MF(Fc, 17) K16_MF(Fc, 18) SB                                            \
+      K16_DMA(4, src_, ob) SB K16_MF(Fc, 19) K16_MF(Fc, 20) K16_MF(Fc, 21) SB                                            \
+      K16_DMA(5, src_, ob) SB K16_MF(Fc, 22) K16_MF(Fc, 23) SB                                                          \
+      __builtin_amdgcn_s_waitcnt(0xc07f);    /* lgkmcnt(0): the next fragments arrived long ago */                      \
+      t++; ob = on_;                                                                                                    \
+    }
+// nkt - 1 steps that prefetch, then the last stage's MFMAs -- ONE tail, so the accumulators keep their registers (two
+// alternative tails met in a join that went through scratch)
+#define K16_MAINLOOP                                                                                                    \
+  const int last = nkt - 1;                                                                                             \
+  if (nkt > 0) {                                                                                                        \
+    _Pragma("unroll") for (int pc = 0; pc < 6; pc++) K16_DMA(pc, 0, 0)                                                  \
+    _Pragma("unroll") for (int pc = 0; pc < 6; pc++) K16_DMA(pc, min(1, last), K16_STG)                                 \
+    __builtin_amdgcn_s_waitcnt(0x0076);      /* vmcnt(6): stage 0 landed */                                             \
+    __builtin_amdgcn_s_barrier();                                                                                       \
+    _Pragma("unroll") for (int pc = 0; pc < 6; pc++) K16_DMA(pc, min(2, last), 2 * K16_STG)                             \
+    Frags F0, F1;                                                                                                       \
+    K16_RD(F0, 0, smem) K16_RD(F0, 1, smem) K16_RD(F0, 2, smem) K16_RD(F0, 3, smem) K16_RD(F0, 4, smem) K16_RD(F0, 5, smem) \
+    __builtin_amdgcn_s_waitcnt(0xc07f);      /* lgkmcnt(0) */                                                           \
+    int t = 0, ob = 0;         /* ob: byte offset of the LDS buffer that holds stage t (and receives stage t + 3) */    \
+    while (t < last - 1) {     /* two steps per trip: the two fragment sets are addressed statically */                 \
+      K16_STEP(F0, F1)                                                                                                  \
+      K16_STEP(F1, F0)                                                                                                  \
+    }                                                                                                                   \
+    K16_STEP(F0, F1)                                                                                                    \
+    K16_MMA_ALL(F1)                                                                                                     \
+    __builtin_amdgcn_s_waitcnt(0x0070);      /* the clamped re-fetches of the last steps */                             \
+  }
 template <int ROWS> __device__ __forceinline__ void stage_rows16(const char* g, size_t rowbytes, char* lds, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < ROWS / 64; i++) {      // 64-byte rows (16 elements): chunk q belongs to row q >> 2, source chunk (q & 3) ^ ((row >> 2) & 3)
@@ -451,72 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define K16_DMA(PC, SRC, BUF)                                                                                           \
   __builtin_amdgcn_global_load_lds(GLB_PTR(((PC) < 4 ? Ag : Bg) + ((size_t)((((PC) < 4 ? (PC) : (PC) - 4)) * 4 + wave)) * piece_rows + (size_t)(SRC) * 64 + voff), \
                                    LDS_PTR(smem + (BUF) + ((PC) < 4 ? 0 : 256 * 64) + ((((PC) < 4 ? (PC) : (PC) - 4)) * 4 + wave) * 1024), 16, 0, 0);
-  // MFMA k of a step (0..23): product k / 8 (hi.lo, lo.hi, hi.hi), tile (k % 8) / 2, (k % 8) % 2 -- eight different
-  // accumulators in a row, so no MFMA waits for the one before it
-#define K16_MF(Fx, KK)                                                                                                  \
-  {                                                                                                                     \
-    constexpr int p_ = (KK) / 8, i_ = ((KK) % 8) / 2, j_ = (KK) % 2;                                                    \
-    const h8 av_ = (p_ == 1) ? Fx.al[i_] : Fx.ah[i_], bv_ = (p_ == 0) ? Fx.bl[j_] : Fx.bh[j_];                            \
-    if (MN) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av_, bv_, acc[i_][j_], 0, 0, 0);                          \
-    else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv_, av_, acc[i_][j_], 0, 0, 0);                             \
-  }
-#define SB __builtin_amdgcn_sched_barrier(0);
-#define K16_MMA_ALL(Fx)                                                                                                 \
-  K16_MF(Fx, 0) K16_MF(Fx, 1) K16_MF(Fx, 2) K16_MF(Fx, 3) K16_MF(Fx, 4) K16_MF(Fx, 5) K16_MF(Fx, 6) K16_MF(Fx, 7)         \
-  K16_MF(Fx, 8) K16_MF(Fx, 9) K16_MF(Fx, 10) K16_MF(Fx, 11) K16_MF(Fx, 12) K16_MF(Fx, 13) K16_MF(Fx, 14) K16_MF(Fx, 15)   \
-  K16_MF(Fx, 16) K16_MF(Fx, 17) K16_MF(Fx, 18) K16_MF(Fx, 19) K16_MF(Fx, 20) K16_MF(Fx, 21) K16_MF(Fx, 22) K16_MF(Fx, 23)
-  const int last = nkt - 1;
-  if (nkt > 0) {
-#pragma unroll
-    for (int pc = 0; pc < 6; pc++) K16_DMA(pc, 0, 0)
-#pragma unroll
-    for (int pc = 0; pc < 6; pc++) K16_DMA(pc, min(1, last), K16_STG)
-    __builtin_amdgcn_s_waitcnt(0x0076);                                    // vmcnt(6): stage 0 landed
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int pc = 0; pc < 6; pc++) K16_DMA(pc, min(2, last), 2 * K16_STG)
-    Frags F0, F1;
-    K16_RD(F0, 0, smem) K16_RD(F0, 1, smem) K16_RD(F0, 2, smem) K16_RD(F0, 3, smem) K16_RD(F0, 4, smem) K16_RD(F0, 5, smem)
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0)
-    int t = 0, ob = 0;         // ob: byte offset of the LDS buffer that holds stage t (and receives stage t + 3)
-    // One step, written out instruction by instruction (a scheduling fence after each item, so the order below IS the
-    // issue order): the LDS reads of stage t + 1 and the DMA pieces of stage t + 3 (clamped to the last stage: a step past
-    // the end re-fetches it into a free buffer, so every step issues the same 6 pieces and one counted wait fits all)
-    // go out in the shadow of this wavefront's own MFMAs of stage t.  Before, loads and MFMAs were separate phases and
-    // the two wavefronts of a SIMD idled through their load phases together (matrix cores busy 60 % of the loop).
-#define K16_STEP(Fc, Fn)                                                                                                \
-    {                                                                                                                   \
-      __builtin_amdgcn_s_waitcnt(0x0076);    /* vmcnt(6): stage t+1 landed (t+2's pieces may stay in flight) */         \
-      __builtin_amdgcn_s_barrier();          /* ... everywhere; buffer t % 3 is read out */                             \
-      SB                                                                                                                \
-      const int src_ = min(t + 3, last);                                                                                \
-      const int on_ = (ob == 2 * K16_STG) ? 0 : ob + K16_STG;      /* buffer of stage t + 1 */                             \
-      const char* nx_ = smem + on_;                                                                                     \
-      K16_MF(Fc, 0) SB K16_RD(Fn, 0, nx_) SB K16_MF(Fc, 1) SB K16_RD(Fn, 1, nx_) SB K16_MF(Fc, 2) SB K16_RD(Fn, 2, nx_) SB  \
-      K16_MF(Fc, 3) SB K16_RD(Fn, 3, nx_) SB K16_MF(Fc, 4) SB K16_RD(Fn, 4, nx_) SB K16_MF(Fc, 5) SB K16_RD(Fn, 5, nx_) SB  \
-      K16_MF(Fc, 6) SB K16_DMA(0, src_, ob) SB K16_MF(Fc, 7) K16_MF(Fc, 8) K16_MF(Fc, 9) SB                              \
-      K16_DMA(1, src_, ob) SB K16_MF(Fc, 10) K16_MF(Fc, 11) K16_MF(Fc, 12) SB                                            \
-      K16_DMA(2, src_, ob) SB K16_MF(Fc, 13) K16_MF(Fc, 14) K16_MF(Fc, 15) SB                                            \
-      K16_DMA(3, src_, ob) SB K16_MF(Fc, 16) K16_MF(Fc, 17) K16_MF(Fc, 18) SB                                            \
-      K16_DMA(4, src_, ob) SB K16_MF(Fc, 19) K16_MF(Fc, 20) K16_MF(Fc, 21) SB                                            \
-      K16_DMA(5, src_, ob) SB K16_MF(Fc, 22) K16_MF(Fc, 23) SB                                                          \
-      __builtin_amdgcn_s_waitcnt(0xc07f);    /* lgkmcnt(0): the next fragments arrived long ago */                      \
-      t++; ob = on_;                                                                                                    \
-    }
-    // nkt is even (K and the split size are multiples of 32): nkt - 1 steps that prefetch, then the last stage's MFMAs --
-    // ONE tail, so the accumulators keep their registers (two alternative tails met in a join that went through scratch)
-    while (t < last - 1) {       // two steps per trip: the two fragment sets are addressed statically
-      K16_STEP(F0, F1)
-      K16_STEP(F1, F0)
-    }
-    K16_STEP(F0, F1)
-    K16_MMA_ALL(F1)
-#undef K16_STEP
-    __builtin_amdgcn_s_waitcnt(0x0070);      // the clamped re-fetches of the last steps
-  }
-#undef SB
-#undef K16_MMA_ALL
-#undef K16_MF
+  K16_MAINLOOP
 #undef K16_DMA
 #undef K16_RD
   if (MN) gemm_epilogue_mn<EPI, TM, TN>(a, acc, m0 + mw, n0 + nw, lane);
@@ -625,6 +623,90 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; r++)
         Cp[(size_t)(i0 + wi + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf) * a.N + j0 + wj + 32 * j + l31] = alpha * acc[i][j][r];
+}
+
+// The same product on the 4-wavefront main loop (K16_MAINLOOP above): tile 256 (i) x 128 (j), stages of 16 samples (A part
+// 16 rows x 1 KB, B part 16 rows x 512 B = the 24 KB of the other kernel's stage), three LDS buffers, two workgroups per CU,
+// every DMA piece one contiguous 1 KB row (A) or two 512-byte rows (B).  Transposing reads: with the stage's swizzle
+// (chunk ^ ((row & 1) | ((row & 2) << 2))) fragment q of an operand sits 128 (q ^ s3) bytes from fragment 0, s3 = bit 1 of the
+// lane's row -- two base addresses per operand half (even / odd q) and immediates cover all fragments.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_tn16_kernel(GemmArgs a) {
+  constexpr int TM = 4, TN = 2, RA = 1024, RB = 512, BOFF = 16 * RA;
+  constexpr bool MN = true;                       // D[i][j]: lane = column j, registers = rows i
+  __shared__ __attribute__((aligned(1024))) char smem[3 * K16_STG];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int ntn = a.N / 128;
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y, nsplit = gridDim.y;      // split-major: see hoic_gemm_f16x3_tn_kernel
+  const int split = lin % nsplit, g = lin / nsplit;
+  const int i0 = (g / ntn) * 256, j0 = (g % ntn) * 128;
+  const int kt0 = split * a.kt_per_split * 2;                       // kt_per_split counts 32 samples = 2 stages
+  const int nkt = min(a.kt_per_split * 2, a.K / 16 - kt0);
+  const size_t lda = (size_t)a.M * 4, ldb = (size_t)a.N * 4;       // bytes per sample row of the packed operands
+  const char* Ag = (const char*)a.A + (size_t)kt0 * 16 * lda + (size_t)i0 * 4;
+  const char* Bg = (const char*)a.B + (size_t)kt0 * 16 * ldb + (size_t)j0 * 4;
+  const int wi = (wave >> 1) * 128, wj = (wave & 1) * 64;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  struct Frags { h8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  // transposing-read addresses (read_frag_tr's mapping with 16-row stages): lane group gq = lane / 16 covers columns
+  // 16 (gq & 1) .. + 15 and rows 8 (gq / 2) .. + 7 of a 32-column fragment; lane il = lane % 16 addresses row il / 4 (+ 4 for the
+  // second read), columns 4 (il & 3) .. + 3
+  const int gq = lane >> 4, il = lane & 15;
+  const int row0 = 8 * (gq >> 1) + (il >> 2), s0 = row0 & 1, s3 = (row0 >> 1) & 1;
+  const int chl = 4 * (gq & 1) + 2 * ((il & 3) >> 1), ho = (il & 1) ? 8 : 0;
+  const int aB0 = row0 * RA + 16 * (wi / 4 + (chl ^ s0)) + ho, aB1 = row0 * RA + 16 * (wi / 4 + ((chl + 1) ^ s0)) + ho;
+  const int bB0 = BOFF + row0 * RB + 16 * (wj / 4 + (chl ^ s0)) + ho, bB1 = BOFF + row0 * RB + 16 * (wj / 4 + ((chl + 1) ^ s0)) + ho;
+  const int aE0 = aB0 + 128 * s3, aO0 = aB0 + 128 * (1 - s3), aE1 = aB1 + 128 * s3, aO1 = aB1 + 128 * (1 - s3);
+  const int bE0 = bB0 + 128 * s3, bO0 = bB0 + 128 * (1 - s3), bE1 = bB1 + 128 * s3, bO1 = bB1 + 128 * (1 - s3);
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+#define TR_RD(OFF) __builtin_bit_cast(u64, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hw4*)LDS_PTR(OFF)))
+#define K16_RD(Fx, Q, STG)                                                                                              \
+  {                                                                                                                     \
+    if ((Q) < TN) {                                                                                                     \
+      const char* h_ = (STG) + (((Q) & 1) ? bO0 : bE0) + 128 * ((Q) & ~1);                                                \
+      const char* l_ = (STG) + (((Q) & 1) ? bO1 : bE1) + 128 * ((Q) & ~1);                                                \
+      const u64x2 hv_ = {TR_RD(h_), TR_RD(h_ + 4 * RB)}, lv_ = {TR_RD(l_), TR_RD(l_ + 4 * RB)};                            \
+      Fx.bh[(Q) < TN ? (Q) : 0] = __builtin_bit_cast(h8, hv_); Fx.bl[(Q) < TN ? (Q) : 0] = __builtin_bit_cast(h8, lv_);     \
+    } else {                                                                                                            \
+      constexpr int q_ = (Q) >= TN ? (Q) - TN : 0;                                                                      \
+      const char* h_ = (STG) + ((q_ & 1) ? aO0 : aE0) + 128 * (q_ & ~1);                                                  \
+      const char* l_ = (STG) + ((q_ & 1) ? aO1 : aE1) + 128 * (q_ & ~1);                                                  \
+      const u64x2 hv_ = {TR_RD(h_), TR_RD(h_ + 4 * RA)}, lv_ = {TR_RD(l_), TR_RD(l_ + 4 * RA)};                            \
+      Fx.ah[q_] = __builtin_bit_cast(h8, hv_); Fx.al[q_] = __builtin_bit_cast(h8, lv_);                                   \
+    }                                                                                                                   \
+  }
+  // DMA pieces: 0..3 = A row 4 pc + wave (1 KB, lane = chunk), 4, 5 = B rows 8 (pc - 4) + 2 wave + lane / 32 (512 B each);
+  // the source chunk is the LDS chunk ^ swizzle(row), and the row's low bits come from the wavefront (and lane / 32) only
+  const unsigned voffA = (unsigned)((lane ^ ((wave & 1) | ((wave & 2) << 2))) << 4);
+  const unsigned voffB = (unsigned)(lane >> 5) * (unsigned)ldb + (unsigned)((((lane & 31) ^ ((lane >> 5) | ((wave & 1) << 3)))) << 4);
+#define K16_DMA(PC, SRC, BUF)                                                                                           \
+  {                                                                                                                     \
+    if ((PC) < 4) __builtin_amdgcn_global_load_lds(GLB_PTR(Ag + ((size_t)(SRC) * 16 + 4 * (PC) + wave) * lda + voffA),    \
+                                                   LDS_PTR(smem + (BUF) + (4 * (PC) + wave) * RA), 16, 0, 0);             \
+    else __builtin_amdgcn_global_load_lds(GLB_PTR(Bg + ((size_t)(SRC) * 16 + 8 * ((PC) - 4) + 2 * wave) * ldb + voffB),   \
+                                          LDS_PTR(smem + (BUF) + BOFF + (8 * ((PC) - 4) + 2 * wave) * RB), 16, 0, 0);     \
+  }
+  K16_MAINLOOP
+#undef K16_DMA
+#undef K16_RD
+#undef TR_RD
+  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
+  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
+  float* __restrict__ Cp = a.C + (size_t)split * a.c_split_stride;
+  const unsigned N = (unsigned)a.N, lane_off = (unsigned)(i0 + wi + 4 * hf) * N + (unsigned)(j0 + wj + l31);
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        Cp[lane_off + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * N + 32u * j] = alpha * acc[i][j][r];
 }
 
 // ---------------------------------------------------------------------------------------------- pack kernels
@@ -809,7 +891,8 @@ extern "C" int32_t hoic_mlp_gemm_tn(int32_t M, int32_t N, int32_t K, const void*
   a.kt_per_split = (K / 32 + splits - 1) / splits;
   a.exps = d_exps; a.ea = slot_a; a.eb = slot_b; a.extra_scale = extra_scale; a.C = d_C; a.c_split_stride = (long long)M * N;
   hipStream_t st = (hipStream_t)stream;
-  if ((N % 256) == 0) hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<256>), dim3((M / 256) * (N / 256), splits), dim3(512), 0, st, a);
+  if (g_gemm_pipeline == 3) hipLaunchKernelGGL(hoic_gemm_f16x3_tn16_kernel, dim3((M / 256) * (N / 128), splits), dim3(256), 0, st, a);
+  else if ((N % 256) == 0) hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<256>), dim3((M / 256) * (N / 256), splits), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<128>), dim3((M / 256) * (N / 128), splits), dim3(512), 0, st, a);
   MCHK(hipGetLastError());
   return HOIC_OK;

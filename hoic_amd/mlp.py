@@ -227,6 +227,21 @@ def pick_splits(tiles, nkt, n_cu=256, max_splits=64):
     return best[1]
 
 
+def pick_splits16(tiles, nkt, slots=512, max_splits=64):
+    """The same for the 4-wavefront weight-gradient kernel (two workgroups per CU = 512 slots, uneven splits allowed: a
+    split is ceil(nkt / splits) stages of 32 samples): time ~ rounds of the slots x stages per split, a little per slab."""
+    best = None
+    for s_ in range(1, max_splits + 1):
+        per = -(-nkt // s_)
+        if (s_ - 1) * per >= nkt:          # the last split would be empty
+            continue
+        rounds = -(-(tiles * s_) // slots)
+        key = (rounds * per * (1.0 + 0.004 * s_), s_)
+        if best is None or key < best[0]:
+            best = (key, s_)
+    return best[1]
+
+
 class SplitMLP:
     SLOT_X, SLOT_W0, SLOT_H0, SLOT_DZ0 = 0, 1, 4, 8        # W: 1..3, H (hidden activations): 4..6, dZ: 8..10
 
@@ -270,7 +285,8 @@ class SplitMLP:
             self.dZp = [None] + [h(Mp, n) for n in self.dims_out[1:]]      # rows: operand of the data-gradient GEMM (layers >= 1)
             self.dZpT = [h(n, Mp) for n in self.dims_out]
         # split-K of the weight gradients: K = Mp rows in stages of 32
-        self.layer_splits = [self.splits or pick_splits((n // 256) * (k // (256 if k % 256 == 0 else 128)), Mp // 32)
+        self.layer_splits = [self.splits or (pick_splits16((n // 256) * (k // 128), Mp // 32) if self.rows_layout else
+                                            pick_splits((n // 256) * (k // (256 if k % 256 == 0 else 128)), Mp // 32))
                              for n, k in zip(self.dims_out, self.Kp)]
         self.slabs = torch.empty(max(sp * n * k for sp, n, k in zip(self.layer_splits, self.dims_out, self.Kp)), dtype=torch.float32, device=dev)
         self.first = True

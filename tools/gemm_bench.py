@@ -34,7 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=53248)
     ap.add_argument("--reps", type=int, default=7)
-    ap.add_argument("--splits", type=int, default=16)
+    ap.add_argument("--splits", type=int, default=0, help="split-K of the weight gradient (0: what SplitMLP picks)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-update", action="store_true")
     ap.add_argument("--zero", action="store_true", help="all-zero operands: the same instruction stream at minimum switching power (a lower "
@@ -66,7 +66,9 @@ def main():
         G = torch.rand(Mr, N, device=dev); Gk = torch.rand(Mr, K, device=dev)
         Hp = torch.empty(Mr, 2 * N, dtype=torch.float16, device=dev); HpT = torch.empty(N, 2 * Mr, dtype=torch.float16, device=dev)
         dXp = torch.empty(Mr, 2 * K, dtype=torch.float16, device=dev); dXpT = torch.empty(K, 2 * Mr, dtype=torch.float16, device=dev)
-        slabs = torch.empty(args.splits, N, K, device=dev)
+        nsp = args.splits or (M.pick_splits16((N // 256) * (K // 128), Mr // 32) if args.pipeline == 3 else
+                              M.pick_splits((N // 256) * (K // (256 if K % 256 == 0 else 128)), Mr // 32))
+        slabs = torch.empty(nsp, N, K, device=dev)
         with torch.no_grad():
             t.exps[3] = 4; t.exps[4] = 10
         cases = [
@@ -75,8 +77,8 @@ def main():
             ("fwd_plain", Mr, N, K, lambda: M.gemm(M.EPI_F32, Mr, N, K, Xp, Wp, t, 0, 1, C_out=G), lambda: torch.mm(x, w.t())),
             ("bwd_data", Mr, K, N, lambda: M.gemm(M.EPI_BWD, Mr, K, N, dZp, WpT, t, 2, 1, 4, gin=Gk, P=dXp, PT=None if args.pipeline == 3 else dXpT),
              lambda: torch.mm(dz, w) * Gk),
-            ("bwd_weight", N, K, Mr, (lambda: M.gemm_tn(N, K, Mr, dZp, Xp, t, 2, 0, args.splits, slabs)) if args.pipeline == 3 else
-             (lambda: M.gemm(M.EPI_F32, N, K, Mr, dZpT, XpT, t, 2, 0, splits=args.splits, C_out=slabs)), lambda: torch.mm(dz.t(), x)),
+            ("bwd_weight", N, K, Mr, (lambda: M.gemm_tn(N, K, Mr, dZp, Xp, t, 2, 0, nsp, slabs)) if args.pipeline == 3 else
+             (lambda: M.gemm(M.EPI_F32, N, K, Mr, dZpT, XpT, t, 2, 0, splits=nsp, C_out=slabs)), lambda: torch.mm(dz.t(), x)),
             ("fwd_nostore", Mr, N, K, lambda: M.gemm(M.EPI_FWD, Mr, N, K, Xp, Wp, t, 0, 1, 3, bias=bias), lambda: None),
         ]
         for name, m_, n_, k_, f_x3, f_32 in cases:
