@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=0, help="1: value-network steps on a side stream under the next rollout (f16x3 only; measured: no gain, the GEMM workgroups take the CUs' LDS); 0: serial")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solver-iterations", type=int, default=8)
+    ap.add_argument("--solver-iterations", type=int, default=None, help="Newton iteration cap per substep (default: the model's <option iterations>, 20)")
     ap.add_argument("--groups", type=int, default=None, help="env ranges pipelined on separate streams during the rollout (default: 2 at >= 4096 envs)")
     args = ap.parse_args()
 

@@ -336,7 +336,7 @@ class PPOLearner:
 class AgentHandMimic:
     def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
-                 strict_reference=True, solver_iterations=8, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
+                 strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
                  start_min=0, overlap_value_update=False):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the

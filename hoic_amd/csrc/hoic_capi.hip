@@ -798,7 +798,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hoic_env_config& c = s->hcfg.c;
   c.pos_diff_thresh = 0.1f; c.rot_diff_thresh = 1.0f; c.jpos_diff_thresh = 0.1f; c.obj_pos_diff_thresh = 0.1f; c.obj_rot_diff_thresh = 1.0f;
   c.residual_force_scale = 2.5f; c.residual_torque_scale = 0.125f; c.sim_step = 15; c.future_w_size = 5;
-  c.residual_force = 1; c.explain_force = 1; c.surface_contact = 1; c.pd_rel = 1; c.solver_iterations = 8;
+  c.residual_force = 1; c.explain_force = 1; c.surface_contact = 1; c.pd_rel = 1; c.solver_iterations = 20;   // the hand MJCF's <option iterations="20">
   for (int i = 0; i < NU; i++) { c.jkp[i] = i < 3 ? 50.f : (i < 6 ? 5.f : 1.f); c.jkd[i] = 0.1f * c.jkp[i]; c.torque_lim[i] = c.jkp[i]; }
   for (int j = 0; j < s->hm.hand_nq && j < NU; j++) {   // ho_im4.py:103-107
     const float lo = s->hm.jnt_range[j][0], hi = s->hm.jnt_range[j][1];

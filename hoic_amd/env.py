@@ -25,7 +25,7 @@ class _Space:
 
 class BatchedHandObjMimic:
     def __init__(self, cfg: Config, expert_seqs, model: mjcf.CompiledModel | bytes | str = "box", n_envs: int = 1,
-                 mode: str = "train", device_index: int = 0, solver_iterations: int = 8):
+                 mode: str = "train", device_index: int = 0, solver_iterations: int | None = None):
         import torch
         self.torch = torch
         self.cc_cfg = cfg
@@ -41,6 +41,8 @@ class BatchedHandObjMimic:
         self.n_envs = int(n_envs)
         self.sim = lib.BatchedSim(blob, self.n_envs, device_index)
         self.device = self.sim.device
+        if solver_iterations is None:      # the model's <option iterations=...> (20 in the reference's hand MJCF), as MuJoCo's Newton solver
+            solver_iterations = int(self.model.arrays["iterations"][0]) if "iterations" in self.model.arrays else 20
         self.sim.set_config(cfg.jkp, cfg.jkd, cfg.torque_lim,
                             (cfg.pos_diff_thresh, cfg.rot_diff_thresh, cfg.jpos_diff_thresh, cfg.obj_pos_diff_thresh,
                              cfg.obj_rot_diff_thresh), cfg.residual_force_scale, cfg.residual_torque_scale,

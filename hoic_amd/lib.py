@@ -164,7 +164,7 @@ class BatchedSim:
     # ---- configuration
     def set_config(self, jkp, jkd, torque_lim, thresh=(0.1, 1.0, 0.1, 0.1, 1.0), rf_scale=2.5, rt_scale=0.125,
                    sim_step=15, residual_force=True, explain_force=True, surface_contact=True, pd_rel=True,
-                   solver_iterations=8, pd_ref_offset=0):
+                   solver_iterations=20, pd_ref_offset=0):
         c = EnvConfig()
         for i in range(26):
             c.jkp[i], c.jkd[i], c.torque_lim[i] = float(jkp[i]), float(jkd[i]), float(torque_lim[i])

@@ -1,8 +1,9 @@
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -4 gpurun_out/pytest_gpu.log
 timeout 400 python bench.py > gpurun_out/r02_bench_box.json 2> gpurun_out/bench_box.err; tail -c 600 gpurun_out/r02_bench_box.json; echo
-timeout 300 python bench.py --workload grasp --no-cpu-baseline > gpurun_out/r02_bench_box_grasp.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_box_grasp.json')); print('grasp', d['value'], d['rollout_only_env_steps_per_s'], d['workload_stats'], d['roofline']['kernel_ms'])"
+timeout 300 python bench.py --pretrain 60 --no-cpu-baseline > gpurun_out/r02_bench_box_tracking.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_box_tracking.json')); print('tracking', d['value'], d['rollout_only_env_steps_per_s'], d['workload_stats'], d['roofline']['kernel_ms'])"
+timeout 200 python tools/gemm_bench.py --pipeline 3 --reps 9 --out gpurun_out/r02_gemm_bench.json > gpurun_out/gemm_bench.log 2>&1; tail -2 gpurun_out/gemm_bench.log
 for o in bottle banana; do timeout 300 python bench.py --obj $o --no-cpu-baseline > gpurun_out/r02_bench_$o.json 2>/dev/null; python -c "
 import json; d=json.load(open('gpurun_out/r02_bench_$o.json')); print('$o', d['value'], d['rollout_only_env_steps_per_s'], d['workload_stats'], d['roofline']['kernel_ms'])"; done
 cd /tmp; export TMPDIR=/tmp
@@ -14,4 +15,5 @@ python3 $R/tools/pmc_summary.py counters --dir /tmp/pmc_a /tmp/pmc_b --kernel ho
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python3 $R/tools/sim_only.py 2048 12 > /tmp/pmc_f.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python3 $R/tools/sim_only.py 2048 12 > /tmp/pmc_w.log 2>&1
 python3 $R/tools/pmc_summary.py traffic --fetch-dir /tmp/pmc_f --write-dir /tmp/pmc_w --kernel hoic_substep_kernel --envs 2048 --obj box --out $R/gpurun_out/r02_hbm_traffic.json --command "separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE -- python3 tools/sim_only.py 2048 12"
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_upd -o u -- python3 $R/tools/update_only.py f16x3 4 > /tmp/prof_upd.log 2>&1; python3 $R/tools/pmc_summary.py stats --dir /tmp/prof_upd --out $R/gpurun_out/r02_update_kernel_stats.csv
 cd $R; ls -la gpurun_out | tail -15
