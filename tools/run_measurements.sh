@@ -4,6 +4,7 @@ timeout 400 python bench.py > gpurun_out/r02_bench_box.json 2> gpurun_out/bench_
 timeout 300 python bench.py --pretrain 60 --no-cpu-baseline > gpurun_out/r02_bench_box_tracking.json 2>/dev/null; python -c "
 import json; d=json.load(open('gpurun_out/r02_bench_box_tracking.json')); print('tracking', d['value'], d['rollout_only_env_steps_per_s'], d['workload_stats'], d['roofline']['kernel_ms'])"
 timeout 200 python tools/gemm_bench.py --pipeline 3 --reps 9 --out gpurun_out/r02_gemm_bench.json > gpurun_out/gemm_bench.log 2>&1; tail -2 gpurun_out/gemm_bench.log
+timeout 200 python tools/gemm_bench.py --pipeline 3 --reps 9 --zero --no-update --out gpurun_out/r02_gemm_bench_zero.json > gpurun_out/gemm_bench_zero.log 2>&1
 for o in bottle banana; do timeout 300 python bench.py --obj $o --no-cpu-baseline > gpurun_out/r02_bench_$o.json 2>/dev/null; python -c "
 import json; d=json.load(open('gpurun_out/r02_bench_$o.json')); print('$o', d['value'], d['rollout_only_env_steps_per_s'], d['workload_stats'], d['roofline']['kernel_ms'])"; done
 cd /tmp; export TMPDIR=/tmp
