@@ -1025,6 +1025,38 @@ extern "C" int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t 
   return HOIC_OK;
 }
 
+// The delayed exponents of the hidden-layer gradients, RELATIVE to the loss-side gradient whose exponent is exact: slot i gets
+// target - ceil(log2 amax[i]) + (exps[ref] - *ref_prev), i.e. last pass's head-room shifted by how much the loss-side scale
+// moved since -- a jump of the whole gradient's scale (new batch, clipped / unclipped ratios) cannot overflow the hidden layers.
+__global__ void hoic_update_exps_rel_kernel(int* __restrict__ exps, float* __restrict__ amax, int nslots, unsigned long long mask, int target,
+                                            int ref_slot, int* __restrict__ ref_prev, int* __restrict__ overflow) {
+  const int i = threadIdx.x;
+  const int shift = exps[ref_slot] - *ref_prev;
+  __syncthreads();
+  if (i < nslots && ((mask >> i) & 1ull) && i != ref_slot) {
+    const float m = amax[i];
+    if (m > 0.f && isfinite(m)) {
+      int ex; frexpf(m, &ex);
+      if (ldexpf(m, exps[i]) > 60000.f && overflow) atomicAdd(overflow, 1);
+      exps[i] = target - ex + shift;
+    } else if (!isfinite(m) && overflow) atomicAdd(overflow, 1);
+    else exps[i] += shift;
+    amax[i] = 0.f;
+  }
+  __syncthreads();
+  if (i == 0) *ref_prev = exps[ref_slot];
+}
+extern "C" int32_t hoic_mlp_update_exps_rel(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t ref_slot,
+                                            int32_t* d_ref_prev, int32_t* d_overflow, void* stream) {
+  if (!d_exps || !d_amax || !d_ref_prev || nslots <= 0 || nslots > 64 || ref_slot < 0 || ref_slot >= nslots) {
+    hoic_set_error("hoic_mlp_update_exps_rel: bad arguments"); return HOIC_ERR_ARG;
+  }
+  hipLaunchKernelGGL(hoic_update_exps_rel_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_exps, d_amax, nslots, (unsigned long long)mask, target,
+                     ref_slot, d_ref_prev, d_overflow);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
 extern "C" int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
                                         float scale, void* stream) {
   if (!d_slabs || !d_out || S <= 0 || rows <= 0 || cols <= 0 || out_cols <= 0 || out_cols > cols) { hoic_set_error("hoic_mlp_slab_reduce: bad arguments"); return HOIC_ERR_ARG; }

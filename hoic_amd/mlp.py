@@ -70,8 +70,9 @@ class _Kernels:
         L.hoic_mlp_colsum_packed.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
         L.hoic_mlp_amax_colsum.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
         L.hoic_mlp_colpart_finish.argtypes = [vp, i32, i32, vp, vp]
+        L.hoic_mlp_update_exps_rel.argtypes = [vp, vp, i32, C.c_uint64, i32, i32, vp, vp, vp]
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
-                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish"):
+                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel"):
             getattr(L, n).restype = i32
         self.L = L
 
@@ -121,13 +122,26 @@ class ScaleTable:
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
         self.device = device
 
-    def update(self, slots, target=TARGET_LOG2):
+    def update(self, slots, target=TARGET_LOG2, exact=False):
+        """exponents of `slots` from their measured maxima.  ``exact``: the maximum was measured on the very tensor that is
+        packed next (inputs, weights, loss-side gradient), so nothing can have overflowed under the OLD exponent -- the
+        overflow check (measured maximum x 2^old exponent beyond the float16 range) applies to delayed slots only."""
         mask = 0
         for s in slots:
             mask |= 1 << s
         K = kernels()
-        K.chk(K.L.hoic_mlp_update_exps(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target, _ptr(self.overflow),
-                                       _stream(self.device)), "hoic_mlp_update_exps")
+        K.chk(K.L.hoic_mlp_update_exps(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target,
+                                       None if exact else _ptr(self.overflow), _stream(self.device)), "hoic_mlp_update_exps")
+
+    def update_rel(self, slots, ref_slot, ref_prev, target=TARGET_LOG2):
+        """delayed exponents of `slots` shifted by the change of the (exact) exponent of `ref_slot` since the last call;
+        ``ref_prev``: device int32[1] holding that exponent as of the last call"""
+        mask = 0
+        for s in slots:
+            mask |= 1 << s
+        K = kernels()
+        K.chk(K.L.hoic_mlp_update_exps_rel(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target, ref_slot, _ptr(ref_prev),
+                                           _ptr(self.overflow), _stream(self.device)), "hoic_mlp_update_exps_rel")
 
     def measure(self, slot, x, mul=None):
         K = kernels()
@@ -147,7 +161,7 @@ def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None
     if measure:
         assert x.is_contiguous()
         table.measure(slot, x, mul)
-        table.update([slot])
+        table.update([slot], exact=True)
     P = torch.empty(Rp, 2 * Cp, dtype=torch.float16, device=dev) if rows else None
     PT = torch.empty(Cp, 2 * Rp, dtype=torch.float16, device=dev) if transposed else None
     K.chk(K.L.hoic_mlp_pack(_ptr(x), _ptr(mul), R, Cc, x.stride(0), _ptr(P), _ptr(PT), Rp, Cp, _ptr(table.exps), slot, _stream(dev)),
@@ -344,7 +358,7 @@ class SplitMLP:
                                              _stream(self.dev)), "hoic_mlp_amax_colsum")
         else:
             t.measure(s_last, dH, self.G[-1])
-        t.update([s_last])
+        t.update([s_last], exact=True)
         P, PT = self.dZp[L - 1], self.dZpT[L - 1]
         Kn.chk(Kn.L.hoic_mlp_pack(_ptr(dH), _ptr(self.G[-1]), Mp, self.dims_out[-1], self.dims_out[-1], _ptr(P if (L > 1 or self.rows_layout) else None),
                                   _ptr(PT), Mp, self.dims_out[-1], _ptr(t.exps), s_last, _stream(self.dev)), "hoic_mlp_pack")
@@ -352,9 +366,10 @@ class SplitMLP:
             with torch.no_grad():
                 for i in range(L - 1):
                     t.exps[self.SLOT_DZ0 + i] = t.exps[s_last]
+                self.ref_prev = t.exps[s_last:s_last + 1].clone()
             self.first_bwd = False
-        else:
-            t.update([self.SLOT_DZ0 + i for i in range(L - 1)])
+        else:       # last pass's head-room, shifted by how far the (exact) loss-side exponent moved since
+            t.update_rel([self.SLOT_DZ0 + i for i in range(L - 1)], s_last, self.ref_prev)
         for i in range(L - 1, 0, -1):          # dZ_{i-1} = (dZ_i W_i) * GELU'(z_{i-1})
             gemm(EPI_BWD, Mp, self.dims_out[i - 1], self.dims_out[i], self.dZp[i], self.WpT[i], t, self.SLOT_DZ0 + i, self.SLOT_W0 + i,
                  self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1],       # (rows layout: dZpT entries are None)

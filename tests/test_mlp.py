@@ -95,6 +95,60 @@ def test_gemm_tn_accuracy(shape):
         assert ((c2.double() - ref).abs() / bound).max().item() < 6e-7
 
 
+@gpu
+def test_bias_gradient_partials_from_the_producing_kernels():
+    """The bias gradients are column sums of dZ taken where dZ is produced: (i) hoic_mlp_amax_colsum (last layer: dH * GELU',
+    maximum + per-128-row partial sums in one pass) and (ii) the data-gradient epilogue's `colpart` output; both finished
+    by hoic_mlp_colpart_finish.  Against float64 sums; the partial sums are written in fixed order (bit-identical reruns)."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(5)
+    R, Cc = 1000, 512
+    x = torch.randn(R, Cc, device=dev, generator=g) * 1e-3; y = torch.rand(R, Cc, device=dev, generator=g)
+    t = M.ScaleTable(dev)
+    K = M.kernels()
+    part = torch.zeros((R + 127) // 128, Cc, device=dev)
+    out = torch.empty(Cc, device=dev)
+    K.chk(K.L.hoic_mlp_amax_colsum(M._ptr(x), M._ptr(y), R, Cc, M._ptr(t.amax), 9, M._ptr(part), M._stream(dev)), "amax_colsum")
+    K.chk(K.L.hoic_mlp_colpart_finish(M._ptr(part), part.shape[0], Cc, M._ptr(out), M._stream(dev)), "colpart_finish")
+    ref = (x.double() * y.double()).sum(0)
+    assert (out.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    assert abs(float(t.amax[9]) - float((x * y).abs().max())) < 1e-12
+    # (ii) data gradient dX = (dZ W) * gin with its column partials
+    Mr, N, Kk = 512, 256, 384
+    dz = torch.randn(Mr, Kk, device=dev, generator=g) * 1e-3; w = torch.randn(Kk, N, device=dev, generator=g) * 0.05
+    gin = torch.rand(Mr, N, device=dev, generator=g)
+    dZp, _ = M.pack(dz, t, 0, Mr, Kk); WpT, _ = M.pack(w.t().contiguous(), t, 1, N, Kk)
+    with torch.no_grad():
+        t.exps[2] = 8
+    P = torch.empty(Mr, 2 * N, dtype=torch.float16, device=dev)
+    outs = []
+    for rep in range(2):
+        cp = torch.zeros(Mr // 128, N, device=dev)
+        M.gemm(M.EPI_BWD, Mr, N, Kk, dZp, WpT, t, 0, 1, 2, gin=gin, P=P, colpart=cp)
+        db = torch.empty(N, device=dev)
+        K.chk(K.L.hoic_mlp_colpart_finish(M._ptr(cp), Mr // 128, N, M._ptr(db), M._stream(dev)), "colpart_finish")
+        outs.append(db.clone())
+    ref = ((dz.double() @ w.double()) * gin.double()).sum(0)
+    assert (outs[0].double() - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+    assert torch.equal(outs[0], outs[1])
+    # the partial sums exist only for the D[m][n] epilogue: asking for them in another kernel mode is an error, not a silent zero
+    M.set_pipeline(2)
+    try:
+        with pytest.raises(Exception, match="column partial sums"):
+            M.gemm(M.EPI_BWD, Mr, N, Kk, dZp, WpT, t, 0, 1, 2, gin=gin, P=P, colpart=cp)
+    finally:
+        M.set_pipeline(3)
+
+
+def test_split_choice_for_the_weight_gradient_kernels():
+    """pick_splits16: tiles x splits fill the 512 workgroup slots (two per CU) in whole rounds, no split is empty"""
+    for n, k, want in ((2048, 640, 12), (1024, 2048, 8), (512, 1024, 32)):
+        tiles, nkt = (n // 256) * (k // 128), 53248 // 32
+        s_ = M.pick_splits16(tiles, nkt)
+        assert s_ == want and tiles * s_ <= 512 and (s_ - 1) * -(-nkt // s_) < nkt
+    assert M.pick_splits16(1, 2) in (1, 2) and M.pick_splits16(600, 100) >= 1
+
+
 def _nets(hidden, seed=0):
     from hoic_amd.rl import MLP
     torch.manual_seed(seed)
@@ -141,6 +195,17 @@ def test_split_mlp_forward_backward_matches_autograd(mode):
                 ga, gr = getattr(l, pn).grad.double(), getattr(l64, pn).grad
                 assert (ga - gr).abs().max().item() < 2e-6 * gr.abs().max().item(), (rep, pn, (ga - gr).abs().max().item(), gr.abs().max().item())
         eng.check_overflow()
+    # the whole gradient's scale jumps between passes (a new batch, clipped / unclipped PPO ratios): the hidden layers'
+    # delayed exponents follow the exact loss-side exponent, nothing leaves the float16 range, the gradients stay exact
+    for scale in (4096.0, 1.0 / 4096.0):
+        h = eng.forward(inp)
+        loss = ((head(h) - tgt) ** 2).mean() * 1e-3 * scale
+        loss.backward()
+        eng.backward(h.grad)
+        eng.check_overflow()
+        for l, l64 in zip(net.affine_layers, net64.affine_layers):
+            ga, gr = l.weight.grad.double(), l64.weight.grad * scale
+            assert (ga - gr).abs().max().item() < 2e-6 * gr.abs().max().item(), (scale, (ga - gr).abs().max().item(), gr.abs().max().item())
     # no-grad forward gives the same activations
     h2 = eng.forward(inp, need_grad=False)
     assert not h2.requires_grad and torch.equal(h2, h.detach())
