@@ -65,7 +65,8 @@ def main():
                     "cpu_fixed": "float64 CPU-oracle envs, the batched sampler's fixed-horizon scheme (4096 envs x 13 steps, value bootstrap)",
                     "hip_fixed": "HIP simulator, fixed-horizon batches (4096 envs x 13 steps, value bootstrap): product default",
                     "hip_episodes": "HIP simulator, whole-episode batches (sample_mode='episodes')",
-                    "hip_fixed_long": "HIP simulator, fixed horizon with 1024 envs x 49 steps"},
+                    "hip_fixed_long": "HIP simulator, fixed horizon with 1024 envs x 49 steps",
+                    "hip_fixed_f16x3": "hip_fixed with the update's GEMMs on the f16x3 matrix-core path (bench.py's default update)"},
            "note": args.note, "bands": bands, "runs": runs}
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
