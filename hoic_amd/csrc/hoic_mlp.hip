@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
   const int src0 = ((lane & ~7) + 2 * (lane & 3)) << 2, src1 = src0 + 4;        // ds_bpermute byte addresses of the two source lanes
   const unsigned sel = (lane & 4) ? 0x07060302u : 0x05040100u;                  // lanes 4..7 of a group assemble the lo halves
   // addresses: the arrays' base pointers stay in scalar registers, the element offset is ONE 32-bit VGPR chain (outputs are
-  // below 4 GB: asserted on the host)
+  // below 2^32 elements: checked in hoic_mlp_gemm)
   const unsigned N = (unsigned)a.N;
   const unsigned lane_off = (unsigned)mb * N + (unsigned)(nb + l31) + 4u * (unsigned)hf * N;
   float vmax = 0.f;
@@ -862,6 +862,9 @@ extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, c
   if (epi == EPI_FWD && !d_bias) { hoic_set_error("hoic_mlp_gemm: forward epilogue needs the bias"); return HOIC_ERR_ARG; }
   if (epi == EPI_BWD && !d_gin) { hoic_set_error("hoic_mlp_gemm: backward epilogue needs gin"); return HOIC_ERR_ARG; }
   if (epi != EPI_F32 && splits != 1) { hoic_set_error("hoic_mlp_gemm: split-K only with the float32 epilogue"); return HOIC_ERR_ARG; }
+  if ((unsigned long long)M * (unsigned long long)N >= (1ull << 32)) {      // the epilogues index their outputs with 32-bit element offsets
+    hoic_set_error("hoic_mlp_gemm: M x N must stay below 2^32 elements"); return HOIC_ERR_ARG;
+  }
   if (d_colpart && !(epi == EPI_BWD && g_gemm_pipeline == 3 && !d_PT)) {
     hoic_set_error("hoic_mlp_gemm: column partial sums come from the data-gradient epilogue in D[m][n] form (pipeline mode 3, no transposed output)");
     return HOIC_ERR_ARG;
@@ -886,6 +889,7 @@ extern "C" int32_t hoic_mlp_gemm_tn(int32_t M, int32_t N, int32_t K, const void*
   if (M <= 0 || N <= 0 || K <= 0 || (M & 255) || (N & 127) || (K & 31) || !d_A || !d_B || !d_C || splits < 1) {
     hoic_set_error("hoic_mlp_gemm_tn: M must be a multiple of 256, N of 128, K (rows) of 32"); return HOIC_ERR_ARG;
   }
+  if ((unsigned long long)M * (unsigned long long)N >= (1ull << 32)) { hoic_set_error("hoic_mlp_gemm_tn: M x N must stay below 2^32 elements"); return HOIC_ERR_ARG; }
   GemmArgs a{};
   a.A = (const u16*)d_A; a.B = (const u16*)d_B; a.M = M; a.N = N; a.K = K;
   a.kt_per_split = (K / 32 + splits - 1) / splits;

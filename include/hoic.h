@@ -211,9 +211,10 @@ int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const void* 
  * hoic_mlp_amax_colsum: one pass over two float32 arrays [R x C]: d_amax[slot] = max(., max |x * mul|) and
  *   d_part[ceil(R / 128)][C] = column sums of x * mul per 128-row chunk (the last layer's dZ = dH * gelu').
  * hoic_mlp_colpart_finish: out[c] = sum over the chunks of d_part[chunk][c] (fixed order: deterministic).
- * hoic_mlp_set_pipeline: kernel variant of hoic_mlp_gemm (measurement aid; 3 = default): 0 plain loop, 1 software-pipelined
- * 8-wavefront kernel, 2 4-wavefront 256 x 128 kernel with K stages of 16 and two workgroups per CU, 3 = 2 with D[m][n]
- * accumulators for epilogues 1, 2 when no transposed output is requested (full-line stores). */
+ * hoic_mlp_set_pipeline: kernel variant of hoic_mlp_gemm / hoic_mlp_gemm_tn (measurement aid; 3 = default): 0 plain loop,
+ * 1 software-pipelined 8-wavefront kernel, 2 4-wavefront 256 x 128 kernel with K stages of 16 and two workgroups per CU,
+ * 3 = 2 with D[m][n] accumulators for epilogues 1, 2 when no transposed output is requested (full-line stores, column
+ * partial sums) and the weight gradient on the same 4-wavefront main loop (modes 0-2: its 8-wavefront predecessor). */
 int32_t hoic_mlp_gemm_tn(int32_t M, int32_t N, int32_t K, const void* d_A, const void* d_B, const int32_t* d_exps, int32_t slot_a,
                          int32_t slot_b, float extra_scale, int32_t splits, float* d_C, void* stream);
 int32_t hoic_mlp_colsum_packed(const void* d_P, int32_t R, int32_t C, float* d_out, float* d_scratch, const int32_t* d_exps,
