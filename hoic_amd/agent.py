@@ -99,8 +99,10 @@ class PPOLearner:
             import torch.distributed as dist
             for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
                 dist.broadcast(p.data, 0)
-        self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay)
-        self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=cfg.value_lr, weight_decay=cfg.value_weightdecay)
+        # one fused kernel per Adam step on the GPU (same arithmetic as the per-tensor form; HOIC_FUSED_ADAM=0 switches it off)
+        fused = {"fused": True} if (torch.device(device).type == "cuda" and os.environ.get("HOIC_FUSED_ADAM", "1") != "0") else {}
+        self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay, **fused)
+        self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=cfg.value_lr, weight_decay=cfg.value_weightdecay, **fused)
         self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
         self.opt_num_epochs = cfg.num_optim_epoch
         self._losses = None
@@ -449,6 +451,20 @@ class AgentHandMimic:
                         total_c_info=ci, sample_time=time.time() - t0, end_bonus=bonus)
 
     # ------------------------------------------------------------------ rollout (sample / sample_process, :430-535)
+    def _rollout_forward(self, groups):
+        """TiledForward engines of the rollout ranges (f16x3 learner, GELU policy body, range sizes that are multiples of
+        32), their weights re-packed from the current policy; None = the PyTorch float32 forward."""
+        if self.learner.update_dtype != "f16x3" or os.environ.get("HOIC_ROLLOUT_FWD", "tiled") != "tiled":
+            return None
+        from . import mlp as _mlp
+        if not all(_mlp.TiledForward.supports(self.policy_net.net, count) for _, count in groups):
+            return None
+        if getattr(self, "_fwd_engines", None) is None or len(self._fwd_engines) != len(groups):
+            self._fwd_engines = [_mlp.TiledForward(self.policy_net.net, x_bound=getattr(self.running_state, "clip", None)) for _ in groups]
+        for e in self._fwd_engines:
+            e.refresh()
+        return self._fwd_engines
+
     @torch.no_grad()
     def sample(self, min_batch_size):
         if self.sample_mode == "episodes":
@@ -475,6 +491,10 @@ class AgentHandMimic:
         groups = self._groups()
         G = len(groups)
         use_streams = G > 1
+        # With the f16x3 update the policy body's forward pass runs on the LDS-free tiled GEMM (hoic_amd.mlp.TiledForward):
+        # its wavefronts fit beside the other range's substep workgroups, the float32 library GEMMs queue behind them
+        # (measured: 6 ms of a 36 ms rollout).  One engine per range (own buffers and exponents: the ranges run concurrently).
+        fwd = self._rollout_forward(groups) if (dt == torch.float32 and dev.type == "cuda") else None
         # Per-step outputs go straight into the rollout's [T, N, .] storage (no copy kernels in a range's chain), the
         # next-episode draws of all T steps are made up front, masks and statistics are derived once at the end.
         direct = dt == torch.float32 and dev.type == "cuda"
@@ -501,7 +521,10 @@ class AgentHandMimic:
                     if state.data_ptr() != states[t, sl].data_ptr():
                         states[t, sl] = state
                     if direct:
-                        action = self.policy_net.select_action(state, out=actions[t, sl])
+                        if fwd is not None:
+                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl])
+                        else:
+                            action = self.policy_net.select_action(state, out=actions[t, sl])
                         self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count,
                                       out=(rewards[t, sl], rinfo_all[t, sl], flags_all[t, sl], pct[sl]))
                     else:
@@ -516,6 +539,9 @@ class AgentHandMimic:
         masks.copy_((~done_all).to(dt))
         obs = self.env.get_obs()
         self._obs = obs
+        if fwd is not None:
+            for e in fwd:
+                e.check_overflow()          # hidden activations beyond the float16 range under their delayed exponents: loud, not silent
         if self.distributed:
             self.running_state.sync()          # one observation filter for all ranks from here on
         next_state = self.running_state(obs, update=False)

@@ -827,6 +827,131 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
   if (tid == 0) out[r] = ldexpf(part[0], -(exps ? exps[slot] : 0));
 }
 
+// ---------------------------------------------------------------------------------------------- rollout forward
+// The policy's forward pass DURING the rollout runs next to the simulator's substep kernel, whose workgroups hold every
+// CU's LDS (8 x 19.98 KB) and 384 of a SIMD's 512 registers: a GEMM whose workgroups need LDS queues behind them (the
+// hipBLASLt float32 GEMMs of the 2048-row batches took 6 ms of a 36 ms rollout that way).  This kernel needs NO LDS and
+// <= 128 registers, so its wavefronts start at once as a third wavefront per SIMD: operands go from L2 straight into MFMA
+// registers, which asks for a layout in which a wavefront's operand load is one contiguous kilobyte --
+// "tiled" format T of a matrix [R x K]: tile (a, s) = rows 32 a .. + 31, k = 16 s .. + 15, 2 KB at ((a K/16 + s) * 2048):
+//   hi plane [64 lanes x 16 B], then lo plane; lane = 32 hf + l31 holds row 32 a + l31, k = 16 s + 8 hf .. + 7.
+// One wavefront per workgroup computes 32 rows (m) x 64 columns (n): D = W X^T per tile, i.e. lane = row m, registers =
+// columns n = (r & 3) + 8 (r >> 2) + 4 hf -- after one v_permlane32_swap per register pair a lane holds 8 consecutive n,
+// which IS the next layer's operand fragment, so the epilogue (bias + GELU) writes format T again, 1 KB per store.
+__global__ __launch_bounds__(64) void hoic_pack_tiled_kernel(const float* __restrict__ x, int R, int Cc, long long ld, char* __restrict__ T, int Rp,
+                                                             int Kp, const int* __restrict__ exps, int slot) {
+  const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;        // one lane slot of one tile
+  const int ksteps = Kp >> 4;
+  const long long tile = gid >> 6;
+  if (tile >= (long long)(Rp >> 5) * ksteps) return;
+  const int lane = (int)(gid & 63), l31 = lane & 31, hf = lane >> 5;
+  const int a = (int)(tile / ksteps), st = (int)(tile % ksteps);
+  const int r = 32 * a + l31, c0 = 16 * st + 8 * hf;
+  const float sc = ldexpf(1.f, exps ? exps[slot] : 0);
+  unsigned w[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = pack_hl((r < R && c0 + k < Cc) ? x[(long long)r * ld + c0 + k] * sc : 0.f);
+  u32x4 hi, lo;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { hi[k] = (w[2 * k] & 0xffffu) | (w[2 * k + 1] << 16); lo[k] = (w[2 * k] >> 16) | (w[2 * k + 1] & 0xffff0000u); }
+  char* t = T + tile * 2048 + lane * 16;
+  *(u32x4*)t = hi; *(u32x4*)(t + 1024) = lo;
+}
+
+struct FwdArgs {
+  const char* X; const char* W;      // format T: X [M x K], W [N x K]
+  int M, N, K;
+  const int* exps; float* amax; int ex, ew, eo;
+  const float* bias;                 // [N]
+  char* outT;                        // format T [M x N] at 2^exps[eo] (hidden layers), or
+  float* outF;                       // float32 row-major [M x N] (last layer)
+};
+template <bool LAST>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void hoic_fwd_tiled_kernel(FwdArgs a) {
+  const int lane = threadIdx.x, l31 = lane & 31, hf = lane >> 5;
+  const int ksteps = a.K >> 4, nt2 = a.N >> 6;
+  const int mt = blockIdx.x / nt2, n2 = blockIdx.x % nt2;          // 32-row tile, pair of 32-column tiles
+  const char* xp = a.X + (size_t)mt * ksteps * 2048 + lane * 16;
+  const char* w0 = a.W + (size_t)(2 * n2) * ksteps * 2048 + lane * 16;
+  const char* w1 = w0 + (size_t)ksteps * 2048;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  struct Fr { h8 xh, xl, ah, al, bh, bl; };
+  auto ld = [&](int st, Fr& f) {
+    const size_t o = (size_t)st * 2048;
+    f.xh = *(const h8*)(xp + o); f.xl = *(const h8*)(xp + o + 1024);
+    f.ah = *(const h8*)(w0 + o); f.al = *(const h8*)(w0 + o + 1024);
+    f.bh = *(const h8*)(w1 + o); f.bl = *(const h8*)(w1 + o + 1024);
+  };
+  auto mm = [&](const Fr& f) {       // D[n][m]: first operand = weights
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.xl, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.xl, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.xh, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl, f.xh, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.xh, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.xh, acc1, 0, 0, 0);
+  };
+  Fr f0, f1;
+  ld(0, f0);
+  int st = 0;
+  for (; st + 2 <= ksteps - 1; st += 2) {       // two register sets: the next step's six loads fly under this step's MFMAs
+    ld(st + 1, f1); mm(f0);
+    ld(st + 2, f0); mm(f1);
+  }
+  if (st + 1 < ksteps) { ld(st + 1, f1); mm(f0); mm(f1); }
+  else mm(f0);
+  // ---- epilogue
+  const int ex = a.exps ? a.exps[a.ex] : 0, ew = a.exps ? a.exps[a.ew] : 0;
+  const float alpha = ldexpf(1.f, -(ex + ew));
+  float vmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const f32x16& acc = j ? acc1 : acc0;
+    const int nb = 64 * n2 + 32 * j;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 b4 = *(const f32x4*)(a.bias + nb + 8 * q + 4 * hf);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float g_, d_;
+        gelu_pair(fmaf(alpha, acc[4 * q + r], b4[r]), g_, d_);
+        v[4 * q + r] = g_;
+        vmax = fmaxf(vmax, fabsf(g_));
+      }
+    }
+    if (LAST) {
+      float* o = a.outF + (size_t)(32 * mt + l31) * a.N + nb + 4 * hf;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const f32x4 t4 = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *(f32x4*)(o + 8 * q) = t4; }
+    } else {
+      const float so = ldexpf(1.f, a.exps ? a.exps[a.eo] : 0);
+      unsigned w[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) w[r] = pack_hl(v[r] * so);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {           // the two 16-column halves of this 32-column tile = two k steps of the next layer
+        unsigned e[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32x2 p = __builtin_amdgcn_permlane32_swap(w[8 * s2 + k], w[8 * s2 + 4 + k], false, false);
+          e[k] = p[0]; e[4 + k] = p[1];          // lane hf 0: n 0..7 of the half, lane hf 1: n 8..15
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hi[k] = (e[2 * k] & 0xffffu) | (e[2 * k + 1] << 16); lo[k] = (e[2 * k] >> 16) | (e[2 * k + 1] & 0xffff0000u); }
+        char* t = a.outT + ((size_t)mt * (a.N >> 4) + (size_t)(nb >> 4) + s2) * 2048 + lane * 16;
+        *(u32x4*)t = hi; *(u32x4*)(t + 1024) = lo;
+      }
+    }
+  }
+  if (!LAST && a.amax) {
+    vmax = wave_max_f(vmax);
+    if (lane == 0) atomicMax((unsigned*)(a.amax + a.eo), __float_as_uint(vmax));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 // 0: plain two-substep loop, 1: software-pipelined 8-wavefront kernel (256 x 256 | 128 tiles, one workgroup per CU),
 // 2: the 4-wavefront 256 x 128 K16 kernel, two workgroups per CU (measurement aid; the default is the fastest measured)
@@ -1077,3 +1202,30 @@ extern "C" int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t
   MCHK(hipGetLastError());
   return HOIC_OK;
 }
+
+extern "C" int32_t hoic_mlp_pack_tiled(const float* d_x, int32_t R, int32_t C, int64_t ld, void* d_T, int32_t Rp, int32_t Kp, const int32_t* d_exps,
+                                       int32_t slot, void* stream) {
+  if (!d_x || !d_T || R <= 0 || C <= 0 || Rp < R || Kp < C || (Rp & 31) || (Kp & 15)) {
+    hoic_set_error("hoic_mlp_pack_tiled: padded sizes must be multiples of 32 (rows) and 16 (columns)"); return HOIC_ERR_ARG;
+  }
+  const long long n = (long long)(Rp >> 5) * (Kp >> 4);
+  hipLaunchKernelGGL(hoic_pack_tiled_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_x, R, C, (long long)ld, (char*)d_T, Rp, Kp, d_exps, slot);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_mlp_forward_tiled(int32_t M, int32_t N, int32_t K, const void* d_X, const void* d_W, const int32_t* d_exps, float* d_amax,
+                                          int32_t slot_x, int32_t slot_w, int32_t slot_out, const float* d_bias, void* d_outT, float* d_outF,
+                                          void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M & 31) || (N & 63) || (K & 15) || !d_X || !d_W || !d_bias || (!d_outT == !d_outF)) {
+    hoic_set_error("hoic_mlp_forward_tiled: M % 32, N % 64, K % 16 must be 0 and exactly one of d_outT / d_outF is given"); return HOIC_ERR_ARG;
+  }
+  FwdArgs a{};
+  a.X = (const char*)d_X; a.W = (const char*)d_W; a.M = M; a.N = N; a.K = K; a.exps = d_exps; a.amax = d_amax;
+  a.ex = slot_x; a.ew = slot_w; a.eo = slot_out; a.bias = d_bias; a.outT = (char*)d_outT; a.outF = d_outF;
+  const dim3 grid((unsigned)((M >> 5) * (N >> 6)));
+  if (d_outF) hipLaunchKernelGGL((hoic_fwd_tiled_kernel<true>), grid, dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((hoic_fwd_tiled_kernel<false>), grid, dim3(64), 0, (hipStream_t)stream, a);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+

@@ -71,8 +71,11 @@ class _Kernels:
         L.hoic_mlp_amax_colsum.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
         L.hoic_mlp_colpart_finish.argtypes = [vp, i32, i32, vp, vp]
         L.hoic_mlp_update_exps_rel.argtypes = [vp, vp, i32, C.c_uint64, i32, i32, vp, vp, vp]
+        L.hoic_mlp_pack_tiled.argtypes = [vp, i32, i32, i64, vp, i32, i32, vp, i32, vp]
+        L.hoic_mlp_forward_tiled.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
-                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel"):
+                  "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel",
+                  "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled"):
             getattr(L, n).restype = i32
         self.L = L
 
@@ -400,3 +403,91 @@ class SplitMLP:
             self.table.overflow.zero_()
             raise lib.HoicError(f"f16x3 GEMM path: {n} tensor(s) exceeded the float16 range under their delayed scale exponent; "
                                 "the update is not valid (use update_dtype='f32')")
+
+
+class TiledForward:
+    """The GELU MLP body's forward pass for the ROLLOUT batches (no gradients): hoic_mlp_forward_tiled, the f16x3 GEMM
+    that needs no LDS and <= 128 registers, so that its wavefronts run beside the simulator's substep kernel instead of
+    queueing for the CUs' LDS (include/hoic.h).  Operands live in the tiled format T; the weights are re-packed by
+    ``refresh()`` (once per PPO iteration), a batch's states by ``forward``.  ``x_bound``: known bound of |x| (the observation
+    filter clips at 5) -- the input's exponent is then a constant and no maximum pass is needed; None = measure."""
+    SLOT_X, SLOT_W0, SLOT_H0 = 0, 1, 4
+
+    def __init__(self, mlp, x_bound=None):
+        from .rl import MLP
+        assert isinstance(mlp, MLP) and isinstance(mlp.activation, torch.nn.GELU), "TiledForward needs a GELU rl.MLP"
+        self.layers = list(mlp.affine_layers)
+        self.dev = self.layers[0].weight.device
+        if self.dev.type != "cuda":
+            raise lib.HoicError("TiledForward: the f16x3 GEMMs run on the GPU only")
+        self.dims_in = [l.in_features for l in self.layers]
+        self.dims_out = [l.out_features for l in self.layers]
+        for n in self.dims_out:
+            assert n % 64 == 0, "hidden sizes must be multiples of 64 for the tiled forward"
+        self.Kp = [_rup(self.dims_in[0], 16)] + self.dims_out[:-1]
+        self.table = ScaleTable(self.dev)
+        self.x_bound = x_bound
+        self.M = None
+        self.WT = None
+        self.first = True
+
+    @staticmethod
+    def supports(mlp, rows):
+        from .rl import MLP
+        return (isinstance(mlp, MLP) and isinstance(mlp.activation, torch.nn.GELU) and rows % 32 == 0
+                and all(l.out_features % 64 == 0 for l in mlp.affine_layers) and mlp.affine_layers[0].weight.is_cuda)
+
+    def refresh(self):
+        """pack the current weights (exact exponents) into format T"""
+        K, t = kernels(), self.table
+        if self.WT is None:
+            self.WT = [torch.empty(n * kp * 4, dtype=torch.uint8, device=self.dev) for n, kp in zip(self.dims_out, self.Kp)]
+        for i, l in enumerate(self.layers):
+            W = l.weight.detach()
+            t.measure(self.SLOT_W0 + i, W); t.update([self.SLOT_W0 + i], exact=True)
+            K.chk(K.L.hoic_mlp_pack_tiled(_ptr(W), W.shape[0], W.shape[1], W.stride(0), _ptr(self.WT[i]), self.dims_out[i], self.Kp[i],
+                                          _ptr(t.exps), self.SLOT_W0 + i, _stream(self.dev)), "hoic_mlp_pack_tiled")
+
+    def forward(self, x):
+        """x: float32 [M, in] (M % 32 == 0) -> float32 [M, out] last hidden activation"""
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] % 32 == 0
+        M_ = x.shape[0]
+        K, t, L = kernels(), self.table, len(self.layers)
+        if self.WT is None:
+            self.refresh()
+        if self.M != M_:
+            self.M = M_
+            self.XT = torch.empty(M_ * self.Kp[0] * 4, dtype=torch.uint8, device=self.dev)
+            self.HT = [torch.empty(M_ * n * 4, dtype=torch.uint8, device=self.dev) for n in self.dims_out[:-1]]
+            self.out = torch.empty(M_, self.dims_out[-1], dtype=torch.float32, device=self.dev)
+            self.first = True
+        st = _stream(self.dev)
+        if self.x_bound is None:
+            t.measure(self.SLOT_X, x if x.is_contiguous() else x.contiguous()); t.update([self.SLOT_X], exact=True)
+        elif self.first:
+            with torch.no_grad():
+                t.exps[self.SLOT_X] = TARGET_LOG2 - int(np.ceil(np.log2(float(self.x_bound))))
+        if self.first:
+            with torch.no_grad():
+                for i in range(L - 1):
+                    t.exps[self.SLOT_H0 + i] = 4
+            self.first = False
+        elif L > 1:
+            t.update([self.SLOT_H0 + i for i in range(L - 1)])          # hidden activations: last pass's maxima
+        K.chk(K.L.hoic_mlp_pack_tiled(_ptr(x), M_, x.shape[1], x.stride(0), _ptr(self.XT), M_, self.Kp[0], _ptr(t.exps), self.SLOT_X, st),
+              "hoic_mlp_pack_tiled")
+        A, sa = self.XT, self.SLOT_X
+        for i, l in enumerate(self.layers):
+            last = i == L - 1
+            K.chk(K.L.hoic_mlp_forward_tiled(M_, self.dims_out[i], self.Kp[i], _ptr(A), _ptr(self.WT[i]), _ptr(t.exps), _ptr(t.amax), sa,
+                                             self.SLOT_W0 + i, self.SLOT_H0 + i, _ptr(l.bias.detach()), None if last else _ptr(self.HT[i]),
+                                             _ptr(self.out) if last else None, st), "hoic_mlp_forward_tiled")
+            if not last:
+                A, sa = self.HT[i], self.SLOT_H0 + i
+        return self.out
+
+    def check_overflow(self):
+        n = int(self.table.overflow.item())
+        if n:
+            self.table.overflow.zero_()
+            raise lib.HoicError(f"tiled forward: {n} hidden activation tensor(s) exceeded the float16 range under their delayed exponent")

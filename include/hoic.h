@@ -223,6 +223,21 @@ int32_t hoic_mlp_amax_colsum(const float* d_x, const float* d_mul, int32_t R, in
                              void* stream);
 int32_t hoic_mlp_colpart_finish(const float* d_part, int32_t nchunks, int32_t C, float* d_out, void* stream);
 int32_t hoic_mlp_set_pipeline(int32_t mode);
+/* The policy's forward pass during the rollout (replaces torch.nn.Linear + GELU of PolicyGaussian.select_action,
+ * uhc/khrylib/rl/core/policy_gaussian.py + uhc/khrylib/models/mlp.py:24-27, for the batched sampler): an f16x3 GEMM with
+ * fused bias + GELU that uses NO LDS and <= 128 registers, so that its wavefronts run beside the simulator's substep kernel
+ * (whose workgroups hold all of every CU's LDS) instead of queueing behind it.  Operands in the tiled format T of a matrix
+ * [R x K]: tile (a, s) = rows 32 a .. + 31, k = 16 s .. + 15 at byte ((a K/16 + s) * 2048): hi plane [64 lanes x 16 B], lo
+ * plane [64 x 16 B]; lane 32 hf + l holds row 32 a + l, k = 16 s + 8 hf .. + 7 (one contiguous KB per operand load).
+ * hoic_mlp_pack_tiled: float32 [R x C] (row stride ld) -> T [Rp x Kp] (Rp % 32 == Kp % 16 == 0, zero padded) at 2^d_exps[slot].
+ * hoic_mlp_forward_tiled: out = gelu(2^-(e_x + e_w) X W^T + bias), X = T [M x K], W = T [N x K] (M % 32 == N % 64 == K % 16
+ *   == 0) -> d_outT (format T [M x N] at 2^d_exps[slot_out], max |out| folded into d_amax[slot_out]: the next layer's
+ *   input) or d_outF (float32 row-major [M x N]: the last hidden layer); exactly one of the two. */
+int32_t hoic_mlp_pack_tiled(const float* d_x, int32_t R, int32_t C, int64_t ld, void* d_T, int32_t Rp, int32_t Kp, const int32_t* d_exps,
+                            int32_t slot, void* stream);
+int32_t hoic_mlp_forward_tiled(int32_t M, int32_t N, int32_t K, const void* d_X, const void* d_W, const int32_t* d_exps, float* d_amax,
+                               int32_t slot_x, int32_t slot_w, int32_t slot_out, const float* d_bias, void* d_outT, float* d_outF,
+                               void* stream);
 int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
                              float scale, void* stream);
 int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot,

@@ -140,6 +140,34 @@ def test_bias_gradient_partials_from_the_producing_kernels():
         M.set_pipeline(3)
 
 
+@gpu
+@pytest.mark.parametrize("rows,bound", [(2048, 5.0), (96, None)])
+def test_tiled_rollout_forward_matches_float64(rows, bound):
+    """TiledForward (the LDS-free f16x3 forward of the rollout policy: tiled operands, fused bias + GELU, tiled hand-over
+    between layers) against the float64 forward of the same network: 2e-6 of the activations' scale, also on the second
+    pass (delayed exponents of the hidden activations) and after a weight change + refresh()."""
+    import copy
+    hidden = (512, 256, 128)
+    net, _ = _nets(hidden, seed=4)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.clamp(torch.randn(rows, 617, device="cuda", generator=g) * 2.0, -5, 5)
+    eng = M.TiledForward(net, x_bound=bound)
+    assert M.TiledForward.supports(net, rows) and not M.TiledForward.supports(net, rows + 1)
+    for rep in range(3):
+        if rep == 2:
+            with torch.no_grad():
+                for l in net.affine_layers:
+                    l.weight.mul_(1.5); l.bias.add_(0.01)
+            eng.refresh()
+        h = eng.forward(x)
+        ref = copy.deepcopy(net).double()(x.double())
+        err = (h.double() - ref).abs().max().item()
+        assert h.shape == (rows, hidden[-1]) and err < 2e-6 * max(1.0, ref.abs().max().item()), (rep, err)
+        eng.check_overflow()
+    # float32 PyTorch is no closer
+    assert (net(x).double() - ref).abs().max().item() > 0.2 * err
+
+
 def test_split_choice_for_the_weight_gradient_kernels():
     """pick_splits16: tiles x splits fill the 512 workgroup slots (two per CU) in whole rounds, no split is empty"""
     for n, k, want in ((2048, 640, 12), (1024, 2048, 8), (512, 1024, 32)):
