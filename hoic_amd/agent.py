@@ -495,6 +495,7 @@ class AgentHandMimic:
         # its wavefronts fit beside the other range's substep workgroups, the float32 library GEMMs queue behind them
         # (measured: 6 ms of a 36 ms rollout).  One engine per range (own buffers and exponents: the ranges run concurrently).
         fwd = self._rollout_forward(groups) if (dt == torch.float32 and dev.type == "cuda") else None
+        std = torch.exp(self.policy_net.action_log_std) if fwd is not None else None
         # Per-step outputs go straight into the rollout's [T, N, .] storage (no copy kernels in a range's chain), the
         # next-episode draws of all T steps are made up front, masks and statistics are derived once at the end.
         direct = dt == torch.float32 and dev.type == "cuda"
@@ -522,11 +523,11 @@ class AgentHandMimic:
                         states[t, sl] = state
                     if direct:
                         if fwd is not None:
-                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl])
+                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl], std=std)
                         else:
                             action = self.policy_net.select_action(state, out=actions[t, sl])
                         self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count,
-                                      out=(rewards[t, sl], rinfo_all[t, sl], flags_all[t, sl], pct[sl]))
+                                      out=(rewards[t, sl], rinfo_all[t, sl], flags_all[t, sl], pct[sl]), want_info=False)
                     else:
                         action = self.policy_net.select_action(state)
                         self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count)

@@ -101,13 +101,15 @@ class BatchedHandObjMimic:
             start_idx = t.zeros(n, dtype=t.int32)
         return self.sim.reset(seq_idx, start_idx, env_ids)
 
-    def step(self, actions, next_seq=None, next_start=None, first=0, count=None, out=None):
+    def step(self, actions, next_seq=None, next_start=None, first=0, count=None, out=None, want_info=True):
         """-> (obs [n,617], env_reward (1.0), done [n] bool, info dict of tensors). The custom reward
         (ho_mimic_reward_9, fused in the kernel) is available as ``self.c_reward`` / ``self.c_info``.
         ``first`` / ``count``: step only that env range (all tensors then have ``count`` rows); ``out``: see
-        ``BatchedSim.step``."""
+        ``BatchedSim.step``; ``want_info=False``: skip the done / info tensors (three small kernels)."""
         obs, rew, rinfo, flags, pct = self.sim.step(actions, next_seq, next_start, first, count, out)
         self.c_reward, self.c_info = rew, rinfo
+        if not want_info:          # the batched sampler reads the flags itself: no per-step mask kernels in a range's chain
+            return obs, 1.0, None, None
         info = {"fail": flags[:, 0] != 0, "end": flags[:, 1] != 0, "percent": pct, "solver_iter": flags[:, 3]}
         return obs, 1.0, flags[:, 2] != 0, info
 

@@ -53,10 +53,12 @@ class PolicyGaussian(nn.Module):
             return mean if out is None else out.copy_(mean)
         return torch.addcmul(mean, torch.exp(log_std), torch.randn_like(mean), out=out)     # mean + std * eps
 
-    def select_action_from_hidden(self, hidden, out=None):
-        """select_action with the MLP body's output computed elsewhere (the rollout's LDS-free f16x3 forward)"""
+    def select_action_from_hidden(self, hidden, out=None, std=None):
+        """select_action with the MLP body's output computed elsewhere (the rollout's LDS-free f16x3 forward);
+        ``std``: exp(action_log_std) when the caller has it already (constant during a rollout)"""
         mean = self.action_mean(hidden)
-        return torch.addcmul(mean, torch.exp(self.action_log_std).expand_as(mean), torch.randn_like(mean), out=out)
+        std = torch.exp(self.action_log_std) if std is None else std
+        return torch.addcmul(mean, std.expand_as(mean), torch.randn_like(mean), out=out)
 
     def get_log_prob(self, x, action, hidden=None):
         """``hidden``: the MLP's output for ``x`` when it was computed elsewhere (the f16x3 GEMM path)"""
