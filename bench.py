@@ -207,6 +207,11 @@ def main():
     ap.add_argument("--groups", type=int, default=None, help="env ranges pipelined on separate streams during the rollout (default: 2 at >= 4096 envs)")
     args = ap.parse_args()
 
+    # Exactly ONE line on stdout: libraries print banners to file descriptor 1 (RCCL's version block at communicator creation),
+    # so everything but the JSON line goes to stderr for the whole run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -323,7 +328,8 @@ def main():
         if args.update_dtype == "f16x3":
             out["roofline_update_gemm"] = update_gemm_roofline(steps_per_iter * args.envs, torch.device("cuda", local_rank))
         out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         torch.distributed.destroy_process_group()
 
