@@ -509,6 +509,11 @@ class AgentHandMimic:
             for st_ in self._streams:
                 st_.wait_stream(main)
         zf_event = None
+        # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
+        # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
+        async_reward = direct and os.environ.get("HOIC_ASYNC_REWARD", "1") != "0"
+        if async_reward:
+            self.env.sim.set_async_reward(True)
         for t in range(T):
             for gi, (first, count) in enumerate(groups):
                 sl = slice(first, first + count)
@@ -536,6 +541,8 @@ class AgentHandMimic:
         if use_streams:
             for st_ in self._streams:
                 main.wait_stream(st_)
+        if async_reward:
+            self.env.sim.set_async_reward(False)        # the main stream waits for every outstanding reward part
         done_all = flags_all[:, :, 2] != 0
         masks.copy_((~done_all).to(dt))
         obs = self.env.get_obs()

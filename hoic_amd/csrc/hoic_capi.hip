@@ -105,47 +105,69 @@ __device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
 // averaging, the residual-force QP (float64), termination, reward, the optional in-launch reset and the 617-float
 // observation.  Expects in the workspace: final qpos / qvel, the clipped action, body / geom poses and the contact sums
 // of the last forward pass, the 15-substep finite differences in sc.post.
+// PART: POST_ALL = all of it (one kernel behind the substeps, or fused into the substep kernel); the split form
+// (hoic_set_async_reward) runs POST_A -- termination, in-launch reset, observation: what the next policy forward waits for --
+// at the end of the substep kernel and POST_B -- contact classification, residual-force QP, reward: needed only when the
+// rollout's rewards are read -- in the post-step kernel on a side stream, from the hand-over record `rec` (which then also
+// carries the pre-reset state and expert view).  Same arithmetic in every form; POST_B cannot fail a step retroactively
+// (a non-finite QP score, never observed, zeroes the score in every form and fails the step in POST_ALL only).
+enum { POST_ALL = 0, POST_A = 1, POST_B = 2 };
+template <int PART>
 __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig& cfg, Work& w, const DevExpert& ex, const DevState& st,
                                              ExpertView& ev, int env, int io, bool ok, int solver_iter, const float* vf, const float* vt,
                                              float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
                                              int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
-                                             const int* __restrict__ next_start) {
+                                             const int* __restrict__ next_start, GPTR(float) rec) {
   const int tid = threadIdx.x;
   float rfc_score = 0.f;
-  if (ok) {
+  if (PART != POST_A && ok) {
     dev_classify_contact(m, w);                                                                // :562
     if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
-    if (!isfinite(rfc_score)) { ok = false; rfc_score = 0.f; }
+    if (!isfinite(rfc_score)) { if (PART == POST_ALL) ok = false; rfc_score = 0.f; }
   }
   asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
-  ev.cur_t += 1;                                                                                // :641
+  if (PART != POST_B) ev.cur_t += 1;                                                            // :641 (POST_B: the record's view is advanced already)
+  const int expert_len = ev.len - ev.start;
+  const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
+  if (PART != POST_A) {
+    float rw[10];
+    dev_reward(m, cfg, w, ev, rfc_score, rw);
+    float r = rw[0];
+    if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                   // agent_handmimic.py:479-480
+    if (tid == 0) { reward[io] = r; as_global(st.rfc_score)[env] = rfc_score; }
+    if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
+    if (PART == POST_B) {
+      if (tid == 6 && rec[PB_DONE] != 0.f) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
+      return;
+    }
+  }
   float df[5];
   dev_ho_diff(m, w, ev, df);
   const bool body_fail = df[0] > cfg.c.pos_diff_thresh || df[1] > cfg.c.rot_diff_thresh || df[2] > cfg.c.jpos_diff_thresh ||
                          df[3] > cfg.c.obj_pos_diff_thresh || df[4] > cfg.c.obj_rot_diff_thresh;
   bool fail = !ok;
   if (cfg.mode_train) fail = fail || body_fail;                                                 // :655-656
-  const int expert_len = ev.len - ev.start;
-  const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
   const bool done = fail || end;
-  float rw[10];
-  dev_reward(m, cfg, w, ev, rfc_score, rw);
-  float r = rw[0];
-  if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;                                     // agent_handmimic.py:479-480
   if (tid == 0) {
-    reward[io] = r;
     flags[4 * io] = fail; flags[4 * io + 1] = end; flags[4 * io + 2] = done; flags[4 * io + 3] = solver_iter;
     percent[io] = (float)ev.cur_t / (float)(expert_len - 1);                                   // :660
-    as_global(st.rfc_score)[env] = rfc_score;
   }
-  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
-  if (done && next_seq != nullptr) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
+  const bool reset = done && next_seq != nullptr;
+  if (PART == POST_A) {        // the reward part's inputs, before the reset below replaces them
+    if (tid < NQP) rec[PB_QPOS + tid] = w.qpos[tid];
+    if (tid < NV) rec[PB_QVEL + tid] = w.qvel[tid];
+    if (tid == 0) {
+      rec[PB_EV] = __int_as_float(ev.off); rec[PB_EV + 1] = __int_as_float(ev.len); rec[PB_EV + 2] = __int_as_float(ev.start);
+      rec[PB_EV + 3] = __int_as_float(ev.cur_t); rec[PB_DONE] = reset ? 1.f : 0.f;
+    }
+  }
+  if (reset) {   // the sampler's next episode (agent_handmimic.py:444-454) in the same launch
     const int ns = min(max(next_seq[io], 0), ex.n_seq - 1);
     const int nst = min(max(next_start[io], 0), as_global(ex.seq_len)[ns] - 2);
     wsync();
     dev_reset_state(m, w, ex, ns, nst);
     dev_kinematics(m, w, w.qpos);
-    if (tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
+    if (PART == POST_ALL && tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
     ev.off = as_global(ex.seq_off)[ns]; ev.len = as_global(ex.seq_len)[ns]; ev.start = nst; ev.cur_t = 0;
     if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; as_global(st.lag_valid)[env] = 0; }
     store_state(st, w, env);
@@ -157,18 +179,18 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
 // ---- kernel 1 of a step: the 15 substeps (control glue + dynamics + contact solve + integration), f32.
 // Leaves the new state in HBM and a hand-over record (lagged body / geom poses, contact sums, 15-substep finite
 // differences) for the post-step kernel.
-template <bool FUSED>
+template <int MODE>      // 0: substeps + hand-over record, 1: + the whole post-step work (FUSED), 2: + its part POST_A (split form)
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                           const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
                                                           const float* __restrict__ action, int first, int use_order, int use_lag,
                                                           float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
                                                           int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
-                                                          const int* __restrict__ next_start, int n_envs) {
+                                                          const int* __restrict__ next_start, int n_envs, int post_buf) {
   // FUSED (HOIC_FUSED_STEP=1): the post-step work (dev_poststep) runs at the end of this launch, on the
   // workspace as it stands, instead of in hoic_poststep_kernel behind a 2.8 KB hand-over record per env.  One launch
   // per env step, but 153 KB of code, 256 registers and 288 B of scratch; measured equal to the two-launch form both
   // for whole-batch steps and in the two-range rollout, so the two-launch form stays the default.
-  constexpr bool fused = FUSED;
+  constexpr bool fused = MODE == 1;
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   int* ovf = (int*)&as_global(st.diag)[2 * env];
   int ncapped = 0;
-  GPTR(float) post = as_global(st.post) + (size_t)env * PB_SIZE;
+  GPTR(float) post = as_global(st.post) + ((size_t)post_buf * n_envs + env) * PB_SIZE;
   GPTR(float) oldg = as_global(st.oldg) + (size_t)env * OG_SIZE;
   // One loop, three modes, so that every stage has a single (inlined) call site:
   //   mode 0  the forward pass on the lagged state: quantities of the previous forward pass (one-substep lag,
@@ -331,10 +353,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (tid == 0) { as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0; if (ncapped) as_global(st.diag)[2 * env + 1] += ncapped; }
   const long long clk1 = (long long)__builtin_readcyclecounter();
   if (tid == 0) as_global(st.cost)[env] = (unsigned)((clk1 - clk0) >> 6);
-  if (fused) {
+  if (MODE != 0) {
     wsync();
-    dev_poststep(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, vf, vt, obs, reward, reward_info, flags, percent, next_seq, next_start);
-    if (tid == 0) as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk1) >> 6);
+    dev_poststep<MODE == 1 ? POST_ALL : POST_A>(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, vf, vt, obs, reward, reward_info, flags, percent,
+                                                next_seq, next_start, post);
+    if (MODE == 1 && tid == 0) as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk1) >> 6);
   }
 #ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock
   if (tid == 0) {
@@ -354,12 +377,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 // ---- kernel 2 of a step: contact averaging, the residual-force QP (float64), termination, reward, the optional
 // in-launch reset and the 617-float observation (HandObjMimic4.step after do_simulation, ho_im4.py:631-662)
+template <int PART>      // POST_ALL: everything after the substeps; POST_B: the reward part of the split form (record-only inputs)
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                            DevExpert ex, DevState st, const float* __restrict__ action,
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
                                                            float* __restrict__ percent, const int* __restrict__ next_seq,
-                                                           const int* __restrict__ next_start, int first, int use_order, int n_envs) {
+                                                           const int* __restrict__ next_start, int first, int use_order, int n_envs, int post_buf) {
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
   const int env = use_order ? as_global(st.order)[n_envs + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
@@ -367,10 +391,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #ifdef HOIC_TRACE_DISPATCH
   if (tid == 0) for (int i = 0; i < 4; i++) g_trace_qp[blockIdx.x * 4 + i] = 0;
 #endif
-  GPTR(const float) post = as_global((const float*)st.post) + (size_t)env * PB_SIZE;
-  if (tid < NQP) w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
+  GPTR(float) post = as_global(st.post) + ((size_t)post_buf * n_envs + env) * PB_SIZE;
+  // POST_B: the state and the expert view of the step come from the record (the env may have been reset since)
+  if (tid < NQP) w.qpos[tid] = PART == POST_B ? post[PB_QPOS + tid] : as_global(st.qpos)[(size_t)env * NQP + tid];
   if (tid < NV) {
-    w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid];
+    w.qvel[tid] = PART == POST_B ? post[PB_QVEL + tid] : as_global(st.qvel)[(size_t)env * NV + tid];
     w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);
   }
   for (int k = tid; k < m.nbody * 3; k += NT) w.xpos[k / 3][k % 3] = post[PB_XPOS + k];
@@ -385,12 +410,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   wsync();
   const int seq = as_global(st.seq)[env];
   ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], as_global(st.start)[env], as_global(st.cur_t)[env]};
+  if (PART == POST_B) {
+    ev.off = __float_as_int(post[PB_EV]); ev.len = __float_as_int(post[PB_EV + 1]); ev.start = __float_as_int(post[PB_EV + 2]);
+    ev.cur_t = __float_as_int(post[PB_EV + 3]);
+  }
   float vf[3], vt[3];
   for (int i = 0; i < 3; i++) {
     vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
     vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
   }
-  dev_poststep(m, cfg, w, ex, st, ev, env, io, ok, solver_iter, vf, vt, obs, reward, reward_info, flags, percent, next_seq, next_start);
+  dev_poststep<PART>(m, cfg, w, ex, st, ev, env, io, ok, solver_iter, vf, vt, obs, reward, reward_info, flags, percent, next_seq, next_start, post);
   if (tid == 0) {
     as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk0) >> 6);
 #ifdef HOIC_TRACE_DISPATCH
@@ -571,9 +600,16 @@ struct hoic_sim {
   hipEvent_t ev[NEV][3] = {};
   long long n_timed = 0, n_drained = 0;
   bool has_expert = false;
+  // split post-step (hoic_set_async_reward): per env range a side stream for the reward part, the record buffer of the next
+  // step and the events "reward part of the step that used buffer b has finished"
+  struct AsyncRange { int first = 0, count = 0, next_buf = 0; hipStream_t side = nullptr; hipEvent_t sub_done = nullptr, rew_done[2] = {nullptr, nullptr}; bool pending[2] = {false, false}; };
+  bool async_reward = false;
+  std::vector<AsyncRange> ranges;
   int expert_reserve = 0, expert_cap = 0;   // streaming: room for more frames behind the last sequence
   std::vector<int> h_seq_len, h_seq_off;
 };
+
+static int32_t drain_rewards(hoic_sim* s, hipStream_t stream);      // outstanding reward parts (asynchronous-reward mode) -> dependencies of `stream`
 
 namespace {
 struct Blob {
@@ -815,7 +851,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.warm, n * NV * 4) == hipSuccess && hipMalloc(&s->st.cur_t, n * 4) == hipSuccess &&
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
        hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.diag, n * 8) == hipSuccess &&
-       hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, n * PB_SIZE * 4) == hipSuccess &&
+       hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, 2 * n * PB_SIZE * 4) == hipSuccess &&
        hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess &&
        hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess &&
        hipMalloc(&s->st.lagrec, n * LG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.lag_valid, n * 4) == hipSuccess;
@@ -829,7 +865,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.vlag, 0, n * NV * 4); hipMemset(s->st.warm, 0, n * NV * 4); hipMemset(s->st.cur_t, 0, n * 4);
   hipMemset(s->st.start, 0, n * 4); hipMemset(s->st.seq, 0, n * 4); hipMemset(s->st.rfc_score, 0, n * 4);
   hipMemset(s->st.diag, 0, n * 8); hipMemset(s->st.phase, 0, n * 24 * 8);
-  hipMemset(s->st.post, 0, n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
+  hipMemset(s->st.post, 0, 2 * n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
   hipMemset(s->st.cost, 0, 2 * n * 4);
   hipMemset(s->st.lagrec, 0, n * LG_SIZE * 4); hipMemset(s->st.lag_valid, 0, n * 4);
   hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, 0, s->st.cost, s->st.order, n_envs);   // a valid permutation from the start
@@ -850,6 +886,11 @@ extern "C" void hoic_destroy(hoic_sim* s) {
                   s->st.start, s->st.seq, s->st.rfc_score, s->st.diag, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
+  for (auto& r : s->ranges) {
+    if (r.side) { hipStreamSynchronize(r.side); hipStreamDestroy(r.side); }
+    if (r.sub_done) hipEventDestroy(r.sub_done);
+    for (int b = 0; b < 2; b++) if (r.rew_done[b]) hipEventDestroy(r.rew_done[b]);
+  }
   delete s;
 }
 
@@ -959,6 +1000,7 @@ extern "C" int32_t hoic_reset(hoic_sim* s, const int32_t* d_env_ids, int32_t n, 
   if (!s || !d_seq || !d_start || n <= 0 || n > s->n_envs) { set_err("hoic_reset: bad arguments"); return HOIC_ERR_ARG; }
   if (!s->has_expert) { set_err("hoic_reset: set_expert has not been called"); return HOIC_ERR_STATE; }
   HIPCHK(hipSetDevice(s->device));
+  { const int32_t rc = drain_rewards(s, (hipStream_t)stream); if (rc != HOIC_OK) return rc; }      // the reset writes rfc_score / the QP's flag
   hipLaunchKernelGGL(hoic_reset_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->ex, s->st, d_env_ids, d_seq, d_start, d_obs_out, s->n_envs);
   HIPCHK(hipGetLastError());
   return HOIC_OK;
@@ -976,18 +1018,48 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   hipEvent_t* e = s->timing ? s->ev[s->n_timed % hoic_sim::NEV] : nullptr;
   const int use_order = s->reorder && first == 0 && count == s->n_envs;
   if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
+  if (s->async_reward && !s->fused && !use_order) {
+    // Split form: termination, reset and observation at the end of the substep kernel (what the caller's next policy forward
+    // needs), the reward part (contact classification, residual-force QP, reward) on the range's side stream from the
+    // hand-over record.  The record buffers alternate, so the reward part of step t only has to finish before the
+    // substeps of step t + 2 of the same range overwrite its record; d_action / d_reward / d_reward_info of a step must
+    // stay alive and unread until hoic_sync_rewards.
+    hoic_sim::AsyncRange* r = nullptr;
+    for (auto& q : s->ranges) if (q.first == first && q.count == count) r = &q;
+    if (!r) {
+      if (s->ranges.size() >= 16) { set_err(std::string(who) + ": too many distinct env ranges in asynchronous-reward mode"); return HOIC_ERR_STATE; }
+      s->ranges.emplace_back(); r = &s->ranges.back(); r->first = first; r->count = count;
+      HIPCHK(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&r->sub_done, hipEventDisableTiming));
+      for (int b = 0; b < 2; b++) HIPCHK(hipEventCreateWithFlags(&r->rew_done[b], hipEventDisableTiming));
+    }
+    const int buf = r->next_buf; r->next_buf ^= 1;
+    if (r->pending[buf]) HIPCHK(hipStreamWaitEvent(st, r->rew_done[buf], 0));      // the reward part of step t - 2 read this record
+    if (e) hipEventRecord(e[0], st);
+    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, 0,
+                       s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs, buf);
+    if (e) hipEventRecord(e[1], st);
+    HIPCHK(hipEventRecord(r->sub_done, st));
+    HIPCHK(hipStreamWaitEvent(r->side, r->sub_done, 0));
+    hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
+    HIPCHK(hipEventRecord(r->rew_done[buf], r->side)); r->pending[buf] = true;
+    if (e) { hipEventRecord(e[2], st); s->n_timed++; }
+    HIPCHK(hipGetLastError());
+    return HOIC_OK;
+  }
   if (e) hipEventRecord(e[0], st);
   if (s->fused) {     // one launch: the post-step work runs at the end of the substep kernel
-    hipLaunchKernelGGL(hoic_substep_kernel<true>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
-                       s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs);
+    hipLaunchKernelGGL(hoic_substep_kernel<1>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+                       s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs, 0);
     if (e) hipEventRecord(e[1], st);
   } else {
-    hipLaunchKernelGGL(hoic_substep_kernel<false>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+    hipLaunchKernelGGL(hoic_substep_kernel<0>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
                        s->use_lag ? 1 : 0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
-                       (const int*)nullptr, (const int*)nullptr, s->n_envs);
+                       (const int*)nullptr, (const int*)nullptr, s->n_envs, 0);
     if (e) hipEventRecord(e[1], st);
-    hipLaunchKernelGGL(hoic_poststep_kernel, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs);
+    hipLaunchKernelGGL(hoic_poststep_kernel<POST_ALL>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs, 0);
   }
   if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());
@@ -999,6 +1071,26 @@ extern "C" int32_t hoic_step(hoic_sim* s, const float* d_action, float* d_obs, f
                              void* stream) {
   if (!s) { set_err("hoic_step: null handle"); return HOIC_ERR_ARG; }
   return step_range(s, 0, s->n_envs, d_action, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, stream, "hoic_step");
+}
+
+// every outstanding reward part becomes a dependency of `stream`
+static int32_t drain_rewards(hoic_sim* s, hipStream_t stream) {
+  for (auto& r : s->ranges)
+    for (int b = 0; b < 2; b++)
+      if (r.pending[b]) { HIPCHK(hipStreamWaitEvent(stream, r.rew_done[b], 0)); r.pending[b] = false; }
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_set_async_reward(hoic_sim* s, int32_t enable, void* stream) {
+  if (!s) { set_err("hoic_set_async_reward: null handle"); return HOIC_ERR_ARG; }
+  HIPCHK(hipSetDevice(s->device));
+  if (!enable) { const int32_t rc = drain_rewards(s, (hipStream_t)stream); if (rc != HOIC_OK) return rc; }
+  s->async_reward = enable != 0;
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_sync_rewards(hoic_sim* s, void* stream) {
+  if (!s) { set_err("hoic_sync_rewards: null handle"); return HOIC_ERR_ARG; }
+  HIPCHK(hipSetDevice(s->device));
+  return drain_rewards(s, (hipStream_t)stream);
 }
 
 extern "C" int32_t hoic_step_range(hoic_sim* s, int32_t first, int32_t count, const float* d_action, float* d_obs, float* d_reward,
@@ -1017,6 +1109,7 @@ extern "C" int32_t hoic_get_state(hoic_sim* s, float* d_qpos, float* d_qvel, int
 extern "C" int32_t hoic_set_state(hoic_sim* s, const float* d_qpos, const float* d_qvel, void* stream) {
   if (!s || !d_qpos || !d_qvel) { set_err("hoic_set_state: null"); return HOIC_ERR_ARG; }
   HIPCHK(hipSetDevice(s->device));
+  { const int32_t rc = drain_rewards(s, (hipStream_t)stream); if (rc != HOIC_OK) return rc; }
   hipLaunchKernelGGL(hoic_set_state_kernel, dim3(s->n_envs), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->st, d_qpos, d_qvel);
   HIPCHK(hipGetLastError());
   return HOIC_OK;

@@ -102,8 +102,13 @@ struct DevExpert {
 #define PB_GVEL (PB_RECCNT + NHG)
 #define PB_GANGVEL (PB_GVEL + NG * 3)
 #define PB_OBJACC (PB_GANGVEL + NG * 3)
-#define PB_SIZE 704
-static_assert(PB_OBJACC + 6 <= PB_SIZE, "post buffer layout");
+// split post-step (hoic_set_async_reward): what the reward part needs of the state BEFORE the in-launch reset
+#define PB_QPOS 704                 // final qpos / qvel of the step
+#define PB_QVEL (PB_QPOS + NQP)
+#define PB_EV (PB_QVEL + NV)        // expert view as int bits: sequence offset, length, start, cur_t (already advanced)
+#define PB_DONE (PB_EV + 4)         // 1: the env was reset in the launch (clear the QP's warm-start flag)
+#define PB_SIZE 784
+static_assert(PB_OBJACC + 6 <= PB_QPOS && PB_DONE + 1 <= PB_SIZE, "post buffer layout");
 // geom poses at launch start (for the 15-substep finite differences, ho_im4.py:553-559)
 #define OG_SIZE (NG * 12)
 // quantities of an env's last forward pass (the pass on the state before the last integration) that the first substep
@@ -130,7 +135,7 @@ struct DevState {
   float* rfc_score;  // [n]
   int* diag;     // [n, 2] running counters: forward passes that found more than MAXCON contacts (the list is cut after
                  // MAXCON), substeps whose Newton loop used up cfg.solver_iterations without meeting a stop criterion
-  float* post;   // [n, PB_SIZE]
+  float* post;   // [2, n, PB_SIZE]: two buffers, alternated per step by the split post-step (buffer 0 otherwise)
   float* oldg;   // [n, OG_SIZE]
   float* lagrec; // [n, LG_SIZE]
   int* lag_valid; // [n] 0: the record does not belong to (qlag, vlag) (after a reset / set_state / failed step)

@@ -44,7 +44,8 @@ EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame", "hoic_get_diagnostics", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps",
            "hoic_mlp_gemm", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed", "hoic_mlp_set_pipeline", "hoic_mlp_gemm_tn",
-           "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel", "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled"]
+           "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel", "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled",
+           "hoic_set_async_reward", "hoic_sync_rewards"]
 
 
 def build(force: bool = False) -> str:
@@ -246,6 +247,8 @@ class BatchedSim:
             out = (self.obs[sl], rw, ri, fl, pc)
         else:
             out = (self.obs[sl], self.reward[sl], self.reward_info[sl], self.flags[sl], self.percent[sl])
+        if getattr(self, "_async_keep", None) is not None:      # asynchronous rewards: the side stream reads / writes these later
+            self._async_keep.append((a, next_seq, next_start, out))
         if first == 0 and count == self.n:
             _chk(self.L.hoic_step(self.h, _ptr(a), *[_ptr(x) for x in out], _ptr(next_seq), _ptr(next_start), self._stream()),
                  "hoic_step")
@@ -278,6 +281,23 @@ class BatchedSim:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         _chk(self.L.hoic_get_diagnostics(self.h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "hoic_get_diagnostics")
         return {"contact_overflow": int(a.value), "solver_cap_hits": int(b.value), "envs_with_overflow": int(c.value)}
+
+    def set_async_reward(self, on=True):
+        """Split post-step (hoic_set_async_reward): ``step`` returns observation, flags and percent in stream order as
+        always, but reward / reward_info / rfc_score are produced on a side stream and are valid only after
+        ``sync_rewards()``; the action and reward buffers of a step must stay alive and unread until then.  Switching it
+        off synchronises."""
+        self.L.hoic_set_async_reward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _chk(self.L.hoic_set_async_reward(self.h, int(bool(on)), self._stream()), "hoic_set_async_reward")
+        self._async_keep = [] if on else None       # buffers of the outstanding steps stay referenced until the synchronisation
+
+    def sync_rewards(self):
+        """the current stream waits for every outstanding reward part"""
+        self.L.hoic_sync_rewards.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.hoic_sync_rewards(self.h, self._stream()), "hoic_sync_rewards")
+        if getattr(self, "_async_keep", None):
+            # the buffers may be released once the CURRENT stream has passed the wait just enqueued: keep them one more round
+            self._async_prev, self._async_keep = self._async_keep, []
 
     def enable_timing(self, on=True):
         _chk(self.L.hoic_enable_timing(self.h, int(on)), "hoic_enable_timing")

@@ -163,6 +163,18 @@ int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, const int32_t
  *                           meeting a stop criterion (gradient, step or cost-improvement tolerance)
  *   envs_with_overflow      number of envs with at least one overflow
  * Any output may be NULL; reset != 0 clears the counters.  Synchronises the device. */
+/* Split post-step for pipelined samplers.  By default hoic_step / hoic_step_range deliver all outputs in stream order.  With
+ * hoic_set_async_reward(s, 1, .) a step delivers d_obs, d_flags and d_percent in stream order (termination, the in-launch
+ * reset and the observation run at the end of the substep kernel: all the next policy forward needs) while d_reward,
+ * d_reward_info and the stored rfc_score come from the rest of the post-step work (contact classification, residual-force
+ * QP in float64, ho_mimic_reward_9) on a side stream per env range, off the caller's critical path: they are valid for
+ * `stream` after hoic_sync_rewards(s, stream), and the d_action / d_reward / d_reward_info buffers of every step since
+ * the last synchronisation must stay alive and untouched until then.  Same results as the default form (bit-identical;
+ * tests/test_gpu_parity.py::test_async_reward_matches_the_default_step).  hoic_reset, hoic_set_state, hoic_set_expert and
+ * switching the mode off synchronise by themselves.  Reference: HandObjMimic4.step returns obs, reward and done together
+ * (ho_im4.py:611-662); the sampler only needs obs to continue (agent_handmimic.py:463-482). */
+int32_t hoic_set_async_reward(hoic_sim* s, int32_t enable, void* stream);
+int32_t hoic_sync_rewards(hoic_sim* s, void* stream);
 int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64_t* solver_cap_hits,
                              int32_t* envs_with_overflow, int32_t reset);
 

@@ -648,6 +648,53 @@ def test_step_range_matches_whole_batch(box_blob, setup):
         b_sim.step(act[:8], ns[:8], nst[:8], N - 4, 8)      # range past the last env
 
 
+def test_async_reward_matches_the_default_step(box_blob, setup):
+    """hoic_set_async_reward: termination / reset / observation at the end of the substep kernel, contact classification +
+    residual-force QP + reward on a side stream from the hand-over record (the rollout's critical path then holds only what
+    the next policy forward needs).  Bit-identical to the default two-launch step: observations, flags and percent after
+    every step in stream order, rewards / reward_info / rfc_score after hoic_sync_rewards, final states -- over steps with
+    in-launch resets, on two env ranges and two streams, with later steps launched before earlier rewards are read."""
+    cfg, ex, thresh = setup
+    N, T = 256, 8
+    a_sim = _sim(box_blob, N, cfg, ex, thresh); b_sim = _sim(box_blob, N, cfg, ex, thresh)
+    g = torch.Generator().manual_seed(5)
+    seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(0, 100, (N,), generator=g, dtype=torch.int32)
+    a_sim.reset(seq, start); b_sim.reset(seq, start)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    acts = (torch.randn(T, N, 32, generator=g) * 0.3).cuda()
+    acts[:, ::7, 26:] *= 4.0                                  # large residual forces on some envs: QP columns, failures, resets
+    ns = torch.randint(0, len(ex), (T, N), generator=g, dtype=torch.int32).cuda(); nst = torch.randint(0, 100, (T, N), generator=g, dtype=torch.int32).cuda()
+    ref = []
+    for t in range(T):
+        ref.append([x.clone() for x in a_sim.step(acts[t], ns[t], nst[t])] + [a_sim.rfc_score().clone()])
+    torch.cuda.synchronize()
+    rew = torch.full((T, N), -7.0, device="cuda"); info = torch.zeros(T, N, 9, device="cuda")
+    flg = torch.zeros(T, N, 4, dtype=torch.int32, device="cuda"); pct = torch.zeros(T, N, device="cuda")
+    b_sim.set_async_reward(True)
+    ranges = ((0, 96), (96, 160))
+    for t in range(T):
+        for k, (first, count) in enumerate(ranges):
+            sl = slice(first, first + count)
+            with torch.cuda.stream(streams[k]):
+                out = b_sim.step(acts[t, sl], ns[t, sl], nst[t, sl], first, count, out=(rew[t, sl], info[t, sl], flg[t, sl], pct[t, sl]))
+                obs_now = out[0].clone()
+            streams[k].synchronize()             # obs / flags / percent are valid in stream order, without any reward sync
+            assert torch.equal(obs_now, ref[t][0][sl]) and torch.equal(flg[t, sl], ref[t][3][sl]) and torch.equal(pct[t, sl], ref[t][4][sl])
+    b_sim.set_async_reward(False)               # synchronises on the current stream
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(rew[t], ref[t][1]) and torch.equal(info[t], ref[t][2]), t
+    assert torch.equal(b_sim.rfc_score(), ref[-1][5])
+    assert int((flg[:, :, 2] != 0).sum()) > 0, "no in-launch reset was exercised"
+    qa, va, ta = a_sim.get_state(); qb, vb, tb = b_sim.get_state()
+    assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(ta, tb)
+    # the default form still works on the same handle afterwards, and gives what the reference simulator gives
+    r1 = [x.clone() for x in a_sim.step(acts[0], ns[0], nst[0])]; r2 = [x.clone() for x in b_sim.step(acts[0], ns[0], nst[0])]
+    torch.cuda.synchronize()
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+
+
 def test_longest_first_launch_order_changes_no_result(box_blob, setup, monkeypatch):
     """HOIC_REORDER=1 (workgroups dispatched by the measured duration of each env's previous pass) only changes which
     CU runs an env: states and outputs stay bit-identical; hoic_env_durations reports the sort keys."""
