@@ -1044,7 +1044,7 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
     hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
                        d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
     HIPCHK(hipEventRecord(r->rew_done[buf], r->side)); r->pending[buf] = true;
-    if (e) { hipEventRecord(e[2], st); s->n_timed++; }
+    if (e) { hipEventRecord(e[2], r->side); s->n_timed++; }      // "post-step" time of this form: end of the substeps -> end of the reward part
     HIPCHK(hipGetLastError());
     return HOIC_OK;
   }
