@@ -258,6 +258,20 @@ class PPOLearner:
                 self.optimizer_value.step()
             policy_step(p_pending)
             self._losses = (value_loss.detach(), surr.detach())
+        elif os.environ.get("HOIC_UPDATE_STREAMS", "2") == "2":
+            # The two networks' chains are independent within an update: the value chain goes to a side stream and the GPU
+            # runs workgroups of both.  Unlike the float32 library GEMMs of round 1 (which filled the GPU: no gain), the
+            # f16x3 kernels leave partial rounds (1664 workgroups on 512 slots) and HBM-bound epilogues for the other
+            # chain's workgroups to fill.
+            cur = torch.cuda.current_stream(self.device)
+            if self._value_stream is None:
+                self._value_stream = torch.cuda.Stream(self.device)
+            self._value_stream.wait_stream(cur)
+            with torch.cuda.stream(self._value_stream):
+                value_loss = value_phase()
+            surr = policy_phase()
+            cur.wait_stream(self._value_stream)
+            self._losses = (value_loss, surr)
         else:
             value_loss = value_phase()
             self._losses = (value_loss, policy_phase())
