@@ -201,6 +201,9 @@ def main():
                     help="untimed PPO iterations before the warm-up: the timed region then runs a policy that tracks the motions and holds "
                          "the object (contact-rich) instead of the random initial policy")
     ap.add_argument("--overlap", type=int, default=0, help="1: value-network steps on a side stream under the next rollout (f16x3 only; measured: no gain, the GEMM workgroups take the CUs' LDS); 0: serial")
+    ap.add_argument("--rollout-forward", default="tiled", choices=["tiled", "torch"], help="policy body during the rollout: LDS-free f16x3 kernel (with --update-dtype f16x3) or PyTorch float32")
+    ap.add_argument("--async-reward", type=int, default=1, help="1: rewards off the sampler's critical path (hoic_set_async_reward); 0: the default step")
+    ap.add_argument("--update-streams", type=int, default=2, choices=[1, 2], help="f16x3 update on one rank: value chain on a side stream (2) or one stream (1)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=None, help="Newton iteration cap per substep (default: the model's <option iterations>, 20)")
@@ -239,7 +242,8 @@ def main():
     agent = AgentHandMimic(cfg, device=torch.device("cuda", local_rank), n_envs=args.envs, model=args.obj,
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
                            solver_iterations=args.solver_iterations, n_groups=args.groups, scaling=args.scaling,
-                           start_min=100 if args.workload == "grasp" else 0, overlap_value_update=bool(args.overlap))
+                           start_min=100 if args.workload == "grasp" else 0, overlap_value_update=bool(args.overlap),
+                           rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams)
     share = world if args.scaling == "strong" else 1
     steps_per_iter = int(math.ceil(math.ceil(cfg.min_batch_size / share) / args.envs))
     n_warm_it = int(math.ceil(args.warmup / steps_per_iter)) if args.warmup > 0 else 0
@@ -309,6 +313,8 @@ def main():
                        "samples_per_iteration": steps_per_iter * args.envs * world, "parallelism": f"env-dp{world}",
                        "rollout_env_ranges": n_groups, "update_gemms": args.update_dtype,
                        "value_update_overlaps_next_rollout": bool(agent.learner.overlap_value_update),
+                       "rollout_policy_forward": "hoic_fwd_tiled_kernel (LDS-free f16x3)" if (args.rollout_forward == "tiled" and args.update_dtype == "f16x3") else "PyTorch float32",
+                       "async_reward": bool(args.async_reward), "update_streams": args.update_streams,
                        "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
                                                 if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,

@@ -84,7 +84,7 @@ class PPOLearner:
     Device-agnostic so the multi-rank path can be exercised with gloo on CPU."""
 
     def __init__(self, cfg: Config, state_dim, action_dim, device, dtype=torch.float32, distributed=False,
-                 update_dtype="f32", strict_reference=True):
+                 update_dtype="f32", strict_reference=True, fused_adam=True, update_streams=2):
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.distributed = distributed
         self.world, self.rank = 1, 0
@@ -99,8 +99,10 @@ class PPOLearner:
             import torch.distributed as dist
             for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
                 dist.broadcast(p.data, 0)
-        # one fused kernel per Adam step on the GPU (same arithmetic as the per-tensor form; HOIC_FUSED_ADAM=0 switches it off)
-        fused = {"fused": True} if (torch.device(device).type == "cuda" and os.environ.get("HOIC_FUSED_ADAM", "1") != "0") else {}
+        # fused_adam: one kernel per Adam step on the GPU (same arithmetic as the per-tensor form)
+        # update_streams: 2 = the value chain of the f16x3 update on a side stream (one rank), 1 = one stream
+        self.update_streams = int(update_streams)
+        fused = {"fused": True} if (torch.device(device).type == "cuda" and fused_adam) else {}
         self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay, **fused)
         self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=cfg.value_lr, weight_decay=cfg.value_weightdecay, **fused)
         self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
@@ -258,7 +260,7 @@ class PPOLearner:
                 self.optimizer_value.step()
             policy_step(p_pending)
             self._losses = (value_loss.detach(), surr.detach())
-        elif os.environ.get("HOIC_UPDATE_STREAMS", "2") == "2":
+        elif self.update_streams == 2:
             # The two networks' chains are independent within an update: the value chain goes to a side stream and the GPU
             # runs workgroups of both.  Unlike the float32 library GEMMs of round 1 (which filled the GPU: no gain), the
             # f16x3 kernels leave partial rounds (1664 workgroups on 512 slots) and HBM-bound epilogues for the other
@@ -353,11 +355,17 @@ class AgentHandMimic:
     def __init__(self, cfg: Config, dtype=torch.float32, device=None, training=True, checkpoint_epoch=0,
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
-                 start_min=0, overlap_value_update=False):
+                 start_min=0, overlap_value_update=False, rollout_forward="tiled", async_reward=True, fused_adam=True,
+                 update_streams=2):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
         self.scaling = scaling
+        # rollout_forward: "tiled" = the policy body on the LDS-free f16x3 kernel whenever the learner runs f16x3 (it fits
+        # beside the substep kernel), "torch" = PyTorch float32;  async_reward: the fixed-horizon sampler takes the rewards
+        # off its critical path (hoic_set_async_reward);  both are on by default and exist as switches for A/B measurements
+        assert rollout_forward in ("tiled", "torch")
+        self.rollout_forward, self.async_reward = rollout_forward, bool(async_reward)
         self.start_min = int(start_min)      # episodes start at frame >= start_min (benchmark workloads; the reference draws from 0)
         self.cfg = self.cc_cfg = cfg
         self.sample_mode = sample_mode
@@ -394,7 +402,7 @@ class AgentHandMimic:
         from . import tuning
         self.tuned_gemms = tuning.enable_tuned_gemms()      # recorded hipBLASLt kernel selections for the MLP shapes
         self.learner = PPOLearner(cfg, self.state_dim, self.action_dim, self.device, dtype, distributed, update_dtype,
-                                  strict_reference)
+                                  strict_reference, fused_adam=fused_adam, update_streams=update_streams)
         # the value network's five steps on a side stream, under the next iteration's rollout (f16x3 update on the GPU only)
         self.learner.overlap_value_update = bool(overlap_value_update) and update_dtype == "f16x3" and self.device.type == "cuda"
         self.policy_net, self.value_net = self.learner.policy_net, self.learner.value_net
@@ -468,7 +476,7 @@ class AgentHandMimic:
     def _rollout_forward(self, groups):
         """TiledForward engines of the rollout ranges (f16x3 learner, GELU policy body, range sizes that are multiples of
         32), their weights re-packed from the current policy; None = the PyTorch float32 forward."""
-        if self.learner.update_dtype != "f16x3" or os.environ.get("HOIC_ROLLOUT_FWD", "tiled") != "tiled":
+        if self.learner.update_dtype != "f16x3" or self.rollout_forward != "tiled":
             return None
         from . import mlp as _mlp
         if not all(_mlp.TiledForward.supports(self.policy_net.net, count) for _, count in groups):
@@ -525,7 +533,7 @@ class AgentHandMimic:
         zf_event = None
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
-        async_reward = direct and os.environ.get("HOIC_ASYNC_REWARD", "1") != "0"
+        async_reward = direct and self.async_reward
         if async_reward:
             self.env.sim.set_async_reward(True)
         for t in range(T):
