@@ -60,10 +60,13 @@ def traffic_from_profile(envs, obj):
     return None if p is None else p[1]["traffic_bytes_per_launch"]
 
 
-def valu_roofline(kernel_ms, envs_per_launch):
+def valu_roofline(kernel_ms, envs_per_launch, rollout_env_steps=None, rollout_s=None):
     """The dominant kernel against the vector-issue peak: VALU instructions per wavefront (= per env-step) from the
     committed SQ counter pass (profiles/*_substep_sq_counters.json) x 64 lanes x envs per launch / the launch time
-    measured here."""
+    measured here.  `achieved` / `frac` price ONE launch against the whole chip although the rollout keeps one launch per
+    env range in flight; `achieved_chip` / `frac_chip` sum over all launches of the timed rollouts: lane-operations of
+    every env-step stepped / the rollouts' wall time (a lower bound of the chip-wide issue rate while the substep
+    kernels run: the wall time also holds the policy forwards, the filter and the end-of-rollout work)."""
     p = _latest_profile("*_substep_sq_counters.json")
     if p is None or kernel_ms <= 0:
         return None
@@ -77,6 +80,8 @@ def valu_roofline(kernel_ms, envs_per_launch):
            "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)) if ("SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_INSTS_VALU")) else None}
     if out["active_lane_fraction"]:      # lanes that carried work: the issue slots above count idle lanes as used
         out["achieved_active"] = achieved * out["active_lane_fraction"]; out["frac_active"] = out["achieved_active"] / VALU_PEAK_LANE_OPS
+    if rollout_env_steps and rollout_s:
+        out["achieved_chip"] = lane_ops * rollout_env_steps / rollout_s; out["frac_chip"] = out["achieved_chip"] / VALU_PEAK_LANE_OPS
     if wc:
         out.update({"wave_quad_cycles_per_env_step": wc, "issuing_frac": c.get("SQ_ACTIVE_INST_ANY", 0) / wc, "waitcnt_frac": c.get("SQ_WAIT_ANY", 0) / wc,
                     "issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0) / wc})
@@ -208,6 +213,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=None, help="Newton iteration cap per substep (default: the model's <option iterations>, 20)")
     ap.add_argument("--groups", type=int, default=None, help="env ranges pipelined on separate streams during the rollout (default: 2 at >= 4096 envs)")
+    ap.add_argument("--sample-mode", default="fixed", choices=["fixed", "episodes"],
+                    help="fixed: fixed-horizon batches of every env (the GPU default, what `value` of the headline is quoted on); episodes: the "
+                         "reference's batch (agent_handmimic.py:430-535): every env is one sampler worker collecting WHOLE episodes until it holds "
+                         "floor(50000 / envs) steps -- use with --envs 32 for the reference's --num_threads 32 shape")
+    ap.add_argument("--min-iterations", type=int, default=10,
+                    help="the timed region holds at least this many PPO iterations whatever --steps asks for (a 2-iteration region is 0.14 s: not a "
+                         "measurement); steps_requested keeps the flag's value")
     args = ap.parse_args()
 
     # Exactly ONE line on stdout: libraries print banners to file descriptor 1 (RCCL's version block at communicator creation),
@@ -243,11 +255,14 @@ def main():
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
                            solver_iterations=args.solver_iterations, n_groups=args.groups, scaling=args.scaling,
                            start_min=100 if args.workload == "grasp" else 0, overlap_value_update=bool(args.overlap),
-                           rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams)
+                           rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams,
+                           sample_mode=args.sample_mode)
     share = world if args.scaling == "strong" else 1
     steps_per_iter = int(math.ceil(math.ceil(cfg.min_batch_size / share) / args.envs))
     n_warm_it = int(math.ceil(args.warmup / steps_per_iter)) if args.warmup > 0 else 0
-    n_it = max(1, int(math.ceil(args.steps / steps_per_iter)))
+    n_it = max(1, args.min_iterations, int(math.ceil(args.steps / steps_per_iter)))
+    if args.sample_mode == "episodes":      # an iteration is >= 50000 / envs steps of whole episodes per env: a few iterations are seconds already
+        n_it = max(1, min(n_it, 3)); n_warm_it = min(n_warm_it, 1)
     K = n_it * steps_per_iter
     W = n_warm_it * steps_per_iter
 
@@ -269,9 +284,12 @@ def main():
     t0 = time.time()
     t_sample = t_update = 0.0
     last_log = None
+    launches = 0
+    collected = 0          # samples that entered the batches (episodes mode: valid rows; fixed horizon: steps x envs)
     for _ in range(n_it):
         info = agent.optimize_policy(epoch, save_model=False); epoch += 1
         t_sample += info["T_sample"]; t_update += info["T_update"]; last_log = info["log"]
+        collected += int(info["log"].num_steps); launches += int(agent.last_rollout_steps)
         a, b = agent.env.sim.step_times()       # HIP events on the launch stream, read after the iteration's own sync
         kernel_ms += a; post_ms += b
     agent.learner.finish_update()            # an asynchronous value phase belongs to the timed region
@@ -281,7 +299,13 @@ def main():
     if distributed:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed, t_sample, t_update = [float(x) for x in tmax.cpu()]
-    total_env_steps = K * args.envs * world
+    if args.sample_mode == "episodes":
+        # whole-episode batches: the units are the env-steps that entered the batches (LoggerRL.num_steps, already summed over
+        # the ranks); launches made for envs that had their quota are work done but not output
+        total_env_steps = collected
+        K = launches                 # step launches actually made (every one steps all envs of the rank)
+    else:
+        total_env_steps = K * args.envs * world
     value = total_env_steps / elapsed
 
     if rank == 0:
@@ -307,10 +331,11 @@ def main():
             "dtype": dtype_txt, "data": "synthetic",
             "config": {"workload": f"{args.obj.capitalize()}, {args.envs} parallel envs per GPU, HIP batched sim "
                                    f"+ PyTorch-ROCm PPO (whole loop: rollout + GAE + {cfg.num_optim_epoch} full-batch epochs)"
+                                   + ("; whole-episode sampler (the reference's batch: every env one sampler worker)" if args.sample_mode == "episodes" else "")
                                    + ("; episodes start at frames >= 100 (grasp phase, contact-rich)" if args.workload == "grasp" else "")
                                    + (f"; policy after {args.pretrain} untimed PPO iterations (tracks the motions, holds the object)" if args.pretrain else ""),
-                       "envs_per_gpu": args.envs, "pretrain_iterations": args.pretrain, "steps_per_iteration": steps_per_iter, "timed_iterations": n_it,
-                       "samples_per_iteration": steps_per_iter * args.envs * world, "parallelism": f"env-dp{world}",
+                       "envs_per_gpu": args.envs, "pretrain_iterations": args.pretrain, "steps_per_iteration": K // n_it, "timed_iterations": n_it,
+                       "samples_per_iteration": total_env_steps // n_it, "parallelism": f"env-dp{world}", "sample_mode": args.sample_mode,
                        "rollout_env_ranges": n_groups, "update_gemms": args.update_dtype,
                        "value_update_overlaps_next_rollout": bool(agent.learner.overlap_value_update),
                        "rollout_policy_forward": "hoic_fwd_tiled_kernel (LDS-free f16x3)" if (args.rollout_forward == "tiled" and args.update_dtype == "f16x3") else "PyTorch float32",
@@ -329,7 +354,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * envs_per_launch, "envs_per_launch": envs_per_launch,
                          "note": "launch durations are HIP-event times on each range's own stream; with 2 ranges in flight a launch "
                                  "shares the GPU with the other range's kernels" if n_groups > 1 else None},
-            "roofline_valu": valu_roofline(k_ms, envs_per_launch),
+            "roofline_valu": valu_roofline(k_ms, envs_per_launch, K * args.envs, t_sample),
         }
         if args.update_dtype == "f16x3":
             out["roofline_update_gemm"] = update_gemm_roofline(steps_per_iter * args.envs, torch.device("cuda", local_rank))

@@ -234,6 +234,7 @@ class PPOLearner:
                 self._value_event = torch.cuda.Event(); self._value_event.record(self._value_stream)
             self._value_keep = (inp, actions, advantages, returns, v_first)       # alive until the side stream is done with them
             self._losses = (value_loss, surr)
+            peng.check_overflow()          # the policy chain ran on the current stream (the value chain's counter: finish_update)
             return
         if self.distributed:      # several ranks: interleave the chains so that each gradient all-reduce hides under the other network's pass
             fixed_log_probs = None
@@ -277,7 +278,9 @@ class PPOLearner:
         else:
             value_loss = value_phase()
             self._losses = (value_loss, policy_phase())
-        veng.check_overflow()
+        # BOTH engines: each SplitMLP owns its exponent table and its saturation counter (a policy hidden activation or
+        # gradient beyond the float16 range under its delayed exponent must be as loud as a value-network one)
+        veng.check_overflow(); peng.check_overflow()
 
     def wait_value_update(self):
         """Everything that reads the value network (or needs the update finished) calls this first: makes the current stream
@@ -296,7 +299,8 @@ class PPOLearner:
             torch.cuda.current_stream(self.device).synchronize()
             self._value_keep = None
             if self._engines is not None:
-                self._engines[0].check_overflow()
+                for eng in self._engines:
+                    eng.check_overflow()
 
     @property
     def last_losses(self):
@@ -580,6 +584,7 @@ class AgentHandMimic:
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
                                 exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values, valid=None)
         log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0)
+        self.last_rollout_steps = T
         return batch, log
 
     @torch.no_grad()
@@ -626,6 +631,7 @@ class AgentHandMimic:
                                 exps=torch.ones(T, N, device=dev, dtype=dt), next_values=None, valid=valid)
         steps = int(valid.sum().item())
         log = self._make_log(steps, rewards, flags[:, :, 1] != 0, done_all, rinfo, valid, t0)
+        self.last_rollout_steps = T          # step launches made (each one steps every env, idle workers included)
         return batch, log
 
     def update_params(self, batch):

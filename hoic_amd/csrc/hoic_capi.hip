@@ -898,25 +898,32 @@ extern "C" int32_t hoic_num_envs(const hoic_sim* s) { return s ? s->n_envs : 0; 
 extern "C" int32_t hoic_obs_dim(const hoic_sim* s) { (void)s; return HOIC_OBS_DIM; }
 extern "C" int32_t hoic_action_dim(const hoic_sim* s) { (void)s; return HOIC_ACT_DIM; }
 
+// The configuration block is rewritten with a synchronous copy while kernels of ANY stream of this handle may still read it
+// (the reward parts of the split post-step run on non-blocking side streams and read cfg.rp): every setter first waits for
+// the whole device, so a step launched before the call sees the old block and a step launched after it the new one.
+static int32_t write_config(hoic_sim* s) {
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (auto& r : s->ranges) r.pending[0] = r.pending[1] = false;      // every reward part has finished
+  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
+  return HOIC_OK;
+}
 extern "C" int32_t hoic_set_config(hoic_sim* s, const hoic_env_config* cfg) {
   if (!s || !cfg) { set_err("hoic_set_config: null"); return HOIC_ERR_ARG; }
   if (cfg->future_w_size != 5) { set_err("hoic_set_config: future_w_size must be 5 (obs layout)"); return HOIC_ERR_ARG; }
   if (cfg->sim_step <= 0 || cfg->solver_iterations <= 0) { set_err("hoic_set_config: sim_step/solver_iterations"); return HOIC_ERR_ARG; }
   s->hcfg.c = *cfg;
-  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
-  return HOIC_OK;
+  return write_config(s);
 }
 extern "C" int32_t hoic_set_reward_params(hoic_sim* s, const hoic_reward_params* rp) {
   if (!s || !rp) { set_err("hoic_set_reward_params: null"); return HOIC_ERR_ARG; }
   s->hcfg.rp = *rp;
-  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
-  return HOIC_OK;
+  return write_config(s);
 }
 extern "C" int32_t hoic_set_mode(hoic_sim* s, int32_t train) {
   if (!s) return HOIC_ERR_ARG;
   s->hcfg.mode_train = train ? 1 : 0;
-  HIPCHK(hipMemcpy(s->d_cfg, &s->hcfg, sizeof(DevConfig), hipMemcpyHostToDevice));
-  return HOIC_OK;
+  return write_config(s);
 }
 
 template <typename T> static T* upload(hoic_sim* s, const T* h, size_t n, size_t extra = 0) {

@@ -361,6 +361,7 @@ HD HullRef hull_ref(const DevModel& m, int mesh) {
 // max over the faces of n.x - d at the point (x, y, z) (hull frame); pl = that face (the first one in face order on ties)
 HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
   const int lane = threadIdx.x;
+  if (h.np <= 0) { pl[0] = pl[1] = pl[2] = pl[3] = 0.f; return -1e30f; }      // a mesh without face planes (wave-uniform): no face, nothing to index
   float bv = -1e30f; int bi = 0x00ffffff;
   for (int t = lane; t < h.np; t += NT) {          // ascending index per lane: '>' keeps the lane's first maximum
     const f4v p = h.pl[t];

@@ -768,7 +768,7 @@ __global__ void hoic_pack_rows_mul_kernel(const float* __restrict__ x, const flo
 }
 // max |x * y| (y optional) over a float32 array -> amax[slot] (atomicMax on the float bits; values are non-negative)
 __global__ void hoic_amax_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float* __restrict__ amax, int slot) {
-  float m = 0.f;
+  float m = 0.f, nf = 0.f;       // nf: 0 while every element is finite (v * 0 is NaN for Inf and NaN; fmaxf alone would drop NaN)
   const long long n4 = ((((size_t)x | (size_t)(y ? y : x)) & 15) == 0) ? (n >> 2) : 0;      // 16-byte aligned: four elements per load
   const long long stride = (long long)gridDim.x * blockDim.x;
 #pragma unroll 4
@@ -776,24 +776,26 @@ __global__ void hoic_amax_kernel(const float* __restrict__ x, const float* __res
     f32x4 v = ((const f32x4*)x)[i];
     if (y) v = v * ((const f32x4*)y)[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    nf = fmaf(v[0], 0.f, fmaf(v[1], 0.f, fmaf(v[2], 0.f, fmaf(v[3], 0.f, nf))));
   }
   for (long long i = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float v = x[i]; if (y) v *= y[i];
-    m = fmaxf(m, fabsf(v));
+    m = fmaxf(m, fabsf(v)); nf = fmaf(v, 0.f, nf);
   }
+  if (nf != 0.f) m = __builtin_inff();       // an Inf / NaN element: the slot's maximum becomes Inf and hoic_update_exps counts it
   m = wave_max_f(m);
   if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)(amax + slot), __float_as_uint(m));
 }
 // exponent of slot i from its running maximum: 2^e * amax lands in [2^(target-1), 2^target); amax == 0 keeps e; then the
 // maximum is cleared for the next pass.  One thread per slot.  mask bit i set = slot i is updated.
 __global__ void hoic_update_exps_kernel(int* __restrict__ exps, float* __restrict__ amax, int nslots, unsigned long long mask, int target,
-                                        int* __restrict__ overflow) {
+                                        int exact, int* __restrict__ overflow) {
   const int i = threadIdx.x;
   if (i >= nslots || !((mask >> i) & 1ull)) return;
   const float m = amax[i];
   if (m > 0.f && isfinite(m)) {
     int ex; frexpf(m, &ex);             // m = f * 2^ex, f in [0.5, 1)
-    if (ldexpf(m, exps[i]) > 60000.f && overflow) atomicAdd(overflow, 1);     // the pass just measured overflowed f16
+    if (!exact && ldexpf(m, exps[i]) > 60000.f && overflow) atomicAdd(overflow, 1);     // the pass just measured overflowed f16
     exps[i] = target - ex;
   } else if (!isfinite(m) && overflow) atomicAdd(overflow, 1);
   amax[i] = 0.f;
@@ -1071,6 +1073,7 @@ __global__ __launch_bounds__(256) void hoic_amax_colsum_kernel(const float* __re
       m = fmaxf(m, fabsf(v)); s += v;
     }
     part[(long long)blockIdx.y * Cc + c] = s;
+    if (!isfinite(s)) m = __builtin_inff();      // an Inf / NaN element survives in the sum: reported as an infinite maximum
   }
   m = wave_max_f(m);
   if ((threadIdx.x & 63) == 0 && amax) atomicMax((unsigned*)(amax + slot), __float_as_uint(m));
@@ -1147,9 +1150,11 @@ extern "C" int32_t hoic_mlp_amax(const float* d_x, const float* d_mul, int64_t n
   return HOIC_OK;
 }
 
-extern "C" int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream) {
+extern "C" int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t exact,
+                                        int32_t* d_overflow, void* stream) {
   if (!d_exps || !d_amax || nslots <= 0 || nslots > 64) { hoic_set_error("hoic_mlp_update_exps: bad arguments"); return HOIC_ERR_ARG; }
-  hipLaunchKernelGGL(hoic_update_exps_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_exps, d_amax, nslots, (unsigned long long)mask, target, d_overflow);
+  hipLaunchKernelGGL(hoic_update_exps_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_exps, d_amax, nslots, (unsigned long long)mask, target, exact,
+                     d_overflow);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

@@ -62,7 +62,7 @@ class _Kernels:
         L.hoic_mlp_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.hoic_mlp_pack.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, i32, vp, i32, vp]
         L.hoic_mlp_amax.argtypes = [vp, vp, i64, vp, i32, vp]
-        L.hoic_mlp_update_exps.argtypes = [vp, vp, i32, C.c_uint64, i32, vp, vp]
+        L.hoic_mlp_update_exps.argtypes = [vp, vp, i32, C.c_uint64, i32, i32, vp, vp]
         L.hoic_mlp_slab_reduce.argtypes = [vp, i32, i32, i32, vp, i32, i64, f32, vp]
         L.hoic_mlp_rowsum_packed.argtypes = [vp, i32, i32, vp, vp, i32, vp]
         L.hoic_mlp_set_pipeline.argtypes = [i32]
@@ -116,6 +116,22 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def _on_device(fn):
+    """The hoic_mlp_* entry points launch on the stream they are given and carry no device ordinal: run the method with
+    the object's device current, whatever the caller's current device is (an agent on cuda:1 in a process whose current
+    device is cuda:0 would otherwise launch into the wrong context)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        dev = getattr(self, "dev", None) or getattr(self, "device", None)
+        if dev is None or torch.device(dev).type != "cuda" or torch.cuda.current_device() == torch.device(dev).index:
+            return fn(self, *a, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class ScaleTable:
     """Per-tensor power-of-two scale exponents, their running |max| and the f16-overflow counter, all on the device."""
 
@@ -125,17 +141,20 @@ class ScaleTable:
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
         self.device = device
 
+    @_on_device
     def update(self, slots, target=TARGET_LOG2, exact=False):
         """exponents of `slots` from their measured maxima.  ``exact``: the maximum was measured on the very tensor that is
         packed next (inputs, weights, loss-side gradient), so nothing can have overflowed under the OLD exponent -- the
-        overflow check (measured maximum x 2^old exponent beyond the float16 range) applies to delayed slots only."""
+        range check (measured maximum x 2^old exponent beyond the float16 range) applies to delayed slots only; a
+        non-finite maximum (an Inf / NaN anywhere in the measured tensor) is counted for every slot."""
         mask = 0
         for s in slots:
             mask |= 1 << s
         K = kernels()
-        K.chk(K.L.hoic_mlp_update_exps(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target,
-                                       None if exact else _ptr(self.overflow), _stream(self.device)), "hoic_mlp_update_exps")
+        K.chk(K.L.hoic_mlp_update_exps(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target, int(bool(exact)),
+                                       _ptr(self.overflow), _stream(self.device)), "hoic_mlp_update_exps")
 
+    @_on_device
     def update_rel(self, slots, ref_slot, ref_prev, target=TARGET_LOG2):
         """delayed exponents of `slots` shifted by the change of the (exact) exponent of `ref_slot` since the last call;
         ``ref_prev``: device int32[1] holding that exponent as of the last call"""
@@ -146,6 +165,7 @@ class ScaleTable:
         K.chk(K.L.hoic_mlp_update_exps_rel(_ptr(self.exps), _ptr(self.amax), NSLOT, C.c_uint64(mask), target, ref_slot, _ptr(ref_prev),
                                            _ptr(self.overflow), _stream(self.device)), "hoic_mlp_update_exps_rel")
 
+    @_on_device
     def measure(self, slot, x, mul=None):
         K = kernels()
         K.chk(K.L.hoic_mlp_amax(_ptr(x), _ptr(mul), x.numel(), _ptr(self.amax), slot, _stream(self.device)), "hoic_mlp_amax")
@@ -225,7 +245,8 @@ class PackedInput:
         self.Mp, self.Kp = _rup(self.M, 256), _rup(self.K, 128)
         self.table = table if table is not None else ScaleTable(x.device)
         kernels()
-        self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=(GEMM_MODE != 3))
+        with torch.cuda.device(x.device):
+            self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=(GEMM_MODE != 3))
 
 
 def pick_splits(tiles, nkt, n_cu=256, max_splits=64):
@@ -316,6 +337,7 @@ class SplitMLP:
             self.Wp.append(P); self.WpT.append(PT)
 
     # ------------------------------------------------------------------ forward
+    @_on_device
     def forward(self, inp: PackedInput, need_grad=True):
         """-> float32 [M, out] last hidden activation (a leaf that requires grad when ``need_grad``)."""
         self._alloc(inp)
@@ -346,6 +368,7 @@ class SplitMLP:
         return out
 
     # ------------------------------------------------------------------ backward
+    @_on_device
     def backward(self, dH):
         """dH: float32 [M, out] gradient of the loss w.r.t. the last hidden activation.  Fills ``.grad`` of the layers."""
         t, inp, L, Mp = self.table, self.inp, len(self.layers), self.M
@@ -437,6 +460,7 @@ class TiledForward:
         return (isinstance(mlp, MLP) and isinstance(mlp.activation, torch.nn.GELU) and rows % 32 == 0
                 and all(l.out_features % 64 == 0 for l in mlp.affine_layers) and mlp.affine_layers[0].weight.is_cuda)
 
+    @_on_device
     def refresh(self):
         """pack the current weights (exact exponents) into format T"""
         K, t = kernels(), self.table
@@ -448,6 +472,7 @@ class TiledForward:
             K.chk(K.L.hoic_mlp_pack_tiled(_ptr(W), W.shape[0], W.shape[1], W.stride(0), _ptr(self.WT[i]), self.dims_out[i], self.Kp[i],
                                           _ptr(t.exps), self.SLOT_W0 + i, _stream(self.dev)), "hoic_mlp_pack_tiled")
 
+    @_on_device
     def forward(self, x):
         """x: float32 [M, in] (M % 32 == 0) -> float32 [M, out] last hidden activation"""
         assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] % 32 == 0

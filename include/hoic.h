@@ -189,8 +189,9 @@ int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64
  *   [Rp x 2 Cp] and / or the transpose d_PT [Cp x 2 Rp], zero padded, scaled by 2^d_exps[slot].
  * hoic_mlp_amax / hoic_mlp_update_exps: d_amax[slot] = max(d_amax[slot], max |x (* mul)|); then for the slots of `mask`
  *   e = target - ceil(log2 amax) (2^e amax in [2^(target-1), 2^target)), amax cleared; *d_overflow += 1 for a slot whose
- *   measured maximum exceeded the float16 range under its previous exponent (pass d_overflow = NULL for slots measured on
- *   the tensor that is packed NEXT: nothing was packed under the old exponent).
+ *   measured maximum exceeded the float16 range under its previous exponent (exact != 0 skips THAT test: the slot was
+ *   measured on the tensor that is packed NEXT, nothing was packed under the old exponent) and, always, for a slot whose
+ *   maximum is not finite (hoic_mlp_amax / hoic_mlp_amax_colsum report Inf for an array holding any Inf or NaN).
  * hoic_mlp_gemm: C[m][n] = extra_scale 2^-(e_a + e_b) sum_k A[m][k] B[n][k], A [M x 2K], B [N x 2K] packed (M % 256 ==
  *   N % 128 == K % 32 == 0), three f16 MFMAs (hi.hi + hi.lo + lo.hi) into one float32 accumulator.  epi 0: float32 d_C
  *   [splits][M x N] (split-K slabs over blockIdx.y);  epi 1 (forward layer): v = gelu(C + bias[n]) -> optional
@@ -203,8 +204,8 @@ int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64
 int32_t hoic_mlp_pack(const float* d_x, const float* d_mul, int32_t R, int32_t C, int64_t ld, void* d_P, void* d_PT, int32_t Rp,
                       int32_t Cp, const int32_t* d_exps, int32_t slot, void* stream);
 int32_t hoic_mlp_amax(const float* d_x, const float* d_mul, int64_t n, float* d_amax, int32_t slot, void* stream);
-int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow,
-                             void* stream);
+int32_t hoic_mlp_update_exps(int32_t* d_exps, float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t exact,
+                             int32_t* d_overflow, void* stream);
 /* the same relative to a reference slot whose exponent is exact (the loss-side gradient): e_i = target - ceil(log2 amax_i) +
  * (e_ref - *d_ref_prev), then *d_ref_prev = e_ref -- the hidden-layer gradients keep their head-room when the whole
  * gradient's scale jumps between passes. */

@@ -282,3 +282,41 @@ def test_ppo_update_f16x3_is_as_accurate_as_float32():
         assert ea ** 0.5 <= 4 * e32 ** 0.5 + 1e-7 * nrm ** 0.5
     for i in range(2):
         assert abs(ref64.last_losses[i] - a.last_losses[i]) < 1e-5 * abs(ref64.last_losses[i]) + 1e-7
+
+
+@gpu
+@pytest.mark.parametrize("which", ["policy", "value"])
+def test_f16x3_overflow_in_either_network_fails_the_update(which):
+    """Each SplitMLP owns its exponent table and saturation counter; PPOLearner reads BOTH after an update (round-2
+    finding: only the value engine's was read).  After one update with ordinary weights (delayed exponents in place) the
+    first layer of one network is scaled by 4096: its hidden activations leave the float16 range under the previous
+    pass's exponent (64x head-room), the policy step built on them is invalid, and update_params must raise HoicError --
+    for the policy network exactly as for the value network.  A NaN weight is caught the same way through the exact
+    (weight) slots."""
+    from types import SimpleNamespace
+    from hoic_amd import lib
+    from hoic_amd.agent import PPOLearner
+    from hoic_amd.config import Config, release_cfg_dict
+    d = release_cfg_dict("box"); d["policy_hsize"] = [512, 256, 256]; d["value_hsize"] = [512, 256, 256]
+    cfg = Config("box_future5_light_add_geom", cfg_dict=d)
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    T, N = 8, 256
+    mk = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    batch = SimpleNamespace(states=torch.clamp(mk(T, N, 617), -5, 5), actions=mk(T, N, 32) * 0.1, rewards=torch.rand(T, N, device=dev, generator=g),
+                            masks=(torch.rand(T, N, device=dev, generator=g) > 0.05).float(), next_values=torch.zeros(N, device=dev), valid=None)
+    for streams in (2, 1):
+        L = PPOLearner(cfg, 617, 32, dev, update_dtype="f16x3", update_streams=streams)
+        L.update_params(batch)                         # fine: exponents measured, nothing saturates
+        net = (L.policy_net if which == "policy" else L.value_net).net
+        with torch.no_grad():
+            net.affine_layers[0].weight.mul_(4096.0); net.affine_layers[0].bias.mul_(4096.0)
+        with pytest.raises(lib.HoicError, match="float16 range"):
+            L.update_params(batch)
+    L = PPOLearner(cfg, 617, 32, dev, update_dtype="f16x3")
+    net = (L.policy_net if which == "policy" else L.value_net).net
+    with torch.no_grad():
+        net.affine_layers[1].weight[3, 5] = float("nan")
+    with pytest.raises(lib.HoicError, match="float16 range"):
+        L.update_params(batch)
