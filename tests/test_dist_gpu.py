@@ -54,7 +54,9 @@ def _worker(rank, world, port, q):
     part = SimpleNamespace(**{k: (v if v is None else (v[:, sl].contiguous() if v.dim() >= 2 else v[sl].contiguous())) for k, v in vars(full).items()})
     L.update_params(part)
     torch.cuda.synchronize()
-    q.put((rank, {k: v.cpu() for k, v in L.policy_net.state_dict().items()}, {k: v.cpu() for k, v in L.value_net.state_dict().items()}, L.last_losses))
+    # NumPy arrays: pickled by value (torch tensors travel as shared-memory handles that die with this process)
+    q.put((rank, {k: v.cpu().numpy() for k, v in L.policy_net.state_dict().items()}, {k: v.cpu().numpy() for k, v in L.value_net.state_dict().items()},
+           L.last_losses))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,6 +73,7 @@ def test_two_rank_f16x3_update_equals_the_single_rank_update():
     for p in ps:
         p.join(60)
     (_, pa, va, la), (_, pb, vb, lb) = res
+    pa, va, pb, vb = [{k: torch.from_numpy(v) for k, v in d.items()} for d in (pa, va, pb, vb)]
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k            # both ranks end with identical parameters, bit for bit
     for k in va:

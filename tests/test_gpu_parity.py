@@ -289,7 +289,7 @@ def test_in_launch_reset_against_reset_kernel_and_oracle(obj, async_reward, orac
                 same = np.abs(obs_all[t, i] - ob).max() < tol
             if not same:
                 diverged += 1; alive[i] = False
-                print(f"  {obj} env {i} step {t} (age {age[i]}): dropped; |d reward| {abs(r - rew[t, i]):.3g} |d terms| "
+                print(f"  {obj} env {i} step {t} (age {age[i]}): dropped; |d obs| {np.abs(obs_all[t, i] - ob).max():.3g} |d reward| {abs(r - rew[t, i]):.3g} |d terms| "
                       f"{np.abs(ri - rinfo[t, i]).max():.3g} done gpu/oracle {done}/{info['done']} oracle ncon {int(envs[i].get('ncon')[0])}")
                 continue
             compared += 1
