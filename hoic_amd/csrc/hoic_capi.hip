@@ -817,6 +817,45 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     for (size_t i = 0; i < mva.size(); i++) { m.mesh_vertadr[i] = mva[i]; m.mesh_vertnum[i] = mvn[i]; m.mesh_planeadr[i] = mpa[i]; m.mesh_planenum[i] = mpn[i]; }
     for (size_t i = 0; i < mv.size(); i++) m.mesh_vert[i / 3][i % 3] = (float)mv[i];     // [.][3] stays 0
     for (size_t i = 0; i < mpl.size(); i++) m.mesh_plane[i / 4][i % 4] = (float)mpl[i];
+    // ---- run bounds (float32 table values, double arithmetic, rounded outward): see hoic_collide.h
+    int vr = 0, fr = 0;
+    for (size_t i = 0; i < mva.size(); i++) {
+      const int va = mva[i], vn = mvn[i], pa = mpa[i], pn = mpn[i];
+      m.mesh_vrunadr[i] = vr; m.mesh_vrunnum[i] = (vn + HOIC_HULL_RUN_VERTS - 1) / HOIC_HULL_RUN_VERTS;
+      m.mesh_frunadr[i] = fr; m.mesh_frunnum[i] = (pn + HOIC_HULL_RUN_FACES - 1) / HOIC_HULL_RUN_FACES;
+      if (m.mesh_vrunnum[i] > NT || m.mesh_frunnum[i] > 2 * NT) { set_err("model blob: a mesh has more runs than the narrow phase handles"); return false; }
+      for (int k = 0; k < 3; k++) { m.mesh_aabb[i][k] = 1e30f; m.mesh_aabb[i][4 + k] = -1e30f; }
+      for (int v = va; v < va + vn; v++)
+        for (int k = 0; k < 3; k++) { m.mesh_aabb[i][k] = std::min(m.mesh_aabb[i][k], m.mesh_vert[v][k]); m.mesh_aabb[i][4 + k] = std::max(m.mesh_aabb[i][4 + k], m.mesh_vert[v][k]); }
+      for (int r = 0; r < m.mesh_vrunnum[i]; r++, vr++) {
+        const int v0 = va + r * HOIC_HULL_RUN_VERTS, v1 = std::min(va + vn, v0 + HOIC_HULL_RUN_VERTS);
+        double c[3] = {0, 0, 0}, rad = 0;
+        for (int v = v0; v < v1; v++) for (int k = 0; k < 3; k++) c[k] += m.mesh_vert[v][k] / (v1 - v0);
+        float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+        for (int v = v0; v < v1; v++) { double d2 = 0; for (int k = 0; k < 3; k++) { const double d = (double)m.mesh_vert[v][k] - cf[k]; d2 += d * d; } rad = std::max(rad, std::sqrt(d2)); }
+        for (int k = 0; k < 3; k++) m.mesh_vrun[vr][k] = cf[k];
+        m.mesh_vrun[vr][3] = std::nextafterf((float)(rad * (1 + 1e-6) + 1e-9), 1e30f);
+      }
+      for (int r = 0; r < m.mesh_frunnum[i]; r++, fr++) {
+        const int f0 = pa + r * HOIC_HULL_RUN_FACES, f1 = std::min(pa + pn, f0 + HOIC_HULL_RUN_FACES);
+        // reference point of the run: the mean of the feet of the origin's perpendiculars onto the faces (near the patch,
+        // inside or on the hull), so that n.c - d is a small non-positive number for the run's own faces
+        double c[3] = {0, 0, 0};
+        float lo[3] = {2.f, 2.f, 2.f}, hi[3] = {-2.f, -2.f, -2.f};
+        for (int f = f0; f < f1; f++)
+          for (int k = 0; k < 3; k++) {
+            c[k] += (double)m.mesh_plane[f][k] * m.mesh_plane[f][3] / (f1 - f0);
+            lo[k] = std::min(lo[k], m.mesh_plane[f][k]); hi[k] = std::max(hi[k], m.mesh_plane[f][k]);
+          }
+        float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+        double emax = -1e300;
+        for (int f = f0; f < f1; f++) emax = std::max(emax, (double)m.mesh_plane[f][0] * cf[0] + (double)m.mesh_plane[f][1] * cf[1] + (double)m.mesh_plane[f][2] * cf[2] - m.mesh_plane[f][3]);
+        float* o = m.mesh_frun[fr];
+        for (int k = 0; k < 3; k++) { o[k] = cf[k]; o[4 + k] = lo[k]; o[8 + k] = hi[k]; }
+        o[3] = std::nextafterf((float)emax, 1e30f); o[7] = 0.f; o[11] = 0.f;
+      }
+    }
+    m.mesh_prune = getenv("HOIC_MESH_STREAM") == nullptr ? 1 : 0;
   } else { set_err("model blob: mesh tables missing"); return false; }
   return true;
 }

@@ -350,26 +350,84 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
 // is the sequential formulation of oracle/ho_collide.c, evaluated uniformly by all lanes; results that depend on an
 // order (first maximum, keep-the-deepest-four, three-lowest) are produced in that order.
 typedef float f4v __attribute__((ext_vector_type(4)));
-struct HullRef { GPTR(const f4v) pl; GPTR(const f4v) vv; int np, nv; };
+// Exact pruning.  The tables are ordered so that runs of HOIC_HULL_RUN_VERTS vertices are compact and runs of
+// HOIC_HULL_RUN_FACES faces have similar normals (hoic_amd/mjcf.py coherent_order); build_model bounds every run:
+//   vertex run: bounding sphere (centre, radius)  -> a run none of whose vertices can qualify is not loaded;
+//   face run:   n.x - d <= sum_i max(nlo_i w_i, nhi_i w_i) + emax with w = x - c   -> a run whose bound is below a value
+//               already found cannot hold the maximum (nor tie with it) and is not loaded.
+// What is loaded is evaluated with the same arithmetic and in the same table order as the streaming form (prune == 0,
+// HOIC_MESH_STREAM=1), so both forms produce bit-identical contacts (tests/test_gpu_parity.py
+// test_mesh_pruning_changes_no_contact); the win is memory traffic: a query on the banana's largest hull reads ~4 KB
+// instead of 29 KB of plane rows through the CU's vector L1, which is what bounded the mesh configurations.
+struct HullRef { GPTR(const f4v) pl; GPTR(const f4v) vv; GPTR(const f4v) vrun; GPTR(const f4v) frun; int np, nv, nvr, nfr, prune; float lo[3], hi[3]; };
 HD HullRef hull_ref(const DevModel& m, int mesh) {
   HullRef h;
-  h.np = m.mesh_planenum[mesh]; h.nv = m.mesh_vertnum[mesh];
+  h.np = m.mesh_planenum[mesh]; h.nv = m.mesh_vertnum[mesh]; h.nvr = m.mesh_vrunnum[mesh]; h.nfr = m.mesh_frunnum[mesh]; h.prune = m.mesh_prune;
   h.pl = (GPTR(const f4v))(GPTR(const void))&m.mesh_plane[m.mesh_planeadr[mesh]][0];
   h.vv = (GPTR(const f4v))(GPTR(const void))&m.mesh_vert[m.mesh_vertadr[mesh]][0];
+  h.vrun = (GPTR(const f4v))(GPTR(const void))&m.mesh_vrun[m.mesh_vrunadr[mesh]][0];
+  h.frun = (GPTR(const f4v))(GPTR(const void))&m.mesh_frun[m.mesh_frunadr[mesh]][0];
+  for (int i = 0; i < 3; i++) { h.lo[i] = m.mesh_aabb[mesh][i]; h.hi[i] = m.mesh_aabb[mesh][4 + i]; }
   return h;
+}
+HD float hull_plane_val(const f4v p, float x, float y, float z) { return fmaf(p.x, x, fmaf(p.y, y, fmaf(p.z, z, -p.w))); }
+// upper bound of n.x - d over face run r (lane-private r), with room for the rounding of this evaluation
+HD float hull_run_bound(const HullRef& h, int r, float x, float y, float z) {
+  const f4v c = h.frun[3 * r], lo = h.frun[3 * r + 1], hi = h.frun[3 * r + 2];
+  const float wx = x - c.x, wy = y - c.y, wz = z - c.z;
+  const float b = fmaxf(lo.x * wx, hi.x * wx) + fmaxf(lo.y * wy, hi.y * wy) + fmaxf(lo.z * wz, hi.z * wz) + c.w;
+  return b + (2e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + fabsf(c.w)) + 1e-8f);
 }
 // max over the faces of n.x - d at the point (x, y, z) (hull frame); pl = that face (the first one in face order on ties)
 HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
   const int lane = threadIdx.x;
   if (h.np <= 0) { pl[0] = pl[1] = pl[2] = pl[3] = 0.f; return -1e30f; }      // a mesh without face planes (wave-uniform): no face, nothing to index
   float bv = -1e30f; int bi = 0x00ffffff;
-  for (int t = lane; t < h.np; t += NT) {          // ascending index per lane: '>' keeps the lane's first maximum
-    const f4v p = h.pl[t];
-    const float v = fmaf(p.x, x, fmaf(p.y, y, fmaf(p.z, z, -p.w)));
-    if (v > bv) { bv = v; bi = t; }
+  if (!h.prune) {
+    for (int t = lane; t < h.np; t += NT) {          // ascending index per lane: '>' keeps the lane's first maximum
+      const float v = hull_plane_val(h.pl[t], x, y, z);
+      if (v > bv) { bv = v; bi = t; }
+    }
+  } else {
+    // pass 1, lane = run (a second sub-pass for hulls of more than 64 runs): the run's upper bound, and its first face as a
+    // value that is certainly attained
+    float ub0 = -1e30f, ub1 = -1e30f;
+    if (lane < h.nfr) { ub0 = hull_run_bound(h, lane, x, y, z); bv = hull_plane_val(h.pl[lane * HOIC_HULL_RUN_FACES], x, y, z); bi = lane * HOIC_HULL_RUN_FACES; }
+    if (h.nfr > NT && lane + NT < h.nfr) {
+      ub1 = hull_run_bound(h, lane + NT, x, y, z);
+      const float v = hull_plane_val(h.pl[(lane + NT) * HOIC_HULL_RUN_FACES], x, y, z);
+      if (v > bv) { bv = v; bi = (lane + NT) * HOIC_HULL_RUN_FACES; }
+    }
+    float best = wave_max(bv);
+    // pass 2: the runs that can still reach `best`, two per pass (one per half-wave), in ascending run order, so that a
+    // lane meets its faces in ascending table order and '>' keeps its first maximum
+    float fv = -1e30f; int fi = 0x00ffffff;
+    const int half = lane >> 5, sub = lane & 31;
+#pragma unroll 1
+    for (int part = 0; part < 2; part++) {
+      if (part == 1 && h.nfr <= NT) break;
+      unsigned long long mask = __ballot((part ? ub1 : ub0) >= best);
+      while (mask) {
+        const int ra = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        int rb = -1;
+        if (mask) { rb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        const int r = (half ? rb : ra) + part * NT;
+        const int t = r * HOIC_HULL_RUN_FACES + sub;
+        if ((half ? rb : ra) >= 0 && t < h.np) {
+          const float v = hull_plane_val(h.pl[t], x, y, z);
+          if (v > fv) { fv = v; fi = t; }
+        }
+        if (mask) {                                  // more candidates: raise the bar with what this pass found
+          best = fmaxf(best, wave_max(fv));
+          mask &= __ballot((part ? ub1 : ub0) >= best);
+        }
+      }
+    }
+    if (fv > bv || (fv == bv && fi < bi)) { bv = fv; bi = fi; }
   }
   const float mx = wave_max(bv);
-  const int idx = (int)wave_min(bv == mx ? (float)bi : 1e9f);     // indices < 2^24 are exact in float32
+  const int idx = min((int)wave_min(bv == mx ? (float)bi : 1e9f), h.np - 1);     // indices < 2^24 are exact in float32 (the clamp: non-finite query points)
   const f4v w = h.pl[idx];                                         // wave-uniform address
   pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
   return mx;
@@ -397,7 +455,22 @@ __device__ __forceinline__ int col_plane_mesh_wave(const HullRef& h, const float
   matcol(pR, 2, n);
   float best[3] = {0.f, 0.f, 0.f}, bpos[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   int nb = 0;
+  // runs of 64 vertices whose bounding sphere reaches below the plane (lane = run); the others hold no candidate
+  unsigned long long runs = ~0ull;
+  if (h.prune) {
+    bool reach = false;
+    if (lane < h.nvr) {
+      const f4v sp = h.vrun[lane];
+      const float lc[3] = {sp.x, sp.y, sp.z};
+      float wc[3];
+      matvec(mR, lc, wc);
+      const float dc = (wc[0] + mp[0] - pp[0]) * n[0] + (wc[1] + mp[1] - pp[1]) * n[1] + (wc[2] + mp[2] - pp[2]) * n[2];
+      reach = dc - sp.w < 1e-6f * (1.f + fabsf(dc));
+    }
+    runs = __ballot(reach);
+  }
   for (int base = 0; base < h.nv; base += NT) {       // 64 vertices per pass, the three lowest inserted in vertex order
+    if (!((runs >> (base / NT)) & 1ull)) continue;
     const int vi = base + lane;
     const f4v q = h.vv[vi < h.nv ? vi : 0];
     const float lv[3] = {q.x, q.y, q.z};
@@ -495,7 +568,24 @@ __device__ __forceinline__ int col_box_mesh_wave(const HullRef& h, const float* 
                                               const float* mp, const float* mR, float mesh_rbound, const LaneContacts& owner) {
   const int lane = threadIdx.x;
   Deep4 keep{0, 0.f, 0.f, 0.f, 0.f};
+  // runs of 64 vertices whose bounding sphere overlaps the box (lane = run)
+  unsigned long long runs = ~0ull;
+  if (h.prune) {
+    bool reach = false;
+    if (lane < h.nvr) {
+      const f4v sp = h.vrun[lane];
+      const float lc[3] = {sp.x, sp.y, sp.z};
+      float wc[3], rel[3], pc[3];
+      matvec(mR, lc, wc);
+      for (int i = 0; i < 3; i++) rel[i] = wc[i] + mp[i] - bp[i];
+      mattvec(bR, rel, pc);
+      reach = true;
+      for (int i = 0; i < 3; i++) if (fabsf(pc[i]) - sp.w > bh[i] + 1e-6f * (1.f + fabsf(pc[i]))) reach = false;
+    }
+    runs = __ballot(reach);
+  }
   for (int base = 0; base < h.nv; base += NT) {   // hull vertices inside the box: 64 per pass, one per lane, kept in vertex order
+    if (!((runs >> (base / NT)) & 1ull)) continue;
     const int vi = base + lane;
     const f4v q = h.vv[vi < h.nv ? vi : 0];
     const float lv[3] = {q.x, q.y, q.z};
@@ -525,6 +615,11 @@ __device__ __forceinline__ int col_box_mesh_wave(const HullRef& h, const float* 
     for (int i = 0; i < 3; i++) { wc[i] += bp[i]; rel[i] = wc[i] - mp[i]; }
     mattvec(mR, rel, p);
     if (dot3(p, p) > rb2) continue;        // outside the hull's bounding sphere: cannot be inside the hull
+    if (h.prune) {                         // outside the hull's bounding box (mesh frame = principal axes: tight for long shapes)
+      bool out = false;
+      for (int i = 0; i < 3; i++) { const float e = 1e-6f * (1.f + fabsf(p[i])); if (p[i] < h.lo[i] - e || p[i] > h.hi[i] + e) out = true; }
+      if (out) continue;
+    }
     float pf[4];
     const float s = hull_max_wave(h, p[0], p[1], p[2], pf);
     if (s >= 0.f) continue;
@@ -572,6 +667,33 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
       }
       isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
       ismesh = test && t2 == HOIC_GEOM_MESH;
+      if (ismesh && m.mesh_prune) {
+        // second reject for mesh pairs: geom1's bounding sphere (a plane: the plane itself) against the hull's bounding BOX
+        // in the mesh frame (the principal axes: a long object's box is far tighter than its bounding sphere).  A pair
+        // farther apart than the margin can only produce contacts that the margin filter below drops: same contact list.
+        const int me = m.pair_mesh[p];
+        const float mg = m.pair_margin[p];
+        float q[3], d1[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        mattvec(R2, d1, q);                              // geom1 centre (plane: a point of it) in the mesh frame
+        if (t1 != HOIC_GEOM_PLANE) {
+          const float r1 = bound - m.geom_rbound[g2];   // = rbound1 + margin
+          float d2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; i++) { const float e = fmaxf(fmaxf(m.mesh_aabb[me][i] - q[i], q[i] - m.mesh_aabb[me][4 + i]), 0.f); d2 += e * e; }
+          const float rr = r1 * (1.f + 1e-5f) + 1e-7f;
+          if (d2 > rr * rr) ismesh = false;
+        } else {
+          float nl[3], pn[3] = {R1[2], R1[5], R1[8]};
+          mattvec(R2, pn, nl);                           // plane normal in the mesh frame; q = a point of the plane
+          float cdist = 0.f, ext = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const float c = 0.5f * (m.mesh_aabb[me][i] + m.mesh_aabb[me][4 + i]), hh = 0.5f * (m.mesh_aabb[me][4 + i] - m.mesh_aabb[me][i]);
+            cdist += (c - q[i]) * nl[i]; ext += hh * fabsf(nl[i]);
+          }
+          if (cdist - ext > mg + 1e-6f * (1.f + fabsf(cdist))) ismesh = false;      // the whole box is farther than the margin above the plane
+        }
+      }
       if (isbb) {
         // per-lane pre-test on the six face axes: a pair separated by more than the margin along a face normal has no
         // contact and does not take a turn in the (sequential) wave-cooperative routine below

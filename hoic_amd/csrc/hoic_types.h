@@ -33,6 +33,8 @@
 #define MAXMESHV HOIC_MAX_MESHVERT
 #define MAXMESHP HOIC_MAX_MESHPLANE
 #define MAXROUND 3       // pointer-jumping rounds of the kinematics (tree depth <= 8)
+#define MAXVRUN (MAXMESHV / HOIC_HULL_RUN_VERTS + HOIC_MAX_MESH)
+#define MAXFRUN (MAXMESHP / HOIC_HULL_RUN_FACES + HOIC_MAX_MESH)
 
 struct DevModel {
   int nbody, njnt, nq, nv, nu, ngeom, npair, nlevel, nround;
@@ -75,6 +77,13 @@ struct DevModel {
   int mesh_vertadr[HOIC_MAX_MESH], mesh_vertnum[HOIC_MAX_MESH], mesh_planeadr[HOIC_MAX_MESH], mesh_planenum[HOIC_MAX_MESH];
   __attribute__((aligned(16))) float mesh_vert[MAXMESHV][4];    // hull vertices (x, y, z, 0), geom frame; float4 loads
   __attribute__((aligned(16))) float mesh_plane[MAXMESHP][4];   // hull faces n.x <= d in the geom frame
+  // ---- run bounds of the hull tables (build_model; exact pruning of the narrow phase's hull queries, hoic_collide.h)
+  int mesh_prune;                                  // 0: stream every table entry (HOIC_MESH_STREAM=1, A/B and the identity test)
+  int mesh_vrunadr[HOIC_MAX_MESH], mesh_vrunnum[HOIC_MAX_MESH], mesh_frunadr[HOIC_MAX_MESH], mesh_frunnum[HOIC_MAX_MESH];
+  __attribute__((aligned(16))) float mesh_aabb[HOIC_MAX_MESH][8];      // lo xyz _, hi xyz _ of the hull vertices (mesh frame)
+  __attribute__((aligned(16))) float mesh_vrun[MAXVRUN][4];            // bounding sphere of a run of HOIC_HULL_RUN_VERTS vertices: centre, radius
+  __attribute__((aligned(16))) float mesh_frun[MAXFRUN][12];           // run of HOIC_HULL_RUN_FACES faces: (c, emax) (nlo, 0) (nhi, 0):
+                                                                       //   n.x - d <= sum_i max(nlo_i w_i, nhi_i w_i) + emax, w = x - c
 };
 
 struct DevConfig {

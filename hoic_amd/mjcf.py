@@ -439,8 +439,15 @@ def compile_model(hand_xml: str, obj_xml: str | None, max_mesh_verts: int | None
             for i in range(1, pl.shape[0]):
                 if np.abs(pl[i] - pl[keep[-1]]).max() > 1e-9:
                     keep.append(i)
+            pl = pl[keep]
+            # Table order = run order of the simulator's narrow phase: consecutive runs of HULL_RUN_VERTS vertices are
+            # spatially compact and consecutive runs of HULL_RUN_FACES faces have similar normals, so that a run's bounding
+            # sphere / normal box (built at load time, hoic_capi.hip build_model) lets the kernels skip most runs of a
+            # query.  The order is part of the model: "first vertex / first face in table order" tie-breaks of the oracle
+            # and of the kernels refer to it.
+            hv = hv[coherent_order(hv, HULL_RUN_VERTS)]
             entry["hull"] = hv
-            entry["planes"] = pl[keep]
+            entry["planes"] = pl[coherent_order(pl[:, :3], HULL_RUN_FACES)]
         mesh_index[key] = len(meshes)
         meshes.append(entry)
         return mesh_index[key]
@@ -710,6 +717,29 @@ def hull_inner_distance(full_pts, sub_pts):
     from scipy.spatial import ConvexHull
     eq = ConvexHull(sub_pts).equations
     return float(np.maximum((np.asarray(full_pts) @ eq[:, :3].T + eq[:, 3]).max(axis=1), 0.0).max())
+
+
+HULL_RUN_VERTS, HULL_RUN_FACES = 64, 32      # = HOIC_HULL_RUN_VERTS / HOIC_HULL_RUN_FACES of include/hoic_model.h
+
+
+def coherent_order(P, leaf):
+    """Permutation of the rows of P (n, d) such that consecutive runs of `leaf` rows are compact: recursive bisection along
+    the axis of largest extent, the cut placed at a multiple of `leaf` nearest the middle (so every run but the last
+    holds rows of one leaf); stable sorts: deterministic."""
+    P = np.asarray(P, dtype=np.float64)
+    out = []
+
+    def rec(ids):
+        if len(ids) <= leaf:
+            out.extend(ids.tolist())
+            return
+        sub = P[ids]
+        ax = int(np.argmax(sub.max(0) - sub.min(0)))
+        order = ids[np.argsort(sub[:, ax], kind="stable")]
+        k = leaf * max(1, int(round(len(ids) / (2.0 * leaf))))
+        rec(order[:k]); rec(order[k:])
+    rec(np.arange(P.shape[0]))
+    return np.array(out, dtype=np.int64)
 
 
 def _decimate_hull(hv, k):

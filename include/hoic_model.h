@@ -54,6 +54,11 @@ enum {
   HOIC_MAX_MESH = 4,
   HOIC_MAX_MESHVERT = 2048,  /* all hull vertices of a model's meshes (banana: 231 + 707 + 939) */
   HOIC_MAX_MESHPLANE = 4096, /* hull face planes n.x <= d, mesh frame */
+  /* The hull tables are ordered (hoic_amd/mjcf.py coherent_order) so that consecutive runs of this many vertices are
+     spatially compact and consecutive runs of this many faces have similar normals: the simulator bounds each run at load
+     time and skips the runs a query cannot touch.  Results never depend on the skipping (exact bounds). */
+  HOIC_HULL_RUN_VERTS = 64,
+  HOIC_HULL_RUN_FACES = 32,
   HOIC_OBS_DIM = 617,  /* get_full_obs_v5(w=5), uhc/envs/ho_im4.py:280-356 */
   HOIC_ACT_DIM = 32,   /* 26 PD targets + 3 residual force + 3 residual torque, ho_im4.py:145-156 */
   HOIC_NHANDBODY = 21, /* bodies named link*, ho_im4.py:77-78 */

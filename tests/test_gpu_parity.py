@@ -785,6 +785,52 @@ def test_async_reward_matches_the_default_step(box_blob, setup):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("obj", ["bottle", "banana"])
+def test_mesh_pruning_changes_no_contact(obj, monkeypatch):
+    """The convex-mesh narrow phase skips the runs of hull vertices / faces that a query cannot touch (bounding spheres,
+    normal boxes, the hull's bounding box in the mesh frame; hoic_collide.h) -- exact bounds, same arithmetic and order
+    on what is loaded: contacts, states and outputs are BIT-identical to the streaming form (HOIC_MESH_STREAM=1: every
+    table entry read by every query), on single forward passes over rest / approach / grasp states with perturbed
+    poses and over whole env steps with in-launch resets."""
+    blob, cfg, ex, thresh = _obj_setup(obj)
+    N = 384
+    a_sim = _sim(blob, N, cfg, ex, thresh)
+    monkeypatch.setenv("HOIC_MESH_STREAM", "1")
+    b_sim = _sim(blob, N, cfg, ex, thresh)
+    monkeypatch.delenv("HOIC_MESH_STREAM")
+    rng = np.random.default_rng(9)
+    qs, vs = [], []
+    for i in range(N):
+        e = ex[i % 4]; f = int(rng.integers(0, 400))
+        q = np.concatenate([e["hand_dof_seq"][f], e["obj_pose_seq"][f]]); q[:26] += rng.normal(size=26) * (0.02 if i % 3 else 0.08)
+        q[26:29] += rng.normal(size=3) * (0.002 if i % 2 else 0.01)
+        if i % 5 == 0:                      # arbitrary object orientation next to the palm
+            qq = rng.normal(size=4); q[29:33] = qq / np.linalg.norm(qq); q[26:29] = q[:3] + rng.normal(size=3) * 0.03 + [0, 0.04, -0.05]
+        qs.append(q); vs.append(np.concatenate([e["hand_dof_vel_seq"][f], e["obj_vel_seq"][f], e["obj_angle_vel_seq"][f]]))
+    qs, vs = np.array(qs), np.array(vs)
+    oa = a_sim.probe_forward(qs, vs, do_step=True); ob = b_sim.probe_forward(qs, vs, do_step=True)
+    assert np.array_equal(oa["ncon"], ob["ncon"]) and np.array_equal(oa["contacts"], ob["contacts"])
+    assert np.array_equal(oa["qacc"], ob["qacc"]) and np.array_equal(oa["qpos_out"], ob["qpos_out"]) and np.array_equal(oa["qvel_out"], ob["qvel_out"])
+    og0, og1 = a_sim.model.scalar("obj_geom0"), a_sim.model.scalar("obj_geom1")
+    cc = oa["contacts"]
+    mesh_c = (cc[:, :, 14] >= og0) & (cc[:, :, 14] <= og1) & (cc[:, :, 15] > 0)
+    hand_mesh = mesh_c & (cc[:, :, 13] >= a_sim.model.scalar("hand_geom0"))
+    print(f"{obj}: {int(mesh_c.sum())} mesh contacts in {int(mesh_c.any(1).sum())} of {N} states, {int(hand_mesh.sum())} of them hand-mesh")
+    assert mesh_c.any(1).sum() > N // 3 and hand_mesh.sum() > 20
+    g = torch.Generator().manual_seed(4)
+    seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(0, 300, (N,), generator=g, dtype=torch.int32)
+    a_sim.reset(seq, start); b_sim.reset(seq, start)
+    for t in range(4):
+        act = (torch.randn(N, 32, generator=g) * 0.2).cuda()
+        ns = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32).cuda(); nst = torch.randint(0, 300, (N,), generator=g, dtype=torch.int32).cuda()
+        ra = [x.clone() for x in a_sim.step(act, ns, nst)]; rb = [x.clone() for x in b_sim.step(act, ns, nst)]
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+    qa, va, _ = a_sim.get_state(); qb, vb, _ = b_sim.get_state()
+    assert torch.equal(qa, qb) and torch.equal(va, vb)
+    a_sim.close(); b_sim.close()
+
+
 def test_longest_first_launch_order_changes_no_result(box_blob, setup, monkeypatch):
     """HOIC_REORDER=1 (workgroups dispatched by the measured duration of each env's previous pass) only changes which
     CU runs an env: states and outputs stay bit-identical; hoic_env_durations reports the sort keys."""
