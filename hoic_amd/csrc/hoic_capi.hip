@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       dev_pd_torque(ml, cl, w, M, ev); PT(1);     // :518-523
       dev_applied(ml, cl, w, vf, vt);             // :526-540
     }
-    dev_forward_kin(ml, w, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
+    dev_forward_kin(ml, cl, w, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
     if (mode == 0) {
       for (int g = tid; g < ml.ngeom; g += NT) {
         for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   wsync();
   dev_load_constants(m, w);
   MReg M;
-  dev_forward_kin(m, w, M, w.qpos, w.qvel, nullptr);
+  dev_forward_kin(m, cfg, w, M, w.qpos, w.qvel, nullptr);
   const bool ok = dev_forward_dyn(m, cfg, w, M);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];

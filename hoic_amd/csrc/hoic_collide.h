@@ -643,7 +643,7 @@ HD void make_frame(float* f) {
 }
 
 // ---- collision driver: lane = pair (two passes when npair > 64); contacts compacted into the workspace
-__device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* overflow) {
+__device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* overflow, int mesh_single) {
   const int tid = opaque(threadIdx.x);
   if (tid == 0) w.ncon = 0;
   wsync();
@@ -754,6 +754,14 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         if (ta == HOIC_GEOM_CAPSULE) nn = col_capsule_mesh_wave(hull, Pa, RA, Sa, Pb, RB, owner);
         else if (ta == HOIC_GEOM_BOX) nn = col_box_mesh_wave(hull, Pa, RA, Sa, Pb, RB, m.geom_rbound[gb], owner);
         else nn = col_plane_mesh_wave(hull, Pa, RA, Pb, RB, owner);
+        if (mesh_single && nn > 1) {     // hoic_env_config::mesh_single_contact: the deepest point only (the first one on ties)
+          wsync();
+          int bq = 0; float bd = lc_at(owner, 0, 0);
+          for (int q = 1; q < nn; q++) { const float dq = lc_at(owner, q, 0); if (dq < bd) { bd = dq; bq = q; } }
+          if (bq != 0 && tid < 7) { const float v = lc_at(owner, bq, tid); lc_at(owner, 0, tid) = v; }
+          wsync();
+          nn = 1;
+        }
         if (tid == L) lc.n = nn;
       }
       wsync();

@@ -24,11 +24,11 @@ struct ExpertView {
 };
 
 // ---- position + velocity stages of the forward pass on state (q, v); leaves M (registers), bias, contacts, S
-__device__ __forceinline__ void dev_forward_kin(const DevModel& m, Work& w, MReg& M, const float* q, const float* v, int* overflow) {
+__device__ __forceinline__ void dev_forward_kin(const DevModel& m, const DevConfig& cfg, Work& w, MReg& M, const float* q, const float* v, int* overflow) {
   dev_kinematics(m, w, q); PT(3);
   dev_mass_matrix(m, w, M); PT(4);
   dev_bias(m, w, v); PT(5);
-  dev_collision(m, w, overflow); PT(6);
+  dev_collision(m, w, overflow, cfg.c.mesh_single_contact); PT(6);
 }
 
 // ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass

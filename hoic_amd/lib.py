@@ -31,7 +31,7 @@ class EnvConfig(C.Structure):
                 ("residual_force_scale", C.c_float), ("residual_torque_scale", C.c_float),
                 ("sim_step", C.c_int32), ("future_w_size", C.c_int32), ("residual_force", C.c_int32),
                 ("explain_force", C.c_int32), ("surface_contact", C.c_int32), ("pd_rel", C.c_int32),
-                ("solver_iterations", C.c_int32), ("pd_ref_offset", C.c_int32)]
+                ("solver_iterations", C.c_int32), ("pd_ref_offset", C.c_int32), ("mesh_single_contact", C.c_int32)]
 
 
 class RewardParams(C.Structure):
@@ -165,7 +165,7 @@ class BatchedSim:
     # ---- configuration
     def set_config(self, jkp, jkd, torque_lim, thresh=(0.1, 1.0, 0.1, 0.1, 1.0), rf_scale=2.5, rt_scale=0.125,
                    sim_step=15, residual_force=True, explain_force=True, surface_contact=True, pd_rel=True,
-                   solver_iterations=20, pd_ref_offset=0):
+                   solver_iterations=20, pd_ref_offset=0, mesh_contacts="multi"):
         c = EnvConfig()
         for i in range(26):
             c.jkp[i], c.jkd[i], c.torque_lim[i] = float(jkp[i]), float(jkd[i]), float(torque_lim[i])
@@ -176,6 +176,8 @@ class BatchedSim:
         c.residual_force, c.explain_force, c.surface_contact = int(residual_force), int(explain_force), int(surface_contact)
         c.pd_rel, c.solver_iterations = int(pd_rel), int(solver_iterations)
         c.pd_ref_offset = int(pd_ref_offset)
+        assert mesh_contacts in ("multi", "single")      # "single": the deepest point of a mesh pair only (MuJoCo's contact count)
+        c.mesh_single_contact = int(mesh_contacts == "single")
         self.torch.cuda.synchronize(self.device)
         _chk(self.L.hoic_set_config(self.h, C.byref(c)), "hoic_set_config")
 

@@ -41,6 +41,10 @@ typedef struct hoic_env_config {
   int32_t solver_iterations; /* Newton iteration cap per substep (fp32) */
   int32_t pd_ref_offset;     /* 0: training env; 1: streaming env (uhc/envs/ho_im_test.py: the new frame is inserted before
                               * env.step, InferenceServer/RLTest.py:298-299, so the PD target is expert frame t+1) */
+  int32_t mesh_single_contact; /* 0 (default): a convex-mesh pair yields every contact point this narrow phase finds (up to 3 plane-mesh,
+                              * 2 capsule-mesh, 4 box-mesh); 1: only the deepest one, the contact COUNT of MuJoCo 2.1's convex
+                              * collider (libccd/MPR: one contact per mesh pair; assets/SingleDepth/bottle_light.xml:12-19,
+                              * banana_light.xml:13-22) -- the switch a MuJoCo capture will be compared under */
 } hoic_env_config;
 
 /* Reward parameters of ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-967); refreshed every epoch by

@@ -387,6 +387,11 @@ void ho_collision(const ho_model* m, ho_data* d) {
     }
     ho_contact tmp[8];
     int n = ho_collide_pair(m, d, p, tmp, 8);
+    if (m->mesh_single_contact && n > 1 && m->geom_type[g2] == HOIC_GEOM_MESH) {   /* the deepest point only (first on ties) */
+      int b = 0;
+      for (int k = 1; k < n; k++) if (tmp[k].dist < tmp[b].dist) b = k;
+      tmp[0] = tmp[b]; n = 1;
+    }
     for (int k = 0; k < n && d->ncon < HO_MAXCON; k++) {
       ho_contact* c = &d->contact[d->ncon];
       *c = tmp[k];

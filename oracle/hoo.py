@@ -45,6 +45,7 @@ def lib():
         L.hoo_env_set_cfg.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p]
         L.hoo_env_set_expert.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
         L.hoo_env_set_pd_ref_offset.argtypes = [C.c_void_p, C.c_int]
+        L.hoo_env_set_mesh_single_contact.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hoo_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hoo_env_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -125,6 +126,10 @@ class OracleEnv:
     def set_pd_ref_offset(self, off: int):
         """1 = streaming env semantics (uhc/envs/ho_im_test.py + InferenceServer/RLTest.py:289-300)"""
         self.L.hoo_env_set_pd_ref_offset(self.h, int(off))
+
+    def set_mesh_single_contact(self, on: bool):
+        """keep only the deepest contact of a convex-mesh pair (MuJoCo's contact count for mesh pairs)"""
+        self.L.hoo_env_set_mesh_single_contact(self.h, int(bool(on)))
 
     def set_expert(self, ex: dict):
         T = ex["hand_dof_seq"].shape[0]

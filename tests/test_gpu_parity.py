@@ -831,6 +831,48 @@ def test_mesh_pruning_changes_no_contact(obj, monkeypatch):
     a_sim.close(); b_sim.close()
 
 
+@pytest.mark.parametrize("obj", ["bottle", "banana"])
+def test_single_contact_mesh_mode(obj, oracle_lib):
+    """mesh_contacts='single' (hoic_env_config::mesh_single_contact; oracle: set_mesh_single_contact): every convex-mesh
+    pair keeps only its deepest contact point -- MuJoCo 2.1's contact COUNT for mesh pairs (libccd/MPR),
+    the mode a MuJoCo capture will be compared under.  Same switch in the oracle and in the kernel: contact lists agree,
+    no mesh pair appears twice, and the constrained accelerations agree as in the default mode."""
+    blob, cfg, ex, thresh = _obj_setup(obj)
+    N = 96
+    sim = _sim(blob, N, cfg, ex, thresh, mesh_contacts="single")
+    multi = _sim(blob, N, cfg, ex, thresh)
+    rng = np.random.default_rng(3)
+    qs, vs = [], []
+    for i in range(N):
+        e = ex[i % 4]; f = int(rng.integers(0, 400))
+        q = np.concatenate([e["hand_dof_seq"][f], e["obj_pose_seq"][f]]); q[:26] += rng.normal(size=26) * 0.03
+        qs.append(q); vs.append(np.concatenate([e["hand_dof_vel_seq"][f], e["obj_vel_seq"][f], e["obj_angle_vel_seq"][f]]))
+    qs, vs = np.array(qs), np.array(vs)
+    out = sim.probe_forward(qs, vs); ref = multi.probe_forward(qs, vs)
+    o = oracle_lib.OracleEnv(blob); o.set_mesh_single_contact(True)
+    og0 = sim.model.scalar("obj_geom0")
+    fewer = mism = ties = 0
+    worst = 0.0
+    for i in range(N):
+        o.set("qpos", qs[i]); o.set("qvel", vs[i]); o.set("qacc_warmstart", np.zeros(32)); o.forward()
+        c = o.contacts(); nc = len(c)
+        if nc != out["ncon"][i]:
+            mism += 1
+            continue
+        fewer += out["ncon"][i] < ref["ncon"][i]
+        g = out["contacts"][i, :nc]
+        assert np.array_equal(g[:, 13:16], c[:, 13:16])
+        pairs = [(int(a), int(b)) for a, b in g[g[:, 14] >= og0][:, 13:15]]
+        assert len(pairs) == len(set(pairs)), pairs                      # one contact per mesh pair
+        if nc and not (np.abs(g[:, 0] - c[:, 0]).max() < 2e-6 and np.abs(g[:, 1:13] - c[:, 1:13]).max() < 2e-5):
+            ties += 1                                                     # two points of a pair equally deep to float32 rounding
+            continue
+        worst = max(worst, _rel(out["qacc"][i], o.get("qacc")))
+    print(f"{obj}: {fewer} of {N} states lose contacts in single mode; ncon mismatches {mism}, depth ties {ties}, worst qacc {worst:.2e}")
+    assert fewer > N // 8 and mism <= 2 and ties <= N // 12 and worst < 2e-3
+    sim.close(); multi.close()
+
+
 def test_longest_first_launch_order_changes_no_result(box_blob, setup, monkeypatch):
     """HOIC_REORDER=1 (workgroups dispatched by the measured duration of each env's previous pass) only changes which
     CU runs an env: states and outputs stay bit-identical; hoic_env_durations reports the sort keys."""
