@@ -26,7 +26,7 @@ extern "C" const char* hoic_last_error(void) { return g_err.c_str(); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return HOIC_ERR_DEVICE; } } while (0)
 
 // ------------------------------------------------------------------------------------------------ kernels
-__device__ void load_state(const DevModel& m, const DevState& st, Work& w, int env) {
+__device__ __forceinline__ void load_state(const DevModel& m, const DevState& st, Work& w, int env) {
   const int tid = threadIdx.x;
   if (tid < NQP) { w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid]; w.qlag[tid] = as_global(st.qlag)[(size_t)env * NQP + tid]; }
   if (tid < NV) {
@@ -38,7 +38,7 @@ __device__ void load_state(const DevModel& m, const DevState& st, Work& w, int e
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; w.capped = 0; }
   wsync();
 }
-__device__ void store_state(const DevState& st, const Work& w, int env) {
+__device__ __forceinline__ void store_state(const DevState& st, const Work& w, int env) {
   const int tid = threadIdx.x;
   if (tid < NQP) { as_global(st.qpos)[(size_t)env * NQP + tid] = w.qpos[tid]; as_global(st.qlag)[(size_t)env * NQP + tid] = w.qlag[tid]; }
   if (tid < NV) {
@@ -71,7 +71,7 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
 }
 
 // semi-implicit Euler with implicit joint damping; also records the pre-integration state (lag) and warm start
-__device__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
+__device__ __forceinline__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const float h = m.timestep;
   const float rhs = (d < m.nv) ? (w.fsmooth[d] + w.fcon[d]) : 0.f;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
     if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
     if (!isfinite(rfc_score)) { if (PART == POST_ALL) ok = false; rfc_score = 0.f; }
   }
-  asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
+  if (PART != POST_A) asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
   if (PART != POST_B) ev.cur_t += 1;                                                            // :641 (POST_B: the record's view is advanced already)
   const int expert_len = ev.len - ev.start;
   const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
@@ -716,6 +716,32 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     int e = i + 1;
     while (e < m.nbody && m.body_depth[e] > m.body_depth[i]) e++;
     m.body_subtree[i] = e - i;
+  }
+  {   // plan of the composite sums (DevModel::body_sum)
+    auto plan = [&](bool two_round) {
+      bool ok = true;
+      for (int i = 0; i < m.nbody; i++) {
+        m.body_kids[i][0] = m.body_kids[i][1] = 0xFFFFFFFFu;
+        bool needed = false;            // some dof reads this body's composite: the body carries dofs itself
+        needed = m.body_dofnum[i] > 0;
+        m.body_sum[i] = needed ? 1 : 0;
+        if (two_round && needed && m.body_subtree[i] > SUM_DIRECT) {
+          int nk = 0;
+          for (int c = i + 1; c < i + m.body_subtree[i]; c += m.body_subtree[c]) {
+            if (nk >= 8 || m.body_subtree[c] > SUM_DIRECT) { ok = false; break; }
+            m.body_kids[i][nk >> 2] = (m.body_kids[i][nk >> 2] & ~(0xFFu << (8 * (nk & 3)))) | ((unsigned)c << (8 * (nk & 3)));
+            nk++;
+          }
+          m.body_sum[i] = 2;
+        }
+      }
+      if (ok)      // children of a mode-2 body are summed in the first round whether or not they carry dofs
+        for (int i = 0; i < m.nbody; i++)
+          if (m.body_sum[i] == 2)
+            for (int k = 0; k < 8; k++) { const unsigned c = (m.body_kids[i][k >> 2] >> (8 * (k & 3))) & 0xFFu; if (c != 0xFFu) m.body_sum[c] = 1; }
+      return ok;
+    };
+    if (!plan(true)) plan(false);       // a tree this plan does not fit (a big subtree below a big subtree): plain range sums
   }
   std::vector<int> lastdof;
   if (!b.i32("body_lastdof", lastdof)) return false;

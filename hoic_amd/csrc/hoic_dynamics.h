@@ -217,12 +217,27 @@ HD void inert_mul(const float* I, const float* v, float* f) {
 // M[i][j] = S_j . (Ic_body(i) S_i) for j an ancestor-or-self dof of i, mirrored for descendants, 0 elsewhere
 __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg& M) {
   const int tid = opaque(threadIdx.x);
-  if (tid < m.nbody) {
+  // composite inertias in two rounds (DevModel::body_sum): small subtrees directly, then the bodies above them from their
+  // children's composites -- the longest loop is SUM_DIRECT / the largest child count instead of the whole hand
+  const int smode = tid < m.nbody ? m.body_sum[tid] : 0;
+  if (smode == 1) {
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
     const int e = tid + m.body_subtree[tid];
     for (int b = tid; b < e; b++)
       for (int i = 0; i < 10; i++) acc[i] += w.sc.dyn.I10[b][i];
+    for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
+  }
+  wsync();
+  if (smode == 2) {
+    float acc[10];
+    for (int i = 0; i < 10; i++) acc[i] = w.sc.dyn.I10[tid][i];
+    const unsigned k0 = m.body_kids[tid][0], k1 = m.body_kids[tid][1];
+    for (int k = 0; k < 8; k++) {
+      const unsigned c = ((k < 4 ? k0 : k1) >> (8 * (k & 3))) & 0xFFu;
+      if (c == 0xFFu) break;
+      for (int i = 0; i < 10; i++) acc[i] += w.sc.dyn.Ic[c][i];
+    }
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
   wsync();   // (also: the joint frames in sc.dyn.u.j are dead from here on, u.f takes their place)
@@ -301,14 +316,27 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     for (int i = 0; i < 6; i++) w.sc.dyn.u.f.cfrc[tid][i] = f[i];
   }
   wsync();
-  if (tid < m.nbody) {   // subtree force sums (range sums again), kept in the Ic slots
-    float sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (m.body_dofnum[tid] > 0) {
+  {   // subtree force sums, kept in the Ic slots: the two rounds of the composite inertias
+    const int smode = tid < m.nbody ? m.body_sum[tid] : 0;
+    if (smode == 1) {
+      float sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const int e = tid + m.body_subtree[tid];
       for (int b = tid; b < e; b++)
         for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.u.f.cfrc[b][i];
+      for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
     }
-    for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
+    wsync();
+    if (smode == 2) {
+      float sub[6];
+      for (int i = 0; i < 6; i++) sub[i] = w.sc.dyn.u.f.cfrc[tid][i];
+      const unsigned k0 = m.body_kids[tid][0], k1 = m.body_kids[tid][1];
+      for (int k = 0; k < 8; k++) {
+        const unsigned c = ((k < 4 ? k0 : k1) >> (8 * (k & 3))) & 0xFFu;
+        if (c == 0xFFu) break;
+        for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.Ic[c][i];
+      }
+      for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
+    }
   }
   wsync();
   if (tid < NV) w.bias[tid] = (tid < m.nv) ? dot6(w.S[tid], w.sc.dyn.Ic[m.dof_bodyid[tid]]) : 0.f;

@@ -32,7 +32,7 @@ __device__ __forceinline__ void dev_forward_kin(const DevModel& m, const DevConf
 }
 
 // ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass
-__device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev) {
+__device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev) {
   const int tid = opaque(threadIdx.x), d = tid & 31, n = m.hand_nv;
   const float dt = m.timestep;
   float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
@@ -67,7 +67,7 @@ __device__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, 
 }
 
 // ---- generalized applied forces: gravity compensation + residual object wrench, lagged Jacobians
-__device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
+__device__ __forceinline__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
   const int tid = opaque(threadIdx.x);
   if (tid < NV) {
     float s = 0.f;
@@ -82,7 +82,7 @@ __device__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, co
 }
 
 // ---- record_contact (ho_im4.py:883-889): lane = hand geom, deterministic accumulation order
-__device__ void dev_record_contact(const DevModel& m, Work& w) {
+__device__ __forceinline__ void dev_record_contact(const DevModel& m, Work& w) {
   const int tid = opaque(threadIdx.x);
   if (tid < NHG) {
     const int g = m.hand_geom0 + tid;
@@ -529,7 +529,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
 }
 
 // ---- termination diffs (calc_ho_diff, ho_im4.py:664-688); out: pos, rot, jpos, obj, obj_rot(=0)
-__device__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& ev, float* out) {
+__device__ __forceinline__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& ev, float* out) {
   const int tid = threadIdx.x, hb0 = m.hand_body0, fr = ev.frame(0);
   GPTR(const float) ep = as_global(ev.ex->body_pos) + (size_t)fr * NHB * 3; GPTR(const float) eq = as_global(ev.ex->body_quat) + (size_t)fr * NHB * 4;
   float s = 0.f;
@@ -590,15 +590,16 @@ __device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& 
 }
 
 // ---- get_full_obs_v5(5) (ho_im4.py:280-356): 617 floats written straight to HBM, coalesced per segment
-__device__ void dev_write_obs(const DevModel& m, const Work& w, const ExpertView& ev, float* __restrict__ obs) {
+__device__ __forceinline__ void dev_write_obs(const DevModel& m, const Work& w, const ExpertView& ev, float* __restrict__ obs) {
   const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0;
   const DevExpert& x = *ev.ex;
   float R[9], Rqi[4];
   quat_matrix_ref(w.xquat[hb0], R);
   quat_inv(w.xquat[hb0], Rqi);
   const float* P = w.xpos[hb0];
-#define RT(comp, v) (R[(comp)] * (v)[0] + R[3 + (comp)] * (v)[1] + R[6 + (comp)] * (v)[2])
-  if (tid < 6) obs[tid] = R[(tid >> 1) * 3 + (tid & 1)];
+  // (component selection by compares, not by indexing R with a lane-dependent index: that would put R into scratch memory)
+#define RT(comp, v) (sel3(R[0], R[1], R[2], (comp)) * (v)[0] + sel3(R[3], R[4], R[5], (comp)) * (v)[1] + sel3(R[6], R[7], R[8], (comp)) * (v)[2])
+  if (tid < 6) { const int rw = tid >> 1, cl = tid & 1; obs[tid] = cl ? sel3(R[1], R[4], R[7], rw) : sel3(R[0], R[3], R[6], rw); }
   if (tid < 20) { obs[6 + tid] = w.qpos[6 + tid]; obs[126 + tid] = w.qvel[6 + tid]; }
   for (int t = tid; t < 100; t += NT) {
     const int k = t / 20, i = t % 20;
@@ -646,7 +647,7 @@ __device__ void dev_write_obs(const DevModel& m, const Work& w, const ExpertView
 }
 
 // ---- reset_model (ho_im4.py:690-716): state <- expert frame `start` of sequence `seq`
-__device__ void dev_reset_state(const DevModel& m, Work& w, const DevExpert& x, int seq, int start) {
+__device__ __forceinline__ void dev_reset_state(const DevModel& m, Work& w, const DevExpert& x, int seq, int start) {
   const int tid = threadIdx.x;
   const int len = x.seq_len[seq], off = x.seq_off[seq];
   const int fr = off + (start < len - 1 ? start : len - 1), nh = m.hand_nq;

@@ -33,6 +33,7 @@
 #define MAXMESHV HOIC_MAX_MESHVERT
 #define MAXMESHP HOIC_MAX_MESHPLANE
 #define MAXROUND 3       // pointer-jumping rounds of the kinematics (tree depth <= 8)
+#define SUM_DIRECT 4     // subtrees of at most this many bodies are summed directly (DevModel::body_sum)
 #define MAXVRUN (MAXMESHV / HOIC_HULL_RUN_VERTS + HOIC_MAX_MESH)
 #define MAXFRUN (MAXMESHP / HOIC_HULL_RUN_FACES + HOIC_MAX_MESH)
 
@@ -44,6 +45,11 @@ struct DevModel {
   int body_parent[NB], body_depth[NB], body_jntadr[NB], body_jntnum[NB], body_dofadr[NB], body_dofnum[NB];
   int body_subtree[NB];
   int body_jump[MAXROUND][NB];  // round r composes body b with body_jump[r][b] (-1: already in the world frame)
+  // composite (subtree) sums in two rounds instead of one range sum per body (the hand's root body would walk all 21 bodies
+  // while the other lanes idle): body_sum[b] = 0 not needed (no dof looks at this body's composite), 1 = range sum over the
+  // subtree (<= SUM_DIRECT bodies), 2 = own value + the composites of the children body_kids[b] (all of them mode 1)
+  int body_sum[NB];
+  unsigned body_kids[NB][2];    // up to 8 children, one byte each (0xFF = none)
   unsigned body_dofmask[NB];    // dofs on the path root -> body
   unsigned body_path[NB][3];    // the same path as up to 12 packed dof indices (0xFF = none), root first
   float body_pos[NB][3], body_quat[NB][4], body_ipos[NB][3], body_iquat[NB][4], body_mass[NB], body_inertia[NB][3];
