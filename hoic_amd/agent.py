@@ -522,6 +522,8 @@ class AgentHandMimic:
         # (measured: 6 ms of a 36 ms rollout).  One engine per range (own buffers and exponents: the ranges run concurrently).
         fwd = self._rollout_forward(groups) if (dt == torch.float32 and dev.type == "cuda") else None
         std = torch.exp(self.policy_net.action_log_std) if fwd is not None else None
+        # the rollout's N(0, 1) draws in one launch up front: a range's chain then samples inside the action-head kernel
+        noise_all = torch.randn(T, N, self.action_dim, device=dev, dtype=dt) if fwd is not None else None
         # Per-step outputs go straight into the rollout's [T, N, .] storage (no copy kernels in a range's chain), the
         # next-episode draws of all T steps are made up front, masks and statistics are derived once at the end.
         direct = dt == torch.float32 and dev.type == "cuda"
@@ -554,7 +556,7 @@ class AgentHandMimic:
                         states[t, sl] = state
                     if direct:
                         if fwd is not None:
-                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl], std=std)
+                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl], std=std, eps=noise_all[t, sl])
                         else:
                             action = self.policy_net.select_action(state, out=actions[t, sl])
                         self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count,

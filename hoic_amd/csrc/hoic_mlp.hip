@@ -1234,3 +1234,54 @@ extern "C" int32_t hoic_mlp_forward_tiled(int32_t M, int32_t N, int32_t K, const
   return HOIC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------- the action head of the rollout
+// out[m][n] = sum_k h[m][k] W[n][k] + bias[n] (+ std[n] * eps[m][n]):  PolicyGaussian.action_mean on the MLP body's output and
+// the Gaussian sample (uhc/khrylib/rl/core/policy_gaussian.py:27-33, distributions.py: mean + std * N(0, 1)) in ONE launch
+// that needs no LDS, so that it runs beside the simulator's substep workgroups like hoic_fwd_tiled_kernel does (the library
+// GEMM of this 2048 x 512 x 32 product queues for a CU's LDS behind them, and the sample was two more launches).
+// float32 throughout: v_mfma_f32_32x32x2_f32 is an exact float32 multiply-add chain.  One wavefront = 32 rows; lane (r, half)
+// loads four consecutive k of row r (h) and of output n = r (W) per 8-k block -- half 0 the first four, half 1 the last four --
+// and MFMA step s contracts element s of both halves, so operands are 16-byte loads and both matrices are read as stored.
+__global__ __launch_bounds__(64) void hoic_head_kernel(int M, int K, int N, const float* __restrict__ h, long long ldh, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ stdv, const float* __restrict__ eps,
+                                                        long long lde, float* __restrict__ out, long long ldo) {
+  const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5, row0 = blockIdx.x * 32;
+  const float* hp = h + (long long)(row0 + r) * ldh + 4 * hh;
+  const float* wp = W + (long long)(r < N ? r : 0) * K + 4 * hh;
+  const float wmask = r < N ? 1.f : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll 4
+  for (int kb = 0; kb < K; kb += 8) {
+    const f32x4 a = *(const f32x4*)(hp + kb);
+    f32x4 b = *(const f32x4*)(wp + kb);
+    b = b * wmask;
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  }
+  // D[i][j]: lane (j + 32 * half) holds rows i = (reg & 3) + 8 * (reg >> 2) + 4 * half of output column j
+  if (r < N) {
+    const float bj = bias ? bias[r] : 0.f, sj = (eps && stdv) ? stdv[r] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int i = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+      if (i < M) {
+        float v = acc[reg] + bj;
+        if (eps) v = fmaf(sj, eps[(long long)i * lde + r], v);
+        out[(long long)i * ldo + r] = v;
+      }
+    }
+  }
+}
+extern "C" int32_t hoic_mlp_head(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_bias,
+                                 const float* d_std, const float* d_eps, int64_t lde, float* d_out, int64_t ldo, void* stream) {
+  if (M <= 0 || (M & 31) || K <= 0 || (K & 7) || N <= 0 || N > 32 || !d_h || !d_W || !d_out || (ldh & 3) || ((size_t)d_h & 15) || ((size_t)d_W & 15)) {
+    hoic_set_error("hoic_mlp_head: M % 32 == 0, K % 8 == 0, N <= 32, 16-byte aligned h / W with ldh % 4 == 0"); return HOIC_ERR_ARG;
+  }
+  hipLaunchKernelGGL(hoic_head_kernel, dim3((unsigned)(M >> 5)), dim3(64), 0, (hipStream_t)stream, M, K, N, d_h, (long long)ldh, d_W, d_bias, d_std, d_eps,
+                     (long long)lde, d_out, (long long)ldo);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}

@@ -73,6 +73,8 @@ class _Kernels:
         L.hoic_mlp_update_exps_rel.argtypes = [vp, vp, i32, C.c_uint64, i32, i32, vp, vp, vp]
         L.hoic_mlp_pack_tiled.argtypes = [vp, i32, i32, i64, vp, i32, i32, vp, i32, vp]
         L.hoic_mlp_forward_tiled.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+        L.hoic_mlp_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
+        L.hoic_mlp_head.restype = i32
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
                   "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel",
                   "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled"):
@@ -426,6 +428,23 @@ class SplitMLP:
             self.table.overflow.zero_()
             raise lib.HoicError(f"f16x3 GEMM path: {n} tensor(s) exceeded the float16 range under their delayed scale exponent; "
                                 "the update is not valid (use update_dtype='f32')")
+
+
+def action_head(hidden, weight, bias, std=None, eps=None, out=None):
+    """mean = hidden @ weight^T + bias, or the Gaussian sample mean + std * eps when ``eps`` is given, in one LDS-free float32
+    launch (hoic_mlp_head); hidden [M, K] float32 with M % 32 == 0, weight [N <= 32, K]."""
+    M_, K_ = hidden.shape
+    N_ = weight.shape[0]
+    assert hidden.dtype == torch.float32 and hidden.stride(1) == 1 and weight.is_contiguous() and M_ % 32 == 0 and K_ % 8 == 0 and N_ <= 32
+    if out is None:
+        out = torch.empty(M_, N_, dtype=torch.float32, device=hidden.device)
+    assert out.stride(1) == 1 and (eps is None or (eps.stride(1) == 1 and eps.shape == (M_, N_)))
+    std1 = None if std is None else std.reshape(-1).contiguous()
+    K = kernels()
+    with torch.cuda.device(hidden.device):
+        K.chk(K.L.hoic_mlp_head(M_, K_, N_, _ptr(hidden), hidden.stride(0), _ptr(weight), _ptr(bias), _ptr(std1), _ptr(eps),
+                                0 if eps is None else eps.stride(0), _ptr(out), out.stride(0), _stream(hidden.device)), "hoic_mlp_head")
+    return out
 
 
 class TiledForward:

@@ -53,11 +53,19 @@ class PolicyGaussian(nn.Module):
             return mean if out is None else out.copy_(mean)
         return torch.addcmul(mean, torch.exp(log_std), torch.randn_like(mean), out=out)     # mean + std * eps
 
-    def select_action_from_hidden(self, hidden, out=None, std=None):
+    def select_action_from_hidden(self, hidden, out=None, std=None, eps=None):
         """select_action with the MLP body's output computed elsewhere (the rollout's LDS-free f16x3 forward);
-        ``std``: exp(action_log_std) when the caller has it already (constant during a rollout)"""
-        mean = self.action_mean(hidden)
+        ``std``: exp(action_log_std) when the caller has it already (constant during a rollout); ``eps``: the N(0, 1) draws
+        of this batch made up front -- head and sample are then ONE LDS-free launch (hoic_mlp_head) instead of a library
+        GEMM that queues for the CUs' LDS behind the simulator plus two elementwise kernels"""
         std = torch.exp(self.action_log_std) if std is None else std
+        if eps is not None and hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[0] % 32 == 0 and hidden.shape[1] % 8 == 0:
+            from .mlp import action_head
+            return action_head(hidden, self.action_mean.weight.detach(), self.action_mean.bias.detach(), std, eps, out)
+        if eps is not None:
+            mean = self.action_mean(hidden)
+            return torch.addcmul(mean, std.expand_as(mean), eps, out=out)
+        mean = self.action_mean(hidden)
         return torch.addcmul(mean, std.expand_as(mean), torch.randn_like(mean), out=out)
 
     def get_log_prob(self, x, action, hidden=None):

@@ -320,3 +320,32 @@ def test_f16x3_overflow_in_either_network_fails_the_update(which):
         net.affine_layers[1].weight[3, 5] = float("nan")
     with pytest.raises(lib.HoicError, match="float16 range"):
         L.update_params(batch)
+
+
+@gpu
+@pytest.mark.parametrize("rows,n_out", [(2048, 32), (96, 32), (64, 1)])
+def test_action_head_kernel_matches_float64(rows, n_out):
+    """hoic_mlp_head (the rollout's action head + Gaussian sample, one LDS-free float32 MFMA launch) against a float64
+    evaluation of mean = h W^T + b and of mean + std * eps: float32 accumulation error only (1e-6 of sum |h||w|), strided
+    output rows (the rollout writes straight into its [T, N, 32] storage), the mean-only form, and agreement with
+    PolicyGaussian.select_action_from_hidden's tensor path on the same draws."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    h = torch.randn(rows, 512, device="cuda", generator=g)
+    W = torch.randn(n_out, 512, device="cuda", generator=g) * 0.05; b = torch.randn(n_out, device="cuda", generator=g) * 0.1
+    std = torch.full((1, n_out), float(np.exp(-2.3)), device="cuda"); eps = torch.randn(rows, n_out, device="cuda", generator=g)
+    ref_mean = h.double() @ W.double().T + b.double()
+    scale = (h.double().abs() @ W.double().abs().T).max().item()
+    mean = M.action_head(h, W, b)
+    assert mean.shape == (rows, n_out) and (mean.double() - ref_mean).abs().max().item() < 1e-6 * scale
+    store = torch.full((rows, 3, n_out), 7.0, device="cuda")
+    out = M.action_head(h, W, b, std, eps, out=store[:, 1])
+    assert out.data_ptr() == store[:, 1].data_ptr() and torch.all(store[:, 0] == 7.0) and torch.all(store[:, 2] == 7.0)
+    assert (out.double() - (ref_mean + std.double() * eps.double())).abs().max().item() < 1e-6 * scale
+    if n_out == 32:
+        from hoic_amd.config import Config
+        from hoic_amd.rl import PolicyGaussian
+        pol = PolicyGaussian(Config("box_future5_light_add_geom"), 32, 617).cuda()
+        with torch.no_grad():
+            a_k = pol.select_action_from_hidden(h, eps=eps)                                      # kernel path
+            a_t = torch.addcmul(pol.action_mean(h), torch.exp(pol.action_log_std).expand(rows, 32), eps)
+        assert (a_k - a_t).abs().max().item() < 2e-6 * (1 + a_t.abs().max().item())
