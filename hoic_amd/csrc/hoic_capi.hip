@@ -383,16 +383,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
                                                            float* __restrict__ percent, const int* __restrict__ next_seq,
-                                                           const int* __restrict__ next_start, int first, int use_order, int n_envs, int post_buf,
-                                                           const int* __restrict__ list, const int* __restrict__ list_n) {
+                                                           const int* __restrict__ next_start, int first, int use_order, int n_envs, int post_buf) {
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
-  const int tid = threadIdx.x;
-  // list (split form only): the launch covers the envs hoic_reward_lite_kernel left to it, a fixed small grid looping over them
-  const int n_list = list ? *as_global(list_n) : (int)blockIdx.x + 1;      // (no list: exactly one pass, env from the block index)
-  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
-  if (list && li != (int)blockIdx.x) wsync();
-  const int env = list ? as_global(list)[li] : (use_order ? as_global(st.order)[n_envs + blockIdx.x] : first + (int)blockIdx.x), io = env - first;
+  const int env = use_order ? as_global(st.order)[n_envs + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
 #ifdef HOIC_TRACE_DISPATCH
   if (tid == 0) for (int i = 0; i < 4; i++) g_trace_qp[blockIdx.x * 4 + i] = 0;
@@ -433,67 +427,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int i = 0; i < 4; i++) tr[12 + i] = g_trace_qp[blockIdx.x * 4 + i];
 #endif
   }
-  }
-}
-
-// ---- the reward part of the split form for the envs that need no residual-force QP (no hand-object contact in the step,
-// explain_force off, a failed step: ~90 % of the envs of a rollout): contact presence from the record's counts, the free /
-// plain rfc score, ho_mimic_reward_9.  1 KB of LDS and < 112 registers: a workgroup fits BESIDE the eight substep workgroups
-// that fill a CU (3968 bytes of LDS and 112 registers per SIMD lane are what they leave), instead of queueing for one of
-// their 20 KB slots as hoic_poststep_kernel<POST_B> does.  Envs that do need the QP are appended to `list` and processed
-// by hoic_poststep_kernel<POST_B> on a small grid right behind this launch.  Same functions as dev_poststep: same bits.
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(112))) void hoic_reward_lite_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
-                                                                                                  DevExpert ex, DevState st, const float* __restrict__ action,
-                                                                                                  float* __restrict__ reward, float* __restrict__ reward_info,
-                                                                                                  int first, int n_envs, int post_buf,
-                                                                                                  int* __restrict__ list, int* __restrict__ list_n) {
-  __shared__ RewWork w;
-  const DevModel& m = *mp; const DevConfig& cfg = *cp;
-  const int env = first + (int)blockIdx.x, io = (int)blockIdx.x, tid = threadIdx.x;
-  GPTR(float) post = as_global(st.post) + ((size_t)post_buf * n_envs + env) * PB_SIZE;
-  const bool ok = post[PB_OK] != 0.f;
-  const bool has = tid < NHG && (int)post[PB_RECCNT + tid] > 0;
-  const int n_avg = __popcll(__ballot(has));                                                  // classify_contact's count (:567-597)
-  if (ok && cfg.c.residual_force && cfg.c.explain_force && n_avg > 0) {                       // the QP: not here
-    if (tid == 0) as_global(list)[atomicAdd(list_n, 1)] = env;
-    return;
-  }
-  if (tid < NQP) w.qpos[tid] = post[PB_QPOS + tid];
-  if (tid < NV) w.qvel[tid] = post[PB_QVEL + tid];
-  for (int k = tid; k < m.nbody * 3; k += NT) w.xpos[k / 3][k % 3] = post[PB_XPOS + k];
-  for (int k = tid; k < m.nbody * 4; k += NT) w.xquat[k / 4][k % 4] = post[PB_XQUAT + k];
-  wsync();
-  ExpertView ev{&ex, __float_as_int(post[PB_EV]), __float_as_int(post[PB_EV + 1]), __float_as_int(post[PB_EV + 2]), __float_as_int(post[PB_EV + 3])};
-  float rfc_score = 0.f;
-  if (ok && cfg.c.residual_force) {
-    if (!cfg.c.explain_force) {
-      float vf[3], vt[3];
-      for (int i = 0; i < 3; i++) {
-        vf[i] = cfg.c.residual_force_scale * fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + m.nu + i], -1.f), 1.f);
-        vt[i] = cfg.c.residual_torque_scale * fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + m.nu + 3 + i], -1.f), 1.f);
-      }
-      rfc_score = dev_rfc_score_plain(vf, vt);
-    } else {
-      const int lastg = m.ngeom - 1;
-      float ow[3], acc6[6];
-      for (int i = 0; i < 3; i++) ow[i] = post[PB_GANGVEL + lastg * 3 + i];
-      for (int i = 0; i < 6; i++) acc6[i] = post[PB_OBJACC + i];
-      double F[3], tau[3];
-      dev_required_wrench(m, &w.qpos[m.nq - 4], ow, acc6, F, tau);
-      rfc_score = dev_rfc_score_free(F, tau);
-      if (tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
-    }
-    if (!isfinite(rfc_score)) rfc_score = 0.f;
-  }
-  const int expert_len = ev.len - ev.start;
-  const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;
-  float rw[10];
-  dev_reward(m, cfg, w, ev, rfc_score, rw);
-  float r = rw[0];
-  if (cfg.rp.use_end_reward && end) r += cfg.rp.end_reward;
-  if (tid == 0) { reward[io] = r; as_global(st.rfc_score)[env] = rfc_score; }
-  if (tid < HOIC_NREWARD_INFO) reward_info[(size_t)io * HOIC_NREWARD_INFO + tid] = rw[1 + tid];
-  if (tid == 6 && post[PB_DONE] != 0.f) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
 }
 
 // ---- launch order of the next step (optional, HOIC_REORDER=1).  An env's pass takes between ~0.7x and ~1.8x the
@@ -671,7 +604,6 @@ struct hoic_sim {
   // step and the events "reward part of the step that used buffer b has finished"
   struct AsyncRange { int first = 0, count = 0, next_buf = 0; hipStream_t side = nullptr; hipEvent_t sub_done = nullptr, rew_done[2] = {nullptr, nullptr}; bool pending[2] = {false, false}; };
   bool async_reward = false;
-  bool lite_reward = true;       // HOIC_NO_LITE_REWARD=1: the whole reward part on hoic_poststep_kernel<POST_B> (A/B)
   std::vector<AsyncRange> ranges;
   int expert_reserve = 0, expert_cap = 0;   // streaming: room for more frames behind the last sequence
   std::vector<int> h_seq_len, h_seq_off;
@@ -987,8 +919,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, 2 * n * PB_SIZE * 4) == hipSuccess &&
        hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess &&
        hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess &&
-       hipMalloc(&s->st.lagrec, n * LG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.lag_valid, n * 4) == hipSuccess &&
-       hipMalloc(&s->st.heavy_list, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.heavy_cnt, 2 * 16 * 4) == hipSuccess;
+       hipMalloc(&s->st.lagrec, n * LG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.lag_valid, n * 4) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
   ok = hipMalloc(&s->d_ex, sizeof(DevExpert)) == hipSuccess && hipMalloc(&s->d_st, sizeof(DevState)) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
@@ -1008,8 +939,6 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   s->reorder = getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '1';
   s->use_lag = getenv("HOIC_NO_LAGREC") == nullptr;
   s->fused = getenv("HOIC_FUSED_STEP") != nullptr && getenv("HOIC_FUSED_STEP")[0] == '1';
-  s->lite_reward = getenv("HOIC_NO_LITE_REWARD") == nullptr;
-  s->ranges.reserve(16);         // AsyncRange addresses stay valid (indices into heavy_cnt)
   hipDeviceSynchronize();
   return s;
 }
@@ -1019,7 +948,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.diag, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->st.heavy_list, s->st.heavy_cnt, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.diag, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   for (auto& r : s->ranges) {
@@ -1184,20 +1113,8 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
     if (e) hipEventRecord(e[1], st);
     HIPCHK(hipEventRecord(r->sub_done, st));
     HIPCHK(hipStreamWaitEvent(r->side, r->sub_done, 0));
-    if (s->lite_reward) {
-      // the envs without a residual-force QP on a kernel that fits beside the substep workgroups, the others (listed by it) on
-      // a small looping grid of the full post-step kernel
-      const int ri = (int)(r - &s->ranges[0]);
-      int* list = s->st.heavy_list + (size_t)buf * s->n_envs + first;
-      int* cnt = s->st.heavy_cnt + buf * 16 + ri;
-      HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int), r->side));
-      hipLaunchKernelGGL(hoic_reward_lite_kernel, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_reward, d_reward_info,
-                         first, s->n_envs, buf, list, cnt);
-      hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(std::min(count, 256)), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                         d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf, (const int*)list, (const int*)cnt);
-    } else
     hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf, (const int*)nullptr, (const int*)nullptr);
+                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
     HIPCHK(hipEventRecord(r->rew_done[buf], r->side)); r->pending[buf] = true;
     if (e) { hipEventRecord(e[2], r->side); s->n_timed++; }      // "post-step" time of this form: end of the substeps -> end of the reward part
     HIPCHK(hipGetLastError());
@@ -1214,7 +1131,7 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
                        (const int*)nullptr, (const int*)nullptr, s->n_envs, 0);
     if (e) hipEventRecord(e[1], st);
     hipLaunchKernelGGL(hoic_poststep_kernel<POST_ALL>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs, 0, (const int*)nullptr, (const int*)nullptr);
+                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs, 0);
   }
   if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());

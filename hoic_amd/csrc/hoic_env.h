@@ -430,19 +430,20 @@ __device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, con
   if (stat) stat[1] = n_dual;
 }
 
-// The wrench the object needs for its measured 15-substep motion (ho_im4.py:961-976): F = m (a + g), tau = I dw + w x I w, with
-// the inertia rotated by the object's current orientation `oq` (wxyz), ow = its finite-difference angular velocity, acc6 =
-// the finite-difference linear / angular acceleration.  float64, shared by every form of the post-step work.
-HD void dev_required_wrench(const DevModel& m, const float* oq, const float* ow_f, const float* acc6, double (&F)[3], double (&tau)[3]) {
-  const int ob = m.obj_body;
+__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt, double* warm_lam) {
+  const int tid = threadIdx.x;
+  const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025;
+  if (!cfg.c.explain_force)
+    return sqrtf(dot3(vf, vf)) + (float)w_t * sqrtf(dot3(vt, vt));
+  const int nq = m.nq, ob = m.obj_body, lastg = m.ngeom - 1;
   double Rm[9];
   {
     float Rf[9];
-    quat_matrix_ref(oq, Rf);
+    quat_matrix_ref(&w.qpos[nq - 4], Rf);
     for (int i = 0; i < 9; i++) Rm[i] = Rf[i];
   }
-  double I[9], ow[3], oa[3], ooa[3];
-  for (int i = 0; i < 3; i++) { ow[i] = ow_f[i]; oa[i] = acc6[i]; ooa[i] = acc6[3 + i]; }
+  double F[3], tau[3], I[9], ow[3], oa[3], ooa[3];
+  for (int i = 0; i < 3; i++) { ow[i] = w.sc.post.gangvel[lastg][i]; oa[i] = w.sc.post.obj_avg_acc[i]; ooa[i] = w.sc.post.obj_avg_acc[3 + i]; }
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       double s = 0;
@@ -459,25 +460,9 @@ HD void dev_required_wrench(const DevModel& m, const float* oq, const float* ow_
   tau[0] = Ioa[0] + ow[1] * Iw[2] - ow[2] * Iw[1];
   tau[1] = Ioa[1] + ow[2] * Iw[0] - ow[0] * Iw[2];
   tau[2] = Ioa[2] + ow[0] * Iw[1] - ow[1] * Iw[0];
-}
-// rfc_score without a hand-object contact: the whole required wrench is unexplained (ho_im4.py:980-981; w_t, not sqrt(w_t))
-HD float dev_rfc_score_free(const double (&F)[3], const double (&tau)[3]) {
-  return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + 1e4 * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
-}
-HD float dev_rfc_score_plain(const float* vf, const float* vt) {      // explain_force off (ho_im4.py:951-952)
-  return sqrtf(dot3(vf, vf)) + 1e4f * sqrtf(dot3(vt, vt));
-}
-
-__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt, double* warm_lam) {
-  const int tid = threadIdx.x;
-  const double swt = 100.0, mu = 0.75, dx = 0.0025;
-  if (!cfg.c.explain_force) return dev_rfc_score_plain(vf, vt);
-  const int nq = m.nq, lastg = m.ngeom - 1;
-  double F[3], tau[3], ow[3];
-  dev_required_wrench(m, &w.qpos[nq - 4], w.sc.post.gangvel[lastg], w.sc.post.obj_avg_acc, F, tau);
-  for (int i = 0; i < 3; i++) ow[i] = w.sc.post.gangvel[lastg][i];
   if (w.sc.post.n_avg == 0) { if (tid == 6) warm_lam[6] = 0.0; }
-  if (w.sc.post.n_avg == 0) return dev_rfc_score_free(F, tau);
+  if (w.sc.post.n_avg == 0)
+    return (float)(sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) + w_t * sqrt(tau[0] * tau[0] + tau[1] * tau[1] + tau[2] * tau[2]));
   const int npt = cfg.c.surface_contact ? 5 : 1, ncol = w.sc.post.n_avg * npt * 4;
   const int nslot = (ncol + NT - 1) / NT;         // columns per lane actually present (typically 1-2 of at most 6)
   const double inv = 1.0 / sqrt(1.0 + mu * mu);
@@ -565,9 +550,7 @@ __device__ __forceinline__ void dev_ho_diff(const DevModel& m, const Work& w, co
 }
 
 // ---- ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-1047); out[0] reward, out[1..9] info
-// (W: any workspace with qpos / qvel / xpos / xquat of the step -- the full Work or the reward-only kernel's RewWork)
-template <class W>
-__device__ __forceinline__ void dev_reward(const DevModel& m, const DevConfig& cfg, const W& w, const ExpertView& ev, float rfc_score, float* out) {
+__device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& w, const ExpertView& ev, float rfc_score, float* out) {
   const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0, fr = ev.frame(0);
   const float* wk = cfg.rp.wk;
   GPTR(const float) eq = as_global(ev.ex->hand_dof) + (size_t)fr * nh; GPTR(const float) evel = as_global(ev.ex->hand_dof_vel) + (size_t)fr * nh;

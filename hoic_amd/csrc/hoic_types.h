@@ -158,9 +158,6 @@ struct DevState {
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
   unsigned* cost;    // [2, n] shader-clock duration (>> 6) of the env's last substep / post-step pass
   int* order;        // [2, n] launch order of the next step: workgroup b runs env order[b], longest first
-  int* heavy_list;   // [2, n] split post-step: envs of a step whose reward part needs the residual-force QP (per record buffer;
-                     //         a range's entries start at its first env)
-  int* heavy_cnt;    // [2, 16] their number per (record buffer, env range)
 };
 
 // joint-space inertia matrix in the layout of a v_mfma_f32_32x32x2_f32 accumulator: lane (col + 32*hi) holds, in
@@ -242,10 +239,6 @@ static_assert(sizeof(Work) <= 20480, "Work must stay under 20 KB: 8 environments
 #define QP_MAXCOL (NHG * 5 * 4)
 #define QP_COL_FLOATS (7 * QP_MAXCOL)
 static_assert(offsetof(Work, gxmat) + sizeof(((Work*)0)->gxmat) - offsetof(Work, col_lc) >= QP_COL_FLOATS * 4, "QP column overlay");
-
-// workspace of the reward-only kernel (hoic_reward_lite_kernel): what ho_mimic_reward_9 reads of the step
-struct RewWork { float qpos[NQP], qvel[NV], xpos[NB][3], xquat[NB][4]; };
-static_assert(sizeof(RewWork) <= 3968, "RewWork must fit beside eight substep workgroups: 163840 - 8 * 19984 bytes of LDS per CU");
 
 #ifdef HOIC_PHASE_TIMING
 #define PT(i) do { long long t_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) { w.pt[i] += t_ - w.pt_last; w.pt_last = t_; } } while (0)
