@@ -285,11 +285,13 @@ def main():
     t_sample = t_update = 0.0
     last_log = None
     launches = 0
+    host_enqueue = 0.0
     collected = 0          # samples that entered the batches (episodes mode: valid rows; fixed horizon: steps x envs)
     for _ in range(n_it):
         info = agent.optimize_policy(epoch, save_model=False); epoch += 1
         t_sample += info["T_sample"]; t_update += info["T_update"]; last_log = info["log"]
         collected += int(info["log"].num_steps); launches += int(agent.last_rollout_steps)
+        host_enqueue += float(getattr(agent, "last_host_enqueue_s", 0.0))
         a, b = agent.env.sim.step_times()       # HIP events on the launch stream, read after the iteration's own sync
         kernel_ms += a; post_ms += b
     agent.learner.finish_update()            # an asynchronous value phase belongs to the timed region
@@ -344,6 +346,7 @@ def main():
                                                 if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,
             "update_s_per_iteration": t_update / n_it, "rollout_s_per_iteration": t_sample / n_it,
+            "rollout_host_enqueue_s_per_iteration": host_enqueue / n_it,
             "avg_episode_len": float(last_log.avg_episode_len), "avg_c_reward": float(last_log.avg_c_reward),
             "workload_stats": {"hand_object_contact_env_fraction": float(ho.any(1).mean()), "mean_contacts_per_env": float((cc[:, :, 15] > 0).sum(1).mean()),
                                "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"],

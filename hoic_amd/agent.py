@@ -542,6 +542,7 @@ class AgentHandMimic:
         async_reward = direct and self.async_reward
         if async_reward:
             self.env.sim.set_async_reward(True)
+        t_host0 = time.perf_counter()
         for t in range(T):
             for gi, (first, count) in enumerate(groups):
                 sl = slice(first, first + count)
@@ -566,6 +567,7 @@ class AgentHandMimic:
                         self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count)
                         actions[t, sl] = action
                         rewards[t, sl] = self.env.c_reward; rinfo_all[t, sl] = self.env.c_info; flags_all[t, sl] = self.env.sim.flags[sl]
+        self.last_host_enqueue_s = time.perf_counter() - t_host0      # host time to enqueue the rollout (no synchronisation inside)
         if use_streams:
             for st_ in self._streams:
                 main.wait_stream(st_)
