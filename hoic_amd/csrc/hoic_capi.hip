@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
   // workgroup b runs env first + b (I/O row b), or env order[b] of a whole-batch step in longest-first order
-  const int env = use_order ? as_global(st.order)[blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
+  const int env = use_order ? as_global(st.order)[first + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
 #ifdef HOIC_TRACE_DISPATCH
   const long long trace_t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -436,11 +436,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // step to step: a counting sort on 1024 duration bins, one workgroup per kernel (blockIdx 0: substep order, 1:
 // post-step order).  The order only changes which CU runs an env, never a result.
 #define ORDER_NT 1024
-__global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __restrict__ cost_all, int* __restrict__ order_all, int n) {
+// (first, count): the env range to order (a rollout range or the whole batch); order[first + k] = k-th longest env of the range
+__global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __restrict__ cost_all, int* __restrict__ order_all, int n_all, int first, int n) {
   __shared__ unsigned hist[ORDER_NT], scan[ORDER_NT];
   __shared__ unsigned lo, hi;
-  const unsigned* cost = cost_all + (size_t)blockIdx.x * n;
-  int* order = order_all + (size_t)blockIdx.x * n;
+  const unsigned* cost = cost_all + (size_t)blockIdx.x * n_all + first;
+  int* order = order_all + (size_t)blockIdx.x * n_all + first;
   const int tid = threadIdx.x;
   if (tid == 0) { lo = 0xFFFFFFFFu; hi = 0u; }
   hist[tid] = 0u;
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __
   __syncthreads();
   for (int i = tid; i < n; i += ORDER_NT) {
     const unsigned b = (ORDER_NT - 1) - (unsigned)(((unsigned long long)(cost[i] - base) * (ORDER_NT - 1)) / span);
-    order[atomicAdd(&hist[b], 1u)] = i;
+    order[atomicAdd(&hist[b], 1u)] = first + i;
   }
 }
 
@@ -933,10 +934,13 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   hipMemset(s->st.post, 0, 2 * n * PB_SIZE * 4); hipMemset(s->st.oldg, 0, n * OG_SIZE * 4); hipMemset(s->st.qp_lam, 0, n * 8 * 8);
   hipMemset(s->st.cost, 0, 2 * n * 4);
   hipMemset(s->st.lagrec, 0, n * LG_SIZE * 4); hipMemset(s->st.lag_valid, 0, n * 4);
-  hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, 0, s->st.cost, s->st.order, n_envs);   // a valid permutation from the start
-  // Off unless HOIC_REORDER=1: at the random-policy start of training the previous step's duration predicts the next
-  // one only weakly (correlation 0.1-0.4, tools/dispatch_trace.py) and the measured kernel time is unchanged.
-  s->reorder = getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '1';
+  hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, 0, s->st.cost, s->st.order, n_envs, 0, n_envs);   // a valid permutation from the start
+  // Longest-first dispatch by each env's previous duration, per launch range (HOIC_REORDER=0 switches it off).  The
+  // step-to-step correlation of an env's duration is only 0.4-0.5 (tools/duration_predictors.py; the contact count before the
+  // step predicts even less: 0.2-0.25), but in the two-range rollout the workgroups of a launch start one by one as the
+  // other range's wavefronts retire, and starting the likely-long ones first shortens the launch: 2.10 -> 1.95 ms per
+  // 2048-env launch, rollout +3 % (+4 % on a tracking policy).  Whole-batch launches gain nothing measurable.
+  s->reorder = !(getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '0');
   s->use_lag = getenv("HOIC_NO_LAGREC") == nullptr;
   s->fused = getenv("HOIC_FUSED_STEP") != nullptr && getenv("HOIC_FUSED_STEP")[0] == '1';
   hipDeviceSynchronize();
@@ -1088,9 +1092,12 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(s->device));     // the launches go to the handle's device whatever the caller's current one is
   hipEvent_t* e = s->timing ? s->ev[s->n_timed % hoic_sim::NEV] : nullptr;
-  const int use_order = s->reorder && first == 0 && count == s->n_envs;
-  if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(2), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs);
-  if (s->async_reward && !s->fused && !use_order) {
+  // longest-first dispatch (HOIC_REORDER=1): the substep workgroups of the launch start in the order of their env's previous
+  // duration; the post-step order only exists for whole-batch launches of the default form
+  const int use_order = s->reorder ? 1 : 0;
+  const bool whole = first == 0 && count == s->n_envs;
+  if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(whole ? 2 : 1), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs, first, count);
+  if (s->async_reward && !s->fused) {
     // Split form: termination, reset and observation at the end of the substep kernel (what the caller's next policy forward
     // needs), the reward part (contact classification, residual-force QP, reward) on the range's side stream from the
     // hand-over record.  The record buffers alternate, so the reward part of step t only has to finish before the
@@ -1108,7 +1115,7 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
     const int buf = r->next_buf; r->next_buf ^= 1;
     if (r->pending[buf]) HIPCHK(hipStreamWaitEvent(st, r->rew_done[buf], 0));      // the reward part of step t - 2 read this record
     if (e) hipEventRecord(e[0], st);
-    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, 0,
+    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
                        s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs, buf);
     if (e) hipEventRecord(e[1], st);
     HIPCHK(hipEventRecord(r->sub_done, st));
@@ -1131,7 +1138,7 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
                        (const int*)nullptr, (const int*)nullptr, s->n_envs, 0);
     if (e) hipEventRecord(e[1], st);
     hipLaunchKernelGGL(hoic_poststep_kernel<POST_ALL>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, use_order, s->n_envs, 0);
+                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, (use_order && whole) ? 1 : 0, s->n_envs, 0);
   }
   if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());
@@ -1322,6 +1329,12 @@ extern "C" int32_t hoic_step_times(hoic_sim* s, float* substep_ms, float* postst
   return n;
 }
 
+extern "C" int32_t hoicdbg_env_ncon(hoic_sim* s, float* out) {      // development aid: contacts of every env's last forward pass (lag record)
+  if (!s || !out) return HOIC_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy2D(out, 4, s->st.lagrec + LG_NCON, (size_t)LG_SIZE * 4, 4, s->n_envs, hipMemcpyDeviceToHost));
+  return HOIC_OK;
+}
 extern "C" int32_t hoicdbg_phase_raw(hoic_sim* s, long long* out) {     // development aid: the raw [n_envs, 24] counters
   if (!s || !out) return HOIC_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
