@@ -360,7 +360,7 @@ class AgentHandMimic:
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
                  start_min=0, overlap_value_update=False, rollout_forward="tiled", async_reward=True, fused_adam=True,
-                 update_streams=2):
+                 update_streams=2, filter_mode="online"):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
@@ -370,6 +370,13 @@ class AgentHandMimic:
         # off its critical path (hoic_set_async_reward);  both are on by default and exist as switches for A/B measurements
         assert rollout_forward in ("tiled", "torch")
         self.rollout_forward, self.async_reward = rollout_forward, bool(async_reward)
+        # observation filter during sampling: "online" = every step's observations update it before they are normalised (the
+        # reference's ZFilter updates row by row inside its sampler, zfilter.py:59-73); "frozen" = a rollout is normalised with
+        # the statistics of the iterations before it and its valid observations are merged afterwards (what a sampler that
+        # ships the statistics to its workers once per iteration does: tools/reward_curve.py's CPU arms) -- whole-episode mode
+        # only, a switch for attributing reward-curve differences, not a product mode
+        assert filter_mode in ("online", "frozen")
+        self.filter_mode = filter_mode
         self.start_min = int(start_min)      # episodes start at frame >= start_min (benchmark workloads; the reference draws from 0)
         self.cfg = self.cc_cfg = cfg
         self.sample_mode = sample_mode
@@ -608,11 +615,15 @@ class AgentHandMimic:
         active = torch.ones(N, dtype=torch.bool, device=dev)
         count = torch.zeros(N, dtype=torch.int64, device=dev)
         S, A, R, RI, FL, VA = [], [], [], [], [], []
+        frozen = self.filter_mode == "frozen"
+        RAW = []
         max_steps = quota + int(self.env.seq_len.max()) + sync_every + 1
         for t in range(max_steps):
             # every env's observation updates the filter, idle workers' included (they keep running the same policy, so
             # the statistics are those of the same state distribution; one fused launch instead of a gather + ~30 kernels)
-            state = self.running_state(obs).to(dt)
+            if frozen:
+                RAW.append(obs.clone())
+            state = self.running_state(obs, update=not frozen).to(dt)
             action = self.policy_net.select_action(state)
             nseq, nstart = self._draw_episodes(N)
             self.env.step(action, nseq, nstart)
@@ -629,6 +640,8 @@ class AgentHandMimic:
         rewards, rinfo, flags, valid = torch.stack(R).to(dt), torch.stack(RI), torch.stack(FL), torch.stack(VA)
         T = states.shape[0]
         done_all = flags[:, :, 2] != 0
+        if frozen:
+            self.running_state.push(torch.stack(RAW)[valid])       # the batch's own observations, after the rollout
         if self.distributed:
             self.running_state.sync()
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=(~done_all).to(dt),

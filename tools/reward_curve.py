@@ -13,6 +13,9 @@ Arms
   hip_episodes   AgentHandMimic(sample_mode="episodes"): the reference's whole-episode batch on the HIP simulator,
                  n_envs = `--episode-workers` playing num_threads
   hip_fixed_f16x3 hip_fixed with update_dtype="f16x3" (the bench default): the learner-level check of "float32-class accuracy"
+  hip_episodes_frozen hip_episodes with the observation filter handled as the CPU arms handle it: a rollout is normalised with
+                 the statistics of the iterations before it (iteration 0: none, i.e. raw observations clipped at +-5) and its
+                 observations are merged afterwards -- separates "filter order" from "simulator" in the cpu/hip gap
   hip_fixed_long fixed horizon with 4x longer windows (envs / 4 environments): a diagnostic for the truncation length
 
 Every `--eval-every` iterations each run evaluates its current policy + observation filter with deterministic
@@ -312,9 +315,10 @@ def run_hip_arm(args, arm, seed):
     expert = motions.synthetic_expert(model, N_SEQ, SEQ_LEN)
     torch.manual_seed(seed)
     mode, n_envs = {"hip_fixed": ("fixed", args.envs), "hip_episodes": ("episodes", args.episode_workers),
+                    "hip_episodes_frozen": ("episodes", args.episode_workers),
                     "hip_fixed_long": ("fixed", max(args.envs // 4, 1)), "hip_fixed_f16x3": ("fixed", args.envs)}[arm]
     agent = AgentHandMimic(cfg, device=dev, n_envs=n_envs, model=args.obj, expert_seqs=expert, sample_mode=mode,
-                           update_dtype="f16x3" if arm.endswith("f16x3") else "f32")
+                           update_dtype="f16x3" if arm.endswith("f16x3") else "f32", filter_mode="frozen" if arm.endswith("_frozen") else "online")
     curve, evals = [], []
     t_start = time.time()
     for it in range(args.iters + 1):
@@ -399,7 +403,7 @@ def main():
     common = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--eval-every", str(args.eval_every),
               "--workers", str(args.workers), "--slots", str(args.slots), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
     t0 = time.time()
-    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes")], [j for j in jobs if j[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3")]
+    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3")]
     procs = []
     for arm, seed in side:
         f = os.path.join(tmp, f"{arm}_{seed}.json")
@@ -428,6 +432,7 @@ def main():
                     "cpu_fixed": "float64 CPU-oracle envs, the batched sampler's fixed-horizon scheme",
                     "hip_fixed": "HIP simulator, fixed-horizon batches with value bootstrap (product default)",
                     "hip_episodes": "HIP simulator, whole-episode batches (sample_mode='episodes')",
+                    "hip_episodes_frozen": "hip_episodes with the CPU arms' filter handling: statistics frozen during a rollout, merged after it",
                     "hip_fixed_long": "HIP simulator, fixed horizon, 4x fewer envs and 4x longer windows",
                     "hip_fixed_f16x3": "hip_fixed with the PPO update's GEMMs on the f16x3 matrix-core path (what bench.py times)"},
            "obj": args.obj, "iters": args.iters, "eval_every": args.eval_every, "workers": args.workers, "envs": args.envs,
