@@ -200,8 +200,10 @@ def main():
     ap.add_argument("--obj", default="box", choices=["box", "bottle", "banana"])
     ap.add_argument("--update-dtype", default="f16x3", choices=["f32", "bf16", "f16x3"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--workload", default="train", choices=["train", "grasp"],
-                    help="train: the sampler's own episode draws; grasp: episodes start at frames >= 100 (object in the hand: contact-rich)")
+    ap.add_argument("--workload", default="train", choices=["train", "grasp", "closed-grasp"],
+                    help="train: the sampler's own episode draws; grasp: episodes start at frames >= 100 (object in the hand: contact-rich); "
+                         "closed-grasp: grasp + reference motions whose five fingers close onto the object from frame 160 on "
+                         "(motions.synthetic_expert(grasp='closed')): with --pretrain >= 100 most envs hold hand-object contacts")
     ap.add_argument("--pretrain", type=int, default=0,
                     help="untimed PPO iterations before the warm-up: the timed region then runs a policy that tracks the motions and holds "
                          "the object (contact-rich) instead of the random initial policy")
@@ -250,11 +252,11 @@ def main():
 
     cfg = Config(f"{args.obj}_future5_light_add_geom")
     model = mjcf.load_packaged(args.obj)
-    expert = motions.synthetic_expert(model, 17, 600)         # 17 sequences x 600 frames
+    expert = motions.synthetic_expert(model, 17, 600, grasp="closed" if args.workload == "closed-grasp" else "kinematic")   # 17 sequences x 600 frames
     agent = AgentHandMimic(cfg, device=torch.device("cuda", local_rank), n_envs=args.envs, model=args.obj,
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
                            solver_iterations=args.solver_iterations, n_groups=args.groups, scaling=args.scaling,
-                           start_min=100 if args.workload == "grasp" else 0, overlap_value_update=bool(args.overlap),
+                           start_min=100 if args.workload in ("grasp", "closed-grasp") else 0, overlap_value_update=bool(args.overlap),
                            rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams,
                            sample_mode=args.sample_mode)
     share = world if args.scaling == "strong" else 1
@@ -334,7 +336,8 @@ def main():
             "config": {"workload": f"{args.obj.capitalize()}, {args.envs} parallel envs per GPU, HIP batched sim "
                                    f"+ PyTorch-ROCm PPO (whole loop: rollout + GAE + {cfg.num_optim_epoch} full-batch epochs)"
                                    + ("; whole-episode sampler (the reference's batch: every env one sampler worker)" if args.sample_mode == "episodes" else "")
-                                   + ("; episodes start at frames >= 100 (grasp phase, contact-rich)" if args.workload == "grasp" else "")
+                                   + ("; episodes start at frames >= 100 (grasp phase, contact-rich)" if args.workload in ("grasp", "closed-grasp") else "")
+                                   + ("; reference motions with the five fingers closed onto the object from frame 160 on" if args.workload == "closed-grasp" else "")
                                    + (f"; policy after {args.pretrain} untimed PPO iterations (tracks the motions, holds the object)" if args.pretrain else ""),
                        "envs_per_gpu": args.envs, "pretrain_iterations": args.pretrain, "steps_per_iteration": K // n_it, "timed_iterations": n_it,
                        "samples_per_iteration": total_env_steps // n_it, "parallelism": f"env-dp{world}", "sample_mode": args.sample_mode,

@@ -212,7 +212,110 @@ def object_rest_height(model: mjcf.CompiledModel, quat) -> float:
     return float(-qrot(np.broadcast_to(np.asarray(quat, dtype=np.float64), (pts.shape[0], 4)), pts)[:, 2].min())
 
 
-def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_half_height: float | None = None) -> dict:
+# ----------------------------------------------------------------------------- closed grasp (contact-rich benchmark workload)
+def _object_signed_distance(model: mjcf.CompiledModel, pts):
+    """Signed distance (box geoms: exact; hull geoms: largest face-plane distance, exact inside and a lower bound outside)
+    of points given in the OBJECT BODY frame to the union of the object's collision geoms; (n,) array."""
+    A = model.arrays
+    ob = model.scalar("obj_body")
+    best = np.full(pts.shape[0], np.inf)
+    for g in range(model.scalar("obj_geom0"), model.scalar("obj_geom1") + 1):
+        if A["geom_bodyid"][g] != ob:
+            continue
+        gq = np.broadcast_to(A["geom_quat"][g] * np.array([1, -1, -1, -1]), (pts.shape[0], 4))      # inverse rotation
+        loc = qrot(gq, pts - A["geom_pos"][g])
+        if A["geom_type"][g] == mjcf.GEOM_BOX:
+            d = np.abs(loc) - A["geom_size"][g]
+            sd = np.linalg.norm(np.maximum(d, 0), axis=1) + np.minimum(d.max(1), 0)
+        elif A["geom_type"][g] == mjcf.GEOM_MESH:
+            me = A["geom_meshid"][g]
+            pl = A["mesh_plane"][A["mesh_planeadr"][me]:A["mesh_planeadr"][me] + A["mesh_planenum"][me]]
+            sd = (loc @ pl[:, :3].T - pl[:, 3]).max(1)
+        else:
+            continue
+        best = np.minimum(best, sd)
+    return best
+
+
+def closed_grasp_pose(model: mjcf.CompiledModel, hand_open, obj_rel_pos, obj_rel_quat, depth=0.0008):
+    """Finger joint angles that close the five fingers onto an object held at (obj_rel_pos, obj_rel_quat) in the PALM frame:
+    per finger, the joints move from `hand_open` along the direction that brings the finger's capsules closest to the
+    object (finite differences of the capsule-to-object distance), by bisection until the nearest capsule penetrates the
+    object by `depth` (or a joint limit stops it).  Pure kinematics on the compiled model (no simulator)."""
+    A = model.arrays
+    nh = model.scalar("hand_nq")
+    lo, hi = A["jnt_range"][:nh, 0], A["jnt_range"][:nh, 1]
+    hb0 = model.scalar("hand_body0")
+    q0 = np.zeros(model.scalar("nq")); q0[:nh] = hand_open; q0[nh:] = A["qpos0"][nh:]
+    q0[:6] = 0.0; q0[2] = 1.0                           # palm pose is irrelevant: everything is expressed in the palm frame
+    fingers = {}                                        # finger base body -> (joint ids, capsule geom ids)
+    for j in range(6, nh):
+        b = int(A["jnt_bodyid"][j]); base = b
+        while int(A["body_parent"][base]) != hb0:
+            base = int(A["body_parent"][base])
+        fingers.setdefault(base, ([], []))[0].append(j)
+    for g in range(model.scalar("hand_geom0"), model.scalar("hand_geom1") + 1):
+        if A["geom_type"][g] != mjcf.GEOM_CAPSULE:
+            continue
+        base = int(A["geom_bodyid"][g])
+        while int(A["body_parent"][base]) != hb0:
+            base = int(A["body_parent"][base])
+        if base in fingers:
+            fingers[base][1].append(g)
+
+    def finger_dist(q, geoms):
+        xpos, xquat = fk_batch(model, q[None])
+        pq = xquat[0, hb0] * np.array([1, -1, -1, -1]); oq = np.asarray(obj_rel_quat) * np.array([1, -1, -1, -1])
+        best = np.inf
+        for g in geoms:
+            b = int(A["geom_bodyid"][g])
+            gp = xpos[0, b] + qrot(xquat[0, b], A["geom_pos"][g]); gq = qmul(xquat[0, b], A["geom_quat"][g])
+            ax = qrot(gq, np.array([0.0, 0.0, 1.0]))
+            pts = gp + np.linspace(-1, 1, 9)[:, None] * A["geom_size"][g][1] * ax                   # along the capsule axis, world
+            pts = qrot(np.broadcast_to(pq, (9, 4)), pts - xpos[0, hb0])                            # palm frame
+            pts = qrot(np.broadcast_to(oq, (9, 4)), pts - np.asarray(obj_rel_pos))                 # object frame
+            best = min(best, float(_object_signed_distance(model, pts).min() - A["geom_size"][g][0]))
+        return best
+    out = np.array(hand_open, dtype=np.float64)
+    for base, (jids, geoms) in fingers.items():
+        if not geoms:
+            continue
+        d0 = finger_dist(q0, geoms)
+        direc = np.zeros(nh)
+        for j in jids:                                   # closing direction of each joint
+            h = 0.05
+            qa = q0.copy(); qa[j] = min(q0[j] + h, hi[j]); qb = q0.copy(); qb[j] = max(q0[j] - h, lo[j])
+            da, db = finger_dist(qa, geoms), finger_dist(qb, geoms)
+            direc[j] = (db - da) / max(qa[j] - qb[j], 1e-9)
+        if not np.any(direc > 1e-4) and not np.any(direc < -1e-4):
+            continue
+        direc = direc / np.abs(direc).max()
+        amax = min(((hi[j] - q0[j]) / direc[j] if direc[j] > 0 else (lo[j] - q0[j]) / direc[j]) for j in jids if abs(direc[j]) > 1e-6)
+        a_lo, a_hi = 0.0, float(amax)
+        pose = lambda a: np.concatenate([np.clip(q0[:nh] + a * direc, lo, hi), q0[nh:]])
+        if d0 <= -depth:
+            continue
+        if finger_dist(pose(a_hi), geoms) > -depth:      # the joint limits stop the finger before it reaches the object
+            out[jids] = pose(a_hi)[jids]
+            continue
+        for _ in range(30):
+            mid = 0.5 * (a_lo + a_hi)
+            if finger_dist(pose(mid), geoms) > -depth:
+                a_lo = mid
+            else:
+                a_hi = mid
+        out[jids] = pose(a_hi)[jids]
+    return out
+
+
+_CLOSED_POSE: dict = {}
+
+
+def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_half_height: float | None = None, grasp: str = "kinematic") -> dict:
+    """``grasp``: "kinematic" = SURVEY.md's generator (the object rigidly follows the palm, the fingers keep swinging: few
+    hand-object contacts); "closed" = the benchmark's contact-rich variant: from frame 160 on the fingers hold the pose
+    `closed_grasp_pose` finds for the object's place under the palm (all five fingers touch it), blended in over frames
+    100-160 -- same palm motion, same object trajectory."""
     rng = np.random.default_rng(seed)
     A = model.arrays
     nh = model.scalar("hand_nq")
@@ -246,16 +349,23 @@ def synthetic_sequence(model: mjcf.CompiledModel, seed: int, T: int = 600, obj_h
     s = (s * s * (3 - 2 * s))[:, None]
     obj_p = (1 - s) * rest_p + s * grasp_p
     obj_q = _slerp(rest_q, grasp_q, s)
+    if grasp == "closed":
+        key = id(model)                                  # one pose per model: the object's place under the palm is the same in every sequence
+        if key not in _CLOSED_POSE:
+            _CLOSED_POSE[key] = closed_grasp_pose(model, np.concatenate([np.zeros(6), mid[6:]]), off, rel_q)
+        closed = _CLOSED_POSE[key]
+        wig = 0.02 * np.sin(2 * np.pi * f * t[:, None] + ph)                    # the fingers keep a small motion on the object
+        hand[:, 6:] = (1 - s) * hand[:, 6:] + s * np.clip(closed[None, 6:] + wig, lo[6:], hi[6:])
     return {"hand_pose_seq": hand, "obj_pose_seq": np.concatenate([obj_p, obj_q], 1)}
 
 
-def synthetic_sequences(model, n_seq: int = 17, T: int = 600, seed0: int = 0):
+def synthetic_sequences(model, n_seq: int = 17, T: int = 600, seed0: int = 0, grasp: str = "kinematic"):
     """17 sequences (16 train + 1 held out, agent_handmimic.py:344,444), seeds seed0..seed0+n_seq-1."""
-    return [synthetic_sequence(model, seed0 + i, T) for i in range(n_seq)]
+    return [synthetic_sequence(model, seed0 + i, T, grasp=grasp) for i in range(n_seq)]
 
 
-def synthetic_expert(model, n_seq: int = 17, T: int = 600, seed0: int = 0):
-    return [preprocess_seq(model, s) for s in synthetic_sequences(model, n_seq, T, seed0)]
+def synthetic_expert(model, n_seq: int = 17, T: int = 600, seed0: int = 0, grasp: str = "kinematic"):
+    return [preprocess_seq(model, s) for s in synthetic_sequences(model, n_seq, T, seed0, grasp)]
 
 
 def action_tape(n_steps: int, n_envs: int = 1, seed: int = 123, scale: float = 0.2):

@@ -297,3 +297,29 @@ def test_convex_mesh_models(oracle_lib, obj):
     loc = (pts - mp_) @ mR
     phi = (loc @ P[:, :3].T - P[:, 3]).max(1)
     assert abs((phi.min() - r) - cm[:, 0].min()) < 1e-6
+
+
+@pytest.mark.parametrize("obj", ["box", "banana"])
+def test_closed_grasp_motions_put_the_fingers_on_the_object(obj, oracle_lib):
+    """motions.synthetic_expert(grasp="closed") (bench.py --workload closed-grasp): the same palm and object trajectories as the
+    SURVEY generator, but from frame 160 on the fingers hold the pose closed_grasp_pose finds by kinematics alone -- checked
+    here with the oracle's collision stage: in the grasp phase several different fingers are in contact with the object
+    (the kinematic variant: the thumb only), before frame 100 the motions are identical."""
+    blob = open(mjcf.packaged_model_path(obj), "rb").read()
+    model = mjcf.CompiledModel.from_blob(blob)
+    closed = motions.synthetic_expert(model, 1, 320, grasp="closed")[0]
+    plain = motions.synthetic_expert(model, 1, 320)[0]
+    assert np.array_equal(closed["obj_pose_seq"], plain["obj_pose_seq"]) and np.array_equal(closed["hand_dof_seq"][:100], plain["hand_dof_seq"][:100])
+    assert np.array_equal(closed["hand_dof_seq"][:, :6], plain["hand_dof_seq"][:, :6])
+    A = model.arrays
+    assert (closed["hand_dof_seq"] >= A["jnt_range"][:26, 0] - 1e-12).all() and (closed["hand_dof_seq"] <= A["jnt_range"][:26, 1] + 1e-12).all()
+    o = oracle_lib.OracleEnv(blob)
+    hg0, hg1, og0 = model.scalar("hand_geom0"), model.scalar("hand_geom1"), model.scalar("obj_geom0")
+    finger_of = lambda g: (int(g) - 6) // 3 if g >= 6 else -1          # capsules 6..20: FF, MF, LF, RF, TH x 3 links
+
+    def fingers_touching(ex, f):
+        o.set("qpos", np.concatenate([ex["hand_dof_seq"][f], ex["obj_pose_seq"][f]])); o.set("qvel", np.zeros(32)); o.forward()
+        return {finger_of(c[13]) for c in o.contacts() if hg0 <= c[13] <= hg1 and c[14] >= og0 and c[13] >= 6}
+    for f in (200, 260, 319):
+        assert len(fingers_touching(closed, f)) >= 3, (f, fingers_touching(closed, f))
+        assert len(fingers_touching(closed, f)) > len(fingers_touching(plain, f))
