@@ -3,7 +3,7 @@ conservation checks SURVEY.md §8(c) lists, plus internal consistency of the sol
 import numpy as np
 import pytest
 
-from hoic_amd import mjcf
+from hoic_amd import mjcf, motions
 
 
 def _rand_state(model, rng, z=0.7):
