@@ -270,116 +270,7 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
   }
 }
 
-template <int BN, int EPI, bool PIPE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_kernel(GemmArgs a) {
-  typedef Cfg<BN> C;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * C::STAGE];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
-  // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of tiles so that the tiles
-  // sharing an A row panel are resident on one L2 at the same time
-  const int ntn = a.N / BN, ntiles = (a.M / 256) * ntn;
-  int g = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = g & 7, idx = g >> 3;
-    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int mt = g / ntn, nt_ = g % ntn;
-  const int m0 = mt * 256, n0 = nt_ * BN;
-  const int split = blockIdx.y;
-  const int kt0 = split * a.kt_per_split;
-  const int nkt = min(a.kt_per_split, a.K / 32 - kt0);
-  const size_t rowbytes = (size_t)a.K * 4;
-  const char* Ag = (const char*)a.A + (size_t)m0 * rowbytes + (size_t)kt0 * 128;
-  const char* Bg = (const char*)a.B + (size_t)n0 * rowbytes + (size_t)kt0 * 128;
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  const int mw = wm * (C::TM * 32), nw = wn * (C::TN * 32);      // wavefront tile origin inside the block tile
-
-  f32x16 acc[C::TM][C::TN];
-#pragma unroll
-  for (int i = 0; i < C::TM; i++)
-#pragma unroll
-    for (int j = 0; j < C::TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  // fragments of one K16 substep: the weight-side (n) and activation-side (m) hi / lo halves
-  struct Frags { h8 ah[C::TM], al[C::TM], bh[C::TN], bl[C::TN]; };
-  auto load_frags = [&](const char* stg, int s_, Frags& f) {
-#pragma unroll
-    for (int j = 0; j < C::TN; j++) read_frag(stg + 256 * 128, nw + j * 32 + l31, s_, hf, f.bh[j], f.bl[j]);
-#pragma unroll
-    for (int i = 0; i < C::TM; i++) read_frag(stg, mw + i * 32 + l31, s_, hf, f.ah[i], f.al[i]);
-  };
-  // D[n][m]: the weight-side fragment is the MFMA's A operand, so a lane ends up with 4 consecutive n of one m
-  auto mma = [&](const Frags& f) {
-#pragma unroll
-    for (int i = 0; i < C::TM; i++)
-#pragma unroll
-      for (int j = 0; j < C::TN; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
-      }
-  };
-  auto stage = [&](int t_) {
-    char* dst = smem + (t_ & 1) * C::STAGE;
-    stage_rows<256>(Ag + (size_t)t_ * 128, rowbytes, dst, wave, lane);
-    stage_rows<BN>(Bg + (size_t)t_ * 128, rowbytes, dst + 256 * 128, wave, lane);
-  };
-  if (PIPE) {
-    // Software pipeline over the K16 substeps: while the matrix core works on one substep's fragments, the LDS reads of
-    // the next one are in flight (two fragment sets in registers), and the stage hand-over (wait for the LDS-DMA of
-    // stage t+1, barrier, issue the DMA of stage t+2 into the buffer just released) sits between the two MFMA groups of
-    // a stage instead of in front of both.
-    if (nkt > 0) {
-      stage(0);
-      __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0) lgkmcnt(0)
-      __syncthreads();
-      if (nkt > 1) stage(1);
-      Frags F0, F1;
-      load_frags(smem, 0, F0);
-      __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0): F0 is in registers when the loop is entered
-      for (int t = 0; t + 1 < nkt; t++) {           // every stage but the last (peeled below: no branch inside the pipeline)
-        const char* cur = smem + (t & 1) * C::STAGE;
-        load_frags(cur, 1, F1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(F0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0): stage t+1 landed; F1 arrived, `cur` is read out
-        __syncthreads();
-        if (t + 2 < nkt) stage(t + 2);                                   // into `cur`, which nobody reads any more
-        load_frags(smem + ((t + 1) & 1) * C::STAGE, 0, F0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(F1);
-        __builtin_amdgcn_sched_barrier(0);
-        // the next substep's fragments had 24 MFMAs to arrive: settle the counter here, so that the loop header knows F0 is
-        // ready and the reads of F1 issued there stay in flight under the MFMAs on F0
-        __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0)
-      }
-      load_frags(smem + ((nkt - 1) & 1) * C::STAGE, 1, F1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(F0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(F1);
-    }
-  } else {
-    if (nkt > 0) stage(0);
-    for (int t = 0; t < nkt; t++) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's share of stage t has landed
-      __syncthreads();                                       // ... everyone's has, and nobody still reads the other buffer
-      if (t + 1 < nkt) stage(t + 1);
-      const char* cur = smem + (t & 1) * C::STAGE;
-#pragma unroll
-      for (int s_ = 0; s_ < 2; s_++) {
-        Frags f;
-        load_frags(cur, s_, f);
-        mma(f);
-      }
-    }
-  }
-
-  gemm_epilogue<EPI, C::TM, C::TN>(a, acc, m0 + mw, n0 + nw, split, lane);
-}
+// (the 8-wavefront two-stage kernel of the first f16x3 version was superseded by the 4-wavefront K16 kernels below and removed)
 
 // ---------------------------------------------------------------------------------------------- second tiling
 // 4 wavefronts, tile 256 x 128 (wavefront tile 128 x 64 as above), K stages of 16, THREE LDS buffers of 24 KB: two
@@ -531,100 +422,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // stage row is 1 KB (BN = 128: 512 B) and 16-byte chunk c of row r sits at chunk c ^ ((r & 1) | ((r & 2) << 2)), which
 // puts the 32 lanes of a transposing read on 32 distinct 8-byte slots of the 256-byte bank row.  Output: float32 slabs
 // [split][NA x NB], one dword per lane with 32 lanes on one 128-byte line.
-template <int ROWB> __device__ __forceinline__ void stage_rows_tn(const char* g, size_t ldg, char* lds, int wave, int lane) {
-  constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
-#pragma unroll
-  for (int i = 0; i < 32 * CPR / 512; i++) {
-    const int q = (i * 8 + wave) * 64 + lane, row = q / CPR, c = (q % CPR) ^ ((row & 1) | ((row & 2) << 2));
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)row * ldg + c * 16), LDS_PTR(lds + (i * 8 + wave) * 1024), 16, 0, 0);
-  }
-}
 typedef __fp16 hw4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-template <int ROWB> __device__ __forceinline__ void read_frag_tr(const char* tile, int cb, int s, int lane, h8& hi, h8& lo) {
-  const int g = lane >> 4, il = lane & 15;
-  const int n = cb + 16 * (g & 1) + 4 * (il & 3);               // first of the 4 columns this lane's address covers
-  const int ch = 2 * (n >> 3), ho = (n & 4) ? 8 : 0;
-  const int row0 = 16 * s + 8 * (g >> 1) + (il >> 2);
-  hw4 r[4];
-#pragma unroll
-  for (int p = 0; p < 2; p++) {
-    const int row = row0 + 4 * p, sw = (row & 1) | ((row & 2) << 2);
-    const char* base = tile + row * ROWB + ho;
-    r[p] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hw4*)LDS_PTR(base + ((ch ^ sw) << 4)));
-    r[2 + p] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hw4*)LDS_PTR(base + (((ch + 1) ^ sw) << 4)));
-  }
-  typedef unsigned long long u64;
-  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-  const u64x2 h = {__builtin_bit_cast(u64, r[0]), __builtin_bit_cast(u64, r[1])}, l = {__builtin_bit_cast(u64, r[2]), __builtin_bit_cast(u64, r[3])};
-  hi = __builtin_bit_cast(h8, h); lo = __builtin_bit_cast(h8, l);
-}
-template <int BN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_gemm_f16x3_tn_kernel(GemmArgs a) {
-  typedef Cfg<BN> C;                      // TM tiles along i (rows of C), TN along j
-  constexpr int RA = 256 * 4, RB = BN * 4, STG = 32 * (RA + RB);
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STG];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
-  const int ntn = a.N / BN;
-  // XCD-aware order: workgroups go to the XCDs round-robin in launch order, and every block of a sample range (split) reads
-  // the same rows of dZ and H -- so the SPLIT is the fast index: with a split count that is a multiple of 8 all tiles of a
-  // sample range run on one XCD and share its L2 (measured before, tile-major: L2 hit rate 38 %, every B panel fetched by 4 XCDs)
-  const int lin = blockIdx.x + gridDim.x * blockIdx.y, nsplit = gridDim.y;
-  const int split = lin % nsplit, g = lin / nsplit;
-  const int i0 = (g / ntn) * 256, j0 = (g % ntn) * BN;
-  const int kt0 = split * a.kt_per_split;
-  const int nkt = min(a.kt_per_split, a.K / 32 - kt0);
-  const size_t lda = (size_t)a.M * 4, ldb = (size_t)a.N * 4;      // bytes per sample row of the packed operands
-  const char* Ag = (const char*)a.A + (size_t)kt0 * 32 * lda + (size_t)i0 * 4;
-  const char* Bg = (const char*)a.B + (size_t)kt0 * 32 * ldb + (size_t)j0 * 4;
-  const int wi = (wave / C::WN) * (C::TM * 32), wj = (wave % C::WN) * (C::TN * 32);
-  f32x16 acc[C::TM][C::TN];
-#pragma unroll
-  for (int i = 0; i < C::TM; i++)
-#pragma unroll
-    for (int j = 0; j < C::TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  auto stage = [&](int t_) {
-    char* dst = smem + (t_ & 1) * STG;
-    stage_rows_tn<RA>(Ag + (size_t)t_ * 32 * lda, lda, dst, wave, lane);
-    stage_rows_tn<RB>(Bg + (size_t)t_ * 32 * ldb, ldb, dst + 32 * RA, wave, lane);
-  };
-  if (nkt > 0) stage(0);
-  for (int t = 0; t < nkt; t++) {
-    __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
-    __syncthreads();
-    if (t + 1 < nkt) stage(t + 1);
-    const char* At = smem + (t & 1) * STG;
-    const char* Bt = At + 32 * RA;
-#pragma unroll
-    for (int s_ = 0; s_ < 2; s_++) {
-      h8 ah[C::TM], al[C::TM], bh[C::TN], bl[C::TN];
-#pragma unroll
-      for (int j = 0; j < C::TN; j++) read_frag_tr<RB>(Bt, wj + 32 * j, s_, lane, bh[j], bl[j]);
-#pragma unroll
-      for (int i = 0; i < C::TM; i++) read_frag_tr<RA>(At, wi + 32 * i, s_, lane, ah[i], al[i]);
-#pragma unroll
-      for (int i = 0; i < C::TM; i++)
-#pragma unroll
-        for (int j = 0; j < C::TN; j++) {       // D[i][j]: lane = column j, registers = rows i
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  }
-  const int ea = a.exps ? a.exps[a.ea] : 0, eb = a.exps ? a.exps[a.eb] : 0;
-  const float alpha = ldexpf(a.extra_scale, -(ea + eb));
-  float* Cp = a.C + (size_t)split * a.c_split_stride;
-#pragma unroll
-  for (int i = 0; i < C::TM; i++)
-#pragma unroll
-    for (int j = 0; j < C::TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        Cp[(size_t)(i0 + wi + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf) * a.N + j0 + wj + 32 * j + l31] = alpha * acc[i][j][r];
-}
-
+// (its 8-wavefront row-major predecessor hoic_gemm_f16x3_tn_kernel: removed, superseded by the kernel below)
 // The same product on the 4-wavefront main loop (K16_MAINLOOP above): tile 256 (i) x 128 (j), stages of 16 samples (A part
 // 16 rows x 1 KB, B part 16 rows x 512 B = the 24 KB of the other kernel's stage), three LDS buffers, two workgroups per CU,
 // every DMA piece one contiguous 1 KB row (A) or two 512-byte rows (B).  Transposing reads: with the stage's swizzle
@@ -955,25 +754,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void hoic
 }
 
 // ---------------------------------------------------------------------------------------------- C-ABI
-// 0: plain two-substep loop, 1: software-pipelined 8-wavefront kernel (256 x 256 | 128 tiles, one workgroup per CU),
-// 2: the 4-wavefront 256 x 128 K16 kernel, two workgroups per CU (measurement aid; the default is the fastest measured)
-//    3: mode 2 with the accumulators in D[m][n] orientation for the forward / data-gradient epilogues (every store a
-//       full line; needs the transposed outputs switched off, i.e. the row-major weight-gradient kernel hoic_mlp_gemm_tn)
+// 2: the 4-wavefront 256 x 128 K16 kernel, two workgroups per CU, accumulators in D[n][m] orientation: forward / data-gradient
+//    epilogues also write transposed copies and the weight gradients are EPI_F32 products of those (kept as the second,
+//    independently laid out form the tests compare the default against);
+// 3 (default): the accumulators in D[m][n] orientation for the forward / data-gradient epilogues (every store a full line;
+//    no transposed outputs: the weight gradients come from the row-major kernel hoic_mlp_gemm_tn)
 static int g_gemm_pipeline = 3;
-extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return HOIC_OK; }
+extern "C" int32_t hoic_mlp_set_pipeline(int32_t mode) { g_gemm_pipeline = mode < 3 ? 2 : 3; return HOIC_OK; }
 
 template <int BN, int EPI> static int32_t launch_gemm(const GemmArgs& a, int splits, hipStream_t st) {
-  const int ntiles = (a.M / 256) * (a.N / BN);
-  if (g_gemm_pipeline >= 2) {
-    if (g_gemm_pipeline == 3 && EPI != EPI_F32 && !a.PT)
-      hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI, true>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI, false>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
-    MCHK(hipGetLastError());
-    return HOIC_OK;
-  }
-  if (g_gemm_pipeline) hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI, true>), dim3(ntiles, splits), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((hoic_gemm_f16x3_kernel<BN, EPI, false>), dim3(ntiles, splits), dim3(512), 0, st, a);
+  if (g_gemm_pipeline == 3 && EPI != EPI_F32 && !a.PT)
+    hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI, true>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((hoic_gemm_f16x3_k16_kernel<EPI, false>), dim3((a.M / 256) * (a.N / 128), splits), dim3(256), 0, st, a);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }
@@ -1022,9 +815,7 @@ extern "C" int32_t hoic_mlp_gemm_tn(int32_t M, int32_t N, int32_t K, const void*
   a.kt_per_split = (K / 32 + splits - 1) / splits;
   a.exps = d_exps; a.ea = slot_a; a.eb = slot_b; a.extra_scale = extra_scale; a.C = d_C; a.c_split_stride = (long long)M * N;
   hipStream_t st = (hipStream_t)stream;
-  if (g_gemm_pipeline == 3) hipLaunchKernelGGL(hoic_gemm_f16x3_tn16_kernel, dim3((M / 256) * (N / 128), splits), dim3(256), 0, st, a);
-  else if ((N % 256) == 0) hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<256>), dim3((M / 256) * (N / 256), splits), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((hoic_gemm_f16x3_tn_kernel<128>), dim3((M / 256) * (N / 128), splits), dim3(512), 0, st, a);
+  hipLaunchKernelGGL(hoic_gemm_f16x3_tn16_kernel, dim3((M / 256) * (N / 128), splits), dim3(256), 0, st, a);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

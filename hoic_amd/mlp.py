@@ -90,10 +90,11 @@ GEMM_MODE = 3      # set by kernels() from HOIC_GEMM_MODE when given
 
 
 def set_pipeline(mode: int):
-    """GEMM kernel variant (A/B measurements): 0 plain loop, 1 software-pipelined 8-wavefront kernel, 2 the 4-wavefront K16
-    kernel with two workgroups per CU, 3 (default) = 2 with D[m][n] accumulators: forward / data-gradient epilogues store
-    full lines and write no transposed copies, the weight gradients come from the row-major kernel (hoic_mlp_gemm_tn).
-    HOIC_GEMM_MODE overrides the default."""
+    """GEMM kernel form: 3 (default) = accumulators in D[m][n] orientation, forward / data-gradient epilogues store full lines
+    and write no transposed copies, the weight gradients come from the row-major kernel (hoic_mlp_gemm_tn); 2 = the same
+    4-wavefront K16 main loop in the other orientation with transposed copies (the independently laid out form the tests
+    compare against).  HOIC_GEMM_MODE overrides the default."""
+    mode = 3 if int(mode) >= 3 else 2
     global GEMM_MODE
     GEMM_MODE = int(mode)
     kernels().L.hoic_mlp_set_pipeline(int(mode))
@@ -109,7 +110,7 @@ def kernels():
         import os
         global GEMM_MODE
         if os.environ.get("HOIC_GEMM_MODE"):
-            GEMM_MODE = int(os.environ["HOIC_GEMM_MODE"])
+            GEMM_MODE = 3 if int(os.environ["HOIC_GEMM_MODE"]) >= 3 else 2
         _K.L.hoic_mlp_set_pipeline(GEMM_MODE)
     return _K
 

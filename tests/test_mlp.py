@@ -186,12 +186,12 @@ def _nets(hidden, seed=0):
 
 
 @gpu
-@pytest.mark.parametrize("mode", [3, 2, 1])
+@pytest.mark.parametrize("mode", [3, 2])
 def test_split_mlp_forward_backward_matches_autograd(mode):
     """SplitMLP.forward / backward against torch autograd in float64 on the same network and batch: activations to 2e-6,
     every parameter gradient to 2e-6 of its largest entry; the batch is not a multiple of the tile (padding path).
     Mode 3 = the default layout (row-major operands everywhere, D[m][n] epilogues, transposing-read weight gradients),
-    modes 2 / 1 = the layouts with transposed copies (K16 and 8-wavefront kernels)."""
+    mode 2 = the layout with transposed copies (same K16 main loop, the other accumulator orientation)."""
     import copy
     M.set_pipeline(mode)
     hidden = (512, 256, 256)

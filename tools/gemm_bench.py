@@ -41,7 +41,7 @@ def main():
                     "time than with random data = the kernel runs against the power limit, not against its schedule)")
     ap.add_argument("--ops", default=None, help="comma list of the ops to time (default all)")
     ap.add_argument("--dims", default="640x2048,2048x1024,1024x512", help="KxN of the layers to time (multiples of 256)")
-    ap.add_argument("--pipeline", type=int, default=1, help="0: plain main loop, 1: software-pipelined (default)")
+    ap.add_argument("--pipeline", type=int, default=3, help="3: the shipped form (D[m][n] epilogues, row-major weight gradients); 2: transposed-copy form")
     args = ap.parse_args()
     import torch
     from hoic_amd import mlp as M
