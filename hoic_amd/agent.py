@@ -623,7 +623,12 @@ class AgentHandMimic:
             # the statistics are those of the same state distribution; one fused launch instead of a gather + ~30 kernels)
             if frozen:
                 RAW.append(obs.clone())
-            state = self.running_state(obs, update=not frozen).to(dt)
+                if float(self.running_state.n) == 0:        # nothing seen yet: identity statistics (mean 0, std 1), as a sampler
+                    state = torch.clamp(obs, -5.0, 5.0).to(dt)      # that ships (0, 1) to its workers before the first batch does
+                else:
+                    state = self.running_state(obs, update=False).to(dt)
+            else:
+                state = self.running_state(obs).to(dt)
             action = self.policy_net.select_action(state)
             nseq, nstart = self._draw_episodes(N)
             self.env.step(action, nseq, nstart)
