@@ -543,7 +543,11 @@ class AgentHandMimic:
             main = torch.cuda.current_stream(dev)
             for st_ in self._streams:
                 st_.wait_stream(main)
-        zf_event = None
+        # The observation filter of a pipelined rollout: every env range updates its own fork of the filter with its own
+        # observations (the reference's sampler threads each run their own copy, agent.py:64-120) and the forks are merged
+        # after the rollout -- the same final statistics as one shared filter, and no dependency between the ranges'
+        # chains (with a shared filter every range's update waited for the previous range's: a convoy).
+        forks = [self.running_state.fork() for _ in groups] if use_streams else None
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
         async_reward = direct and self.async_reward
@@ -555,11 +559,7 @@ class AgentHandMimic:
                 sl = slice(first, first + count)
                 ctx = torch.cuda.stream(self._streams[gi]) if use_streams else contextlib.nullcontext()
                 with ctx:
-                    if use_streams and zf_event is not None:
-                        self._streams[gi].wait_event(zf_event)
-                    state = self.running_state(obs[sl], out=states[t, sl] if direct else None)
-                    if use_streams:
-                        zf_event = torch.cuda.Event(); zf_event.record(self._streams[gi])
+                    state = (forks[gi] if use_streams else self.running_state)(obs[sl], out=states[t, sl] if direct else None)
                     if state.data_ptr() != states[t, sl].data_ptr():
                         states[t, sl] = state
                     if direct:
@@ -578,6 +578,7 @@ class AgentHandMimic:
         if use_streams:
             for st_ in self._streams:
                 main.wait_stream(st_)
+            self.running_state.absorb(forks)
         if async_reward:
             self.env.sim.set_async_reward(False)        # the main stream waits for every outstanding reward part
         done_all = flags_all[:, :, 2] != 0

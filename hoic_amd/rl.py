@@ -249,6 +249,32 @@ class BatchZFilter:
         self.mean = m0 + delta * nb / tot
         self.n = tot
 
+    def fork(self):
+        """A copy that is updated on its own (one per env range of a pipelined rollout: like the reference's sampler
+        threads, each of which runs its own copy of the filter on its own observations, agent.py:64-120); ``absorb``
+        brings what the forks saw back."""
+        f = BatchZFilter(self.dim, clip=self.clip, device=self._st.device)
+        f._st.copy_(self._st)
+        return f
+
+    def absorb(self, forks):
+        """Merge what every fork pushed since it was forked from THIS (since then unchanged) filter: afterwards this filter
+        holds the statistics of pushing all those rows here (Chan merges of the forks' increments; float64)."""
+        n0, m0, S0 = self.n.clone(), self.mean.clone(), self.S.clone()
+        one = torch.ones((), dtype=torch.float64, device=self._st.device)
+        for f in forks:
+            nb = f.n - n0
+            safe = torch.clamp(nb, min=1.0)
+            mb = (f.n * f.mean - n0 * m0) / safe
+            Sb = torch.clamp(f.S - S0 - (mb - m0) ** 2 * n0 * nb / torch.clamp(f.n, min=1.0), min=0.0)
+            n1, m1, S1 = self.n.clone(), self.mean.clone(), self.S.clone()
+            tot = n1 + nb
+            delta = mb - m1
+            w = torch.where(nb > 0, one, 0 * one)                      # a fork that saw nothing changes nothing
+            self.S = S1 + w * (Sb + delta * delta * n1 * nb / torch.clamp(tot, min=1.0))
+            self.mean = m1 + w * delta * nb / torch.clamp(tot, min=1.0)
+            self.n = tot
+
     def _device_path(self, x):
         return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.dim
 

@@ -352,3 +352,26 @@ def test_packaged_models_collide_against_the_full_hulls():
         m64 = mjcf.compile_model("/root/reference/assets/hand_model/spheremesh/sphere_mesh_hand_add_geom.xml",
                                  "/root/reference/assets/SingleDepth/bottle_light.xml", max_mesh_verts=64)
         assert 0.5e-3 < m64.arrays["mesh_hull_error"][:2].max() < 2e-3     # a 64-vertex budget (round 1) is off by more than 0.5 mm
+
+
+def test_filter_forks_merge_to_the_shared_filter():
+    """BatchZFilter.fork / absorb (one fork per env range of the pipelined rollout, merged after it): the merged statistics are
+    those of pushing every row into one filter (float64 rounding), in any interleaving; a fork that saw nothing changes nothing;
+    rows are normalised by a fork with the statistics of the fork point plus the fork's own rows."""
+    from hoic_amd.rl import BatchZFilter
+    g = torch.Generator().manual_seed(3)
+    shared, one = BatchZFilter(9), BatchZFilter(9)
+    x0 = torch.randn(64, 9, generator=g) * 3 + 1
+    shared(x0); one(x0)
+    f = [shared.fork() for _ in range(3)]
+    xs = [torch.randn(40, 9, generator=g) * (1 + i) - i for i in range(6)]
+    for i, x in enumerate(xs):
+        y = f[i % 2](x); one(x)
+        ref = BatchZFilter(9); ref(x0)
+        for j in range(i % 2, i + 1, 2):
+            ref.push(xs[j])
+        torch.testing.assert_close(y, ref(x, update=False), rtol=0, atol=1e-12)
+    shared.absorb(f)
+    assert float(shared.n) == float(one.n) == 64 + 240
+    torch.testing.assert_close(shared.mean, one.mean, rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(shared.S, one.S, rtol=1e-12, atol=1e-12)
