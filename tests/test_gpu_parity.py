@@ -1096,21 +1096,26 @@ def test_train_script_runs_two_iterations(tmp_path):
 def test_reward_curve_band_after_ten_iterations(box_model):
     """North-star clause "reward-curve parity to the CPU reference at equal step count", as far as it can be asserted in a
     test: 10 PPO iterations from the config's initial weights, deterministic reward per step of all 17 sequences.
-    profiles/r02_reward_curve.json (tools/reward_curve.py, 5 seeds x 100 iterations per arm on this hardware) holds the
-    bands; at iteration 10 the reference-shaped CPU sampler (float64 oracle, whole episodes) gives 0.752 +- 0.002.
-      * the HIP simulator under the same whole-episode sampler (sample_mode='episodes') must land in that band;
+    profiles/r02_reward_curve.json and profiles/r03_reward_curve_filter_*.json (tools/reward_curve.py, 5 seeds x 100 iterations
+    per arm on this hardware) hold the bands.  At iteration 10 the reference-shaped CPU sampler (float64 oracle, whole
+    episodes, 64 sampler threads) gives 0.7502 +- 0.0014; the HIP simulator under the same sampler AND the same handling of
+    the observation filter (statistics shipped once per iteration: filter_mode='frozen') gives 0.7510 +- 0.0007 and stays
+    within 0.001 of the CPU curve to iteration 75 -- the round-2 offset of the default (online) filter, 0.004-0.005 from
+    iteration 30 on, is the filter's handling, not the simulator.
+      * whole-episode sampler, CPU-arm filter handling: within 0.004 of the CPU value (mean of two seeds: 2 sigma of both arms);
+      * whole-episode sampler, online filter (the product default): the same at iteration 10 (the curves part later);
       * the default fixed-horizon sampler is a different estimator (13-step windows, value bootstrap): it trails over
         the first ~60 iterations (0.725 +- 0.002 here) and leads after ~75; its known offset is bounded here."""
     from hoic_amd.agent import AgentHandMimic
     from hoic_amd.config import Config
     ex = motions.synthetic_expert(box_model, 17, 600)
     res = {}
-    for mode, n_envs in (("episodes", 32), ("fixed", 4096)):
+    for name, mode, n_envs, fm in (("episodes_frozen", "episodes", 64, "frozen"), ("episodes", "episodes", 64, "online"), ("fixed", "fixed", 4096, "online")):
         vals = []
         for seed in (1, 2):
             cfg = Config("box_future5_light_add_geom"); cfg.seed = seed
             torch.manual_seed(seed)
-            agent = AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode)
+            agent = AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode, filter_mode=fm)
             for it in range(10):
                 agent.optimize_policy(it, save_model=False)
             cfg.update_adaptive_params(9)
@@ -1118,7 +1123,8 @@ def test_reward_curve_band_after_ten_iterations(box_model):
             vals.append(ev["reward_per_step"])
             assert ev["mean_percent"] > 0.9
             agent.env.close(); agent._eval_env.close()
-        res[mode] = float(np.mean(vals))
+        res[name] = float(np.mean(vals))
     print("deterministic reward per step after 10 iterations:", res)
-    assert abs(res["episodes"] - 0.752) < 0.006, res
+    assert abs(res["episodes_frozen"] - 0.7502) < 0.004, res
+    assert abs(res["episodes"] - 0.7502) < 0.005, res
     assert -0.04 < res["fixed"] - res["episodes"] < 0.005, res
