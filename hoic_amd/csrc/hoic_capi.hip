@@ -435,7 +435,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // Longest-first dispatch by the measured duration of the previous pass shortens that tail when durations persist from
 // step to step: a counting sort on 1024 duration bins, one workgroup per kernel (blockIdx 0: substep order, 1:
 // post-step order).  The order only changes which CU runs an env, never a result.
-#define ORDER_NT 1024
+// (256 bins / threads: 2 KB of LDS, so the workgroup fits beside the eight substep workgroups of a CU instead of waiting for one
+//  of their slots -- inside the rollout the 1024-bin version took 51 us per call, most of it waiting)
+#define ORDER_NT 256
 // (first, count): the env range to order (a rollout range or the whole batch); order[first + k] = k-th longest env of the range
 __global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __restrict__ cost_all, int* __restrict__ order_all, int n_all, int first, int n) {
   __shared__ unsigned hist[ORDER_NT], scan[ORDER_NT];
@@ -603,7 +605,8 @@ struct hoic_sim {
   bool has_expert = false;
   // split post-step (hoic_set_async_reward): per env range a side stream for the reward part, the record buffer of the next
   // step and the events "reward part of the step that used buffer b has finished"
-  struct AsyncRange { int first = 0, count = 0, next_buf = 0; hipStream_t side = nullptr; hipEvent_t sub_done = nullptr, rew_done[2] = {nullptr, nullptr}; bool pending[2] = {false, false}; };
+  struct AsyncRange { int first = 0, count = 0, next_buf = 0; hipStream_t side = nullptr; hipEvent_t sub_done = nullptr, ord_done = nullptr, rew_done[2] = {nullptr, nullptr};
+                      bool pending[2] = {false, false}; bool order_ready = false; };
   bool async_reward = false;
   std::vector<AsyncRange> ranges;
   int expert_reserve = 0, expert_cap = 0;   // streaming: room for more frames behind the last sequence
@@ -958,6 +961,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   for (auto& r : s->ranges) {
     if (r.side) { hipStreamSynchronize(r.side); hipStreamDestroy(r.side); }
     if (r.sub_done) hipEventDestroy(r.sub_done);
+    if (r.ord_done) hipEventDestroy(r.ord_done);
     for (int b = 0; b < 2; b++) if (r.rew_done[b]) hipEventDestroy(r.rew_done[b]);
   }
   delete s;
@@ -1096,8 +1100,11 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   // duration; the post-step order only exists for whole-batch launches of the default form
   const int use_order = s->reorder ? 1 : 0;
   const bool whole = first == 0 && count == s->n_envs;
-  if (use_order) hipLaunchKernelGGL(hoic_order_kernel, dim3(whole ? 2 : 1), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs, first, count);
-  if (s->async_reward && !s->fused) {
+  const bool split = s->async_reward && !s->fused;
+  // (split form: the order of a range's next launch is made on the side stream right behind the substeps that measured the
+  //  durations, off the caller's chain; see below)
+  if (use_order && !split) hipLaunchKernelGGL(hoic_order_kernel, dim3(whole ? 2 : 1), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs, first, count);
+  if (split) {
     // Split form: termination, reset and observation at the end of the substep kernel (what the caller's next policy forward
     // needs), the reward part (contact classification, residual-force QP, reward) on the range's side stream from the
     // hand-over record.  The record buffers alternate, so the reward part of step t only has to finish before the
@@ -1110,16 +1117,23 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
       s->ranges.emplace_back(); r = &s->ranges.back(); r->first = first; r->count = count;
       HIPCHK(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&r->sub_done, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&r->ord_done, hipEventDisableTiming));
       for (int b = 0; b < 2; b++) HIPCHK(hipEventCreateWithFlags(&r->rew_done[b], hipEventDisableTiming));
     }
     const int buf = r->next_buf; r->next_buf ^= 1;
     if (r->pending[buf]) HIPCHK(hipStreamWaitEvent(st, r->rew_done[buf], 0));      // the reward part of step t - 2 read this record
+    const int have_order = (use_order && r->order_ready) ? 1 : 0;
+    if (have_order) HIPCHK(hipStreamWaitEvent(st, r->ord_done, 0));                // this range's launch order (made behind its previous step)
     if (e) hipEventRecord(e[0], st);
-    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, have_order,
                        s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs, buf);
     if (e) hipEventRecord(e[1], st);
     HIPCHK(hipEventRecord(r->sub_done, st));
     HIPCHK(hipStreamWaitEvent(r->side, r->sub_done, 0));
+    if (use_order) {
+      hipLaunchKernelGGL(hoic_order_kernel, dim3(1), dim3(ORDER_NT), 0, r->side, s->st.cost, s->st.order, s->n_envs, first, count);
+      HIPCHK(hipEventRecord(r->ord_done, r->side)); r->order_ready = true;
+    }
     hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
                        d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
     HIPCHK(hipEventRecord(r->rew_done[buf], r->side)); r->pending[buf] = true;
