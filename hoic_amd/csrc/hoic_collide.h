@@ -359,6 +359,9 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // HOIC_MESH_STREAM=1), so both forms produce bit-identical contacts (tests/test_gpu_parity.py
 // test_mesh_pruning_changes_no_contact); the win is memory traffic: a query on the banana's largest hull reads ~4 KB
 // instead of 29 KB of plane rows through the CU's vector L1, which is what bounded the mesh configurations.
+#ifndef HULL_STREAM_BELOW
+#define HULL_STREAM_BELOW 512
+#endif
 struct HullRef { GPTR(const f4v) pl; GPTR(const f4v) vv; GPTR(const f4v) vrun; GPTR(const f4v) frun; int np, nv, nvr, nfr, prune; float lo[3], hi[3]; };
 HD HullRef hull_ref(const DevModel& m, int mesh) {
   HullRef h;
@@ -383,7 +386,7 @@ HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
   const int lane = threadIdx.x;
   if (h.np <= 0) { pl[0] = pl[1] = pl[2] = pl[3] = 0.f; return -1e30f; }      // a mesh without face planes (wave-uniform): no face, nothing to index
   float bv = -1e30f; int bi = 0x00ffffff;
-  if (!h.prune) {
+  if (!h.prune || h.np <= HULL_STREAM_BELOW) {          // (small hulls: a handful of streaming passes cost less than bounds + visits)
     for (int t = lane; t < h.np; t += NT) {          // ascending index per lane: '>' keeps the lane's first maximum
       const float v = hull_plane_val(h.pl[t], x, y, z);
       if (v > bv) { bv = v; bi = t; }
