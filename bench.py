@@ -56,7 +56,7 @@ def traffic_from_profile(envs, obj):
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/sim_only.py, FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950).  Counters cannot be read inside this process, so the number is only reported when a
     profile was taken at the same env count and object; otherwise null."""
-    p = _latest_profile("*_hbm_traffic.json", lambda d: d.get("envs") == envs and d.get("kernel") == "hoic_substep_kernel" and d.get("obj", "box") == obj)
+    p = _latest_profile("*_hbm_traffic*.json", lambda d: d.get("envs") == envs and d.get("kernel") == "hoic_substep_kernel" and d.get("obj", "box") == obj)
     return None if p is None else p[1]["traffic_bytes_per_launch"]
 
 
