@@ -1031,47 +1031,55 @@ extern "C" int32_t hoic_mlp_forward_tiled(int32_t M, int32_t N, int32_t K, const
 // the Gaussian sample (uhc/khrylib/rl/core/policy_gaussian.py:27-33, distributions.py: mean + std * N(0, 1)) in ONE launch
 // that needs no LDS, so that it runs beside the simulator's substep workgroups like hoic_fwd_tiled_kernel does (the library
 // GEMM of this 2048 x 512 x 32 product queues for a CU's LDS behind them, and the sample was two more launches).
-// float32 throughout: v_mfma_f32_32x32x2_f32 is an exact float32 multiply-add chain.  One wavefront = 32 rows; lane (r, half)
-// loads four consecutive k of row r (h) and of output n = r (W) per 8-k block -- half 0 the first four, half 1 the last four --
-// and MFMA step s contracts element s of both halves, so operands are 16-byte loads and both matrices are read as stored.
+// float32 throughout: the f32 MFMA is an exact float32 multiply-add chain.
 __global__ __launch_bounds__(64) void hoic_head_kernel(int M, int K, int N, const float* __restrict__ h, long long ldh, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const float* __restrict__ stdv, const float* __restrict__ eps,
                                                         long long lde, float* __restrict__ out, long long ldo) {
-  const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5, row0 = blockIdx.x * 32;
-  const float* hp = h + (long long)(row0 + r) * ldh + 4 * hh;
-  const float* wp = W + (long long)(r < N ? r : 0) * K + 4 * hh;
-  const float wmask = r < N ? 1.f : 0.f;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  // One wavefront = 16 rows x 32 outputs as two v_mfma_f32_16x16x4_f32 tiles (two independent accumulators: the MFMA chain of
+  // one tile runs in the shadow of the other's).  Lane (r = lane & 15, g = lane >> 4) loads four consecutive k of row r (h)
+  // and of outputs n = r, 16 + r (W) per 16-k block -- group g the g-th four -- and MFMA step s contracts element s of all four
+  // groups, so every operand is a 16-byte load and both matrices are read as stored.
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4, row0 = blockIdx.x * 16;
+  const float* hp = h + (long long)(row0 + r) * ldh + 4 * g;
+  const float* w0 = W + (long long)(r < N ? r : 0) * K + 4 * g;
+  const float* w1 = W + (long long)(16 + r < N ? 16 + r : 0) * K + 4 * g;
+  const float m0 = r < N ? 1.f : 0.f, m1 = 16 + r < N ? 1.f : 0.f;
+  f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-  for (int kb = 0; kb < K; kb += 8) {
+  for (int kb = 0; kb < K; kb += 16) {
     const f32x4 a = *(const f32x4*)(hp + kb);
-    f32x4 b = *(const f32x4*)(wp + kb);
-    b = b * wmask;
+    const f32x4 b0 = *(const f32x4*)(w0 + kb) * m0, b1 = *(const f32x4*)(w1 + kb) * m1;
 #pragma unroll
-    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < 4; s++) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
+    }
   }
-  // D[i][j]: lane (j + 32 * half) holds rows i = (reg & 3) + 8 * (reg >> 2) + 4 * half of output column j
-  if (r < N) {
-    const float bj = bias ? bias[r] : 0.f, sj = (eps && stdv) ? stdv[r] : 0.f;
+  // D[i][j] of a 16 x 16 tile: lane (j + 16 g) holds rows i = 4 g + reg of output column j
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      const int i = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+  for (int t = 0; t < 2; t++) {
+    const int n = 16 * t + r;
+    if (n >= N) continue;
+    const f32x4v& acc = t ? acc1 : acc0;
+    const float bj = bias ? bias[n] : 0.f, sj = (eps && stdv) ? stdv[n] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int i = row0 + 4 * g + reg;
       if (i < M) {
         float v = acc[reg] + bj;
-        if (eps) v = fmaf(sj, eps[(long long)i * lde + r], v);
-        out[(long long)i * ldo + r] = v;
+        if (eps) v = fmaf(sj, eps[(long long)i * lde + n], v);
+        out[(long long)i * ldo + n] = v;
       }
     }
   }
 }
 extern "C" int32_t hoic_mlp_head(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_bias,
                                  const float* d_std, const float* d_eps, int64_t lde, float* d_out, int64_t ldo, void* stream) {
-  if (M <= 0 || (M & 31) || K <= 0 || (K & 7) || N <= 0 || N > 32 || !d_h || !d_W || !d_out || (ldh & 3) || ((size_t)d_h & 15) || ((size_t)d_W & 15)) {
-    hoic_set_error("hoic_mlp_head: M % 32 == 0, K % 8 == 0, N <= 32, 16-byte aligned h / W with ldh % 4 == 0"); return HOIC_ERR_ARG;
+  if (M <= 0 || (M & 15) || K <= 0 || (K & 15) || N <= 0 || N > 32 || !d_h || !d_W || !d_out || (ldh & 3) || ((size_t)d_h & 15) || ((size_t)d_W & 15)) {
+    hoic_set_error("hoic_mlp_head: M % 16 == 0, K % 16 == 0, N <= 32, 16-byte aligned h / W with ldh % 4 == 0"); return HOIC_ERR_ARG;
   }
-  hipLaunchKernelGGL(hoic_head_kernel, dim3((unsigned)(M >> 5)), dim3(64), 0, (hipStream_t)stream, M, K, N, d_h, (long long)ldh, d_W, d_bias, d_std, d_eps,
+  hipLaunchKernelGGL(hoic_head_kernel, dim3((unsigned)(M >> 4)), dim3(64), 0, (hipStream_t)stream, M, K, N, d_h, (long long)ldh, d_W, d_bias, d_std, d_eps,
                      (long long)lde, d_out, (long long)ldo);
   MCHK(hipGetLastError());
   return HOIC_OK;

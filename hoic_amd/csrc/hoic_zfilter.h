@@ -64,11 +64,12 @@ __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_apply_kernel(const float* 
   }
   if (!y) return;
   const double var = cnt > 1.0 ? S / fmax(cnt - 1.0, 1.0) : mean * mean;       // zfilter.py:35
-  const double den = sqrt(var) + 1e-8;
+  const double rden = 1.0 / (sqrt(var) + 1e-8);      // one division per column; the rows multiply (float64: the float32 result sees no difference)
   const int r0 = chunk * ZF_ROWS, r1 = min(r0 + ZF_ROWS, n);
   const double lim = (double)clip;
+#pragma unroll 4
   for (int r = r0; r < r1; r++) {
-    const double v = ((double)x[(size_t)r * dim + col] - mean) / den;
+    const double v = ((double)x[(size_t)r * dim + col] - mean) * rden;
     y[(size_t)r * dim + col] = (float)fmin(fmax(v, -lim), lim);
   }
 }

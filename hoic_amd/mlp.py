@@ -433,10 +433,10 @@ class SplitMLP:
 
 def action_head(hidden, weight, bias, std=None, eps=None, out=None):
     """mean = hidden @ weight^T + bias, or the Gaussian sample mean + std * eps when ``eps`` is given, in one LDS-free float32
-    launch (hoic_mlp_head); hidden [M, K] float32 with M % 32 == 0, weight [N <= 32, K]."""
+    launch (hoic_mlp_head); hidden [M, K] float32 with M % 16 == 0 and K % 16 == 0, weight [N <= 32, K]."""
     M_, K_ = hidden.shape
     N_ = weight.shape[0]
-    assert hidden.dtype == torch.float32 and hidden.stride(1) == 1 and weight.is_contiguous() and M_ % 32 == 0 and K_ % 8 == 0 and N_ <= 32
+    assert hidden.dtype == torch.float32 and hidden.stride(1) == 1 and weight.is_contiguous() and M_ % 16 == 0 and K_ % 16 == 0 and N_ <= 32
     if out is None:
         out = torch.empty(M_, N_, dtype=torch.float32, device=hidden.device)
     assert out.stride(1) == 1 and (eps is None or (eps.stride(1) == 1 and eps.shape == (M_, N_)))

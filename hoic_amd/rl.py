@@ -59,7 +59,7 @@ class PolicyGaussian(nn.Module):
         of this batch made up front -- head and sample are then ONE LDS-free launch (hoic_mlp_head) instead of a library
         GEMM that queues for the CUs' LDS behind the simulator plus two elementwise kernels"""
         std = torch.exp(self.action_log_std) if std is None else std
-        if eps is not None and hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[0] % 32 == 0 and hidden.shape[1] % 8 == 0:
+        if eps is not None and hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[0] % 16 == 0 and hidden.shape[1] % 16 == 0:
             from .mlp import action_head
             return action_head(hidden, self.action_mean.weight.detach(), self.action_mean.bias.detach(), std, eps, out)
         if eps is not None:

@@ -257,8 +257,8 @@ int32_t hoic_mlp_forward_tiled(int32_t M, int32_t N, int32_t K, const void* d_X,
                                void* stream);
 /* hoic_mlp_head: d_out[m][n] = sum_k d_h[m][k] d_W[n][k] + d_bias[n] (+ d_std[n] * d_eps[m][n] when d_eps is given): the action
  * head on the policy body's output and the Gaussian sample in one LDS-free float32 launch (PolicyGaussian.forward /
- * select_action, uhc/khrylib/rl/core/policy_gaussian.py:27-33; mean + std * N(0, 1), distributions.py:11-13).  M % 32 ==
- * K % 8 == 0, N <= 32; row strides ldh / lde / ldo in floats; d_bias, d_std, d_eps may be NULL. */
+ * select_action, uhc/khrylib/rl/core/policy_gaussian.py:27-33; mean + std * N(0, 1), distributions.py:11-13).  M % 16 ==
+ * K % 16 == 0, N <= 32; row strides ldh / lde / ldo in floats; d_bias, d_std, d_eps may be NULL. */
 int32_t hoic_mlp_head(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_bias,
                       const float* d_std, const float* d_eps, int64_t lde, float* d_out, int64_t ldo, void* stream);
 int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
