@@ -59,7 +59,7 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   }
   if (tid < NV) w.fsmooth[tid] = fs;
   PT(20);
-  float a0 = dev_hsolve(m, w, M, 0.f, m.nv, false, fs); PT(8);     // unconstrained acceleration
+  float a0 = dev_hsolve<false>(m, w, M, 0.f, m.nv, fs); PT(8);     // unconstrained acceleration
   if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
   wsync();
   RowK rk;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void dev_euler(const DevModel& m, Work& w, const MReg
   const float h = m.timestep;
   const float rhs = (d < m.nv) ? (w.fsmooth[d] + w.fcon[d]) : 0.f;
   PT(20);
-  const float acc = dev_hsolve(m, w, M, h * w.k_damp[d], m.nv, false, rhs);
+  const float acc = dev_hsolve<false>(m, w, M, h * w.k_damp[d], m.nv, rhs);
   if (tid < NQP) w.qlag[tid] = w.qpos[tid];
   if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
   wsync();
@@ -802,6 +802,21 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     unsigned dm = 0;
     for (int e = 0; e < m.nv; e++) if (e != d && ((m.dof_amask[e] >> d) & 1u)) dm |= 1u << e;
     m.dof_dmask[d] = dm;
+  }
+  // The solver's elimination order (hoic_solver.h hs_factor) is built for the HOIC hand: palm dofs 0..5, five fingers of four
+  // dofs each (6 + 4 f .. 9 + 4 f) that hang on the palm and on nothing else, a free object on dofs 26..31.
+  {
+    bool ok = m.nv == 32 && m.hand_nv == 26;
+    for (int d = 0; ok && d < 32; d++) {
+      const unsigned rel = m.dof_amask[d] | m.dof_dmask[d];          // every dof this one shares a chain with
+      unsigned allowed;
+      if (d < 6) allowed = 0x03FFFFFFu;                               // palm: itself and all fingers
+      else if (d < 26) allowed = 0x3Fu | (0xFu << (6 + 4 * ((d - 6) / 4)));      // a finger: the palm and its own four
+      else allowed = 0xFC000000u;                                     // the object: only itself
+      if (rel & ~allowed) ok = false;
+      if (d >= 26 && m.dof_jtype[d] != HOIC_JNT_FREE) ok = false;
+    }
+    if (!ok) { set_err("model blob: the joint structure is not the hand (palm 6 + 5 x 4 finger dofs) + free object the solver's elimination order is built for"); return false; }
   }
   // constraint constants
   for (int i = 0; i < m.nv; i++) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
     rhs = -w.bias[d] - kp * err - kd * qv;
   }
   PT(20);
-  const float acc = dev_hsolve(m, w, M, kd * dt, n, false, rhs);
+  const float acc = dev_hsolve<false>(m, w, M, kd * dt, n, rhs);
   if (tid < NV) {
     float tq = 0.f;
     if (tid < n) {

@@ -36,51 +36,102 @@ HD float hs_pivot_ninv(float d_uniform, float& d_clamped) {
   d_clamped = __int_as_float(di);
   return -__builtin_amdgcn_rcpf(d_clamped);
 }
-// One pivot pair (J, J+1).  Rows J and J+1 of the running matrix sit in two registers of the same half-wave: one
+// One pivot pair (J, J+1), J even.  Rows J and J+1 of the running matrix sit in two registers of the same half-wave: one
 // permlane32_swap puts row J on the low lanes and row J+1 on the high lanes, a second one spreads each over both
 // halves.  nl = -L[.][J] doubles as the MFMA A operand, the forward-substitution multiplier and the value stored in
-// T.  No lane masks anywhere: entries of nl at lanes <= J are rounding residue and only touch entries of y that have
-// already been extracted (y_J goes to lane J of yv, the pivot d_J to lane J of dv).
-template <int J> struct HsFactor {
-  static HD void run(f32x16& acc, float& y, float& yv, float& dv, int hi, float* Tcol) {
-    constexpr int reg0 = (J & 3) + 4 * (J >> 3), reg1 = ((J + 1) & 3) + 4 * ((J + 1) >> 3), half = (J >> 2) & 1;
-    const u32x2v p = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[reg0]), __float_as_uint(acc[reg1]), false, false);
-    const unsigned q = half ? p.y : p.x;                      // low lanes: row J, high lanes: row J+1
-    const u32x2v sp = __builtin_amdgcn_permlane32_swap(q, q, false, false);
-    const float u0 = __uint_as_float(sp.x), r1 = __uint_as_float(sp.y);   // u0[c] = A[J][c] = L[c][J] d_J
-    float d0, d1;
-    const float ninv0 = hs_pivot_ninv(rl(u0, J), d0);
-    const float nl0 = u0 * ninv0;
-    const float u1 = fmaf(rl(nl0, J + 1), u0, r1);            // row J+1 after eliminating pivot J
-    const float ninv1 = hs_pivot_ninv(rl(u1, J + 1), d1);
-    const float nl1 = u1 * ninv1;
-    const float A = hi ? nl1 : nl0;
-    if (J < 30) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A, hi ? u1 : u0, acc, 0, 0, 0);
-    Tcol[J * LD] = A;                                         // T[J + hi][c] = -L[c][J + hi]
-    const float y0 = rl(y, J);
-    y = fmaf(nl0, y0, y);
-    const float y1 = rl(y, J + 1);
-    y = fmaf(nl1, y1, y);
-    hs_writelane<J>(yv, y0); hs_writelane<J + 1>(yv, y1);
-    hs_writelane<J>(dv, d0); hs_writelane<J + 1>(dv, d1);
-    HsFactor<J + 2>::run(acc, y, yv, dv, hi, Tcol);
+// T.  No lane masks anywhere: entries of nl at lanes of pivots eliminated earlier are rounding residue and only touch entries
+// of y that have already been extracted (y_J goes to lane J of yv, the pivot d_J to lane J of dv).
+// prep: everything but the MFMA; Aop / Bop are its operands.
+// ys: the running right-hand side the pair's own entries are read from -- the state at the start of the step (the pairs of a
+// step do not touch each other's entries, so reading the snapshot takes the pairs' updates of y off each other's chains)
+template <int J> HD void hs_pair_prep(const f32x16& acc, const float ys, float& y, float& yv, float& dv, int hi, float* Tcol, float& Aop, float& Bop) {
+  constexpr int reg0 = (J & 3) + 4 * (J >> 3), reg1 = ((J + 1) & 3) + 4 * ((J + 1) >> 3), half = (J >> 2) & 1;
+  const u32x2v p = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[reg0]), __float_as_uint(acc[reg1]), false, false);
+  const unsigned q = half ? p.y : p.x;                      // low lanes: row J, high lanes: row J+1
+  const u32x2v sp = __builtin_amdgcn_permlane32_swap(q, q, false, false);
+  const float u0 = __uint_as_float(sp.x), r1 = __uint_as_float(sp.y);   // u0[c] = A[J][c] = L[c][J] d_J
+  float d0, d1;
+  const float ninv0 = hs_pivot_ninv(rl(u0, J), d0);
+  const float nl0 = u0 * ninv0;
+  const float u1 = fmaf(rl(nl0, J + 1), u0, r1);            // row J+1 after eliminating pivot J
+  const float ninv1 = hs_pivot_ninv(rl(u1, J + 1), d1);
+  const float nl1 = u1 * ninv1;
+  Aop = hi ? nl1 : nl0; Bop = hi ? u1 : u0;
+  Tcol[J * LD] = Aop;                                       // T[J + hi][c] = -L[c][J + hi]
+  const float y0 = rl(ys, J);
+  const float y1 = rl(fmaf(nl0, y0, ys), J + 1);
+  y = fmaf(nl0, y0, y);
+  y = fmaf(nl1, y1, y);
+  hs_writelane<J>(yv, y0); hs_writelane<J + 1>(yv, y1);
+  hs_writelane<J>(dv, d0); hs_writelane<J + 1>(dv, d1);
+}
+// Elimination order.  The joint-space inertia of the HOIC models is sparse by its tree: the five fingers (4 dofs each, dofs
+// 6 + 4 f .. 9 + 4 f) couple only through the palm (dofs 0..5), the free object (26..31) couples to nothing -- and so is
+// every matrix the solves see as long as no contact row joins two of those groups (diagonal shifts, contacts of the object
+// with the table / floor).  Eliminating the fingers BEFORE the palm keeps that sparsity (no fill between fingers), so the
+// pairs of one step below never touch each other's rows: their rows are read from ONE state of the accumulator, their VALU
+// chains interleave and their rank-2 MFMAs issue back to back -- 5 dependent steps (6 + 6 + 2 + 1 + 1 MFMAs) instead of 16.
+// The same order is a valid LDL^T for any SPD matrix: when contact rows couple the groups (SER) every pair reads the
+// accumulator after the previous pair's MFMA.  build_model checks that the model has this structure.
+//   step:        0                      1                      2        3    4
+#define HS_STEPS(X) X(0, 8, 12, 16, 20, 24, 26) X(1, 6, 10, 14, 18, 22, 28)
+template <int J, bool LASTPAIR> HD void hs_pair_ser(f32x16& acc, float& y, float& yv, float& dv, int hi, float* Tcol) {
+  float A, B;
+  const float ys = y;
+  hs_pair_prep<J>(acc, ys, y, yv, dv, hi, Tcol, A, B);
+  if (!LASTPAIR) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, acc, 0, 0, 0);
+}
+template <int J0, int J1, int J2, int J3, int J4, int J5> HD void hs_step6_par(f32x16& acc, float& y, float& yv, float& dv, int hi, float* Tcol) {
+  float A0, B0, A1, B1, A2, B2, A3, B3, A4, B4, A5, B5;
+  const float ys = y;
+  hs_pair_prep<J0>(acc, ys, y, yv, dv, hi, Tcol, A0, B0); hs_pair_prep<J1>(acc, ys, y, yv, dv, hi, Tcol, A1, B1);
+  hs_pair_prep<J2>(acc, ys, y, yv, dv, hi, Tcol, A2, B2); hs_pair_prep<J3>(acc, ys, y, yv, dv, hi, Tcol, A3, B3);
+  hs_pair_prep<J4>(acc, ys, y, yv, dv, hi, Tcol, A4, B4); hs_pair_prep<J5>(acc, ys, y, yv, dv, hi, Tcol, A5, B5);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, B3, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A4, B4, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A5, B5, acc, 0, 0, 0);
+}
+template <bool PAR> HD void hs_factor(f32x16& acc, float& y, float& yv, float& dv, int hi, float* Tcol) {
+  if (PAR) {
+    hs_step6_par<8, 12, 16, 20, 24, 26>(acc, y, yv, dv, hi, Tcol);
+    hs_step6_par<6, 10, 14, 18, 22, 28>(acc, y, yv, dv, hi, Tcol);
+    {   // palm pair 0 and the object's last pair: independent of each other
+      float A0, B0, A1, B1;
+      const float ys = y;
+      hs_pair_prep<0>(acc, ys, y, yv, dv, hi, Tcol, A0, B0); hs_pair_prep<30>(acc, ys, y, yv, dv, hi, Tcol, A1, B1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc, 0, 0, 0);      // (the object's last pair needs no update: nothing is left below it)
+      (void)A1; (void)B1;
+    }
+  } else {
+    hs_pair_ser<8, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<12, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<16, false>(acc, y, yv, dv, hi, Tcol);
+    hs_pair_ser<20, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<24, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<26, false>(acc, y, yv, dv, hi, Tcol);
+    hs_pair_ser<6, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<10, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<14, false>(acc, y, yv, dv, hi, Tcol);
+    hs_pair_ser<18, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<22, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<28, false>(acc, y, yv, dv, hi, Tcol);
+    hs_pair_ser<0, false>(acc, y, yv, dv, hi, Tcol); hs_pair_ser<30, false>(acc, y, yv, dv, hi, Tcol);
   }
-};
-template <> struct HsFactor<32> { static HD void run(f32x16&, float&, float&, float&, int, float*) {} };
-// backward substitution, 16 columns of L in flight at a time; x_k goes to lane k of xv as soon as it is final
-template <int K> struct HsBack {
+  hs_pair_ser<2, false>(acc, y, yv, dv, hi, Tcol);
+  hs_pair_ser<4, true>(acc, y, yv, dv, hi, Tcol);
+}
+// elimination sequence of the single pivots (the order of HS above); the backward substitution runs through it in reverse
+__device__ constexpr int HS_SEQ[32] = {8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 26, 27, 6, 7, 10, 11, 14, 15, 18, 19, 22, 23, 28, 29, 0, 1, 30, 31, 2, 3, 4, 5};
+// backward substitution over HS_SEQ[P], P = 31 .. 0, sixteen columns of L in flight at a time (lc[i] = -L[HS_SEQ[16 BATCH + i]][col]);
+// x_k goes to lane k of xv as soon as it is final.  Residue of lc at columns eliminated AFTER k only touches entries that
+// are final already.
+template <int P, int BATCH> struct HsBack {
   static HD void run(const float (&lc)[16], float& x, float& xv) {
-    constexpr int kk = K, k = K & 15;
-    const float xk = rl(x, kk);
-    hs_writelane<kk>(xv, xk);
-    if constexpr (kk > 0) x = fmaf(lc[k], xk, x);
-    if constexpr ((K & 15) != 0) HsBack<K - 1>::run(lc, x, xv);
+    constexpr int k = HS_SEQ[P];
+    const float xk = rl(x, k);
+    hs_writelane<k>(xv, xk);
+    if constexpr (P > 0) x = fmaf(lc[P - 16 * BATCH], xk, x);
+    if constexpr (P > 16 * BATCH) HsBack<P - 1, BATCH>::run(lc, x, xv);
   }
 };
 
 // diag: per-lane diagonal increment of row/col (lane & 31); use_rows: add the active contact rows through the
 // MFMA; rhs: per-lane right-hand side (lane & 31).  Returns x[lane & 31] on the low half-wave lanes AND the high ones.
-__device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MReg& M, float dg, int nact, bool use_rows, float rhs) {
+template <bool ROWS>
+__device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MReg& M, float dg, int nact, float rhs) {
+  constexpr bool use_rows = ROWS;
   const int lane = opaque(threadIdx.x), col = lane & 31, hi = lane >> 5;
   f32x16 acc;
   // this lane holds the diagonal entry (col, col) in register dreg if its half-wave owns row col
@@ -94,11 +145,14 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
       if (r >= nact || col >= nact) acc[reg] = (r == col) ? 1.f : 0.f;
     }
   }
+  bool coupled = false;      // some contact joins two of the groups (fingers, palm, object): the pairs of a step are not independent
   if (use_rows) {
     float Sc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) Sc[i] = w.S[col][i];
+    const unsigned objmask = 0xFC000000u;       // dofs 26..31 (checked by build_model)
     for (int c = 0; c < w.ncon; c++) {
+      coupled = coupled || (((w.c_mpos[c] | w.c_mneg[c]) & ~objmask) != 0u);
       const int nr = w.c_nrow[c], r0 = w.c_row0[c];
       const float sg = (float)((w.c_mpos[c] >> col) & 1u) - (float)((w.c_mneg[c] >> col) & 1u);
       const float* fr = w.c_frame[c];
@@ -120,7 +174,8 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
   PT(15);
   float y = rhs, yv = 0.f, dv = 1.f;
   float* T = w.sc.T;
-  HsFactor<0>::run(acc, y, yv, dv, hi, T + hi * LD + col);
+  if (use_rows && coupled) hs_factor<false>(acc, y, yv, dv, hi, T + hi * LD + col);
+  else hs_factor<true>(acc, y, yv, dv, hi, T + hi * LD + col);
   PT(16);
   float x = yv * __builtin_amdgcn_rcpf(dv);       // D^-1 L^-1 rhs
   wsync();
@@ -128,11 +183,11 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
   {
     float lc[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + 16 + k];        // -L[16+k][col]
-    HsBack<31>::run(lc, x, xv);
+    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + HS_SEQ[16 + k]];        // -L[HS_SEQ[16+k]][col]
+    HsBack<31, 1>::run(lc, x, xv);
 #pragma unroll
-    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + k];
-    HsBack<15>::run(lc, x, xv);
+    for (int k = 0; k < 16; k++) lc[k] = T[col * LD + HS_SEQ[k]];
+    HsBack<15, 0>::run(lc, x, xv);
   }
   wsync();
   PT(18);
@@ -404,7 +459,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; break; }
     PT(20);
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
-    const float sd = dev_hsolve(m, w, M, ev.curv_f + ev.curv_l, m.nv, true, -g);
+    const float sd = dev_hsolve<true>(m, w, M, ev.curv_f + ev.curv_l, m.nv, -g);
     if (tid < NV) w.search[tid] = vd ? sd : 0.f;
     wsync();
     // line-search quantities
