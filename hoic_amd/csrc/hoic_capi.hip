@@ -65,8 +65,14 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   RowK rk;
   dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
   dev_solve(m, w, M, rk, cfg.c.solver_iterations); PT(9);
+  // mj_checkPos / mj_checkVel / mj_checkAcc [MJ-doc]: a non-finite or huge (> 1e10) entry of qpos, qvel or qacc is MuJoCo's
+  // "Nan, Inf or huge value" warning, which mujoco_py raises and the env turns into fail = True (ho_im4.py:635-637)
   float bad = 0.f;
-  if (tid < m.nv) { const float a = w.qacc[tid]; bad = (isfinite(a) && fabsf(a) < 1e10f) ? 0.f : 1.f; }
+  if (tid < m.nv) {
+    const float a = w.qacc[tid], v = w.qvel[tid];
+    bad = (isfinite(a) && fabsf(a) < 1e10f && isfinite(v) && fabsf(v) < 1e10f) ? 0.f : 1.f;
+  }
+  if (tid >= 32 && tid - 32 < m.nq) { const float q = w.qpos[tid - 32]; if (!(isfinite(q) && fabsf(q) < 1e10f)) bad = 1.f; }
   return !(wave_max(bad) > 0.f);
 }
 

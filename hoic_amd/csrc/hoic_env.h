@@ -46,8 +46,11 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
     qv = w.qvel[d];
     err = w.qpos[d] + qv * dt - target;
     if (d >= 3) {
-      while (err > 3.14159265358979f) err -= 6.28318530717959f;
-      while (err < -3.14159265358979f) err += 6.28318530717959f;
+      // (the reference's while loops, ho_im4.py:476-481, with a trip limit: an env whose state has run away -- test mode has no
+      //  termination -- reaches |err| > 2^24 * 2 pi, where subtracting 2 pi no longer changes the float and the loop never ends:
+      //  one such wavefront hangs the launch and everything behind it)
+      for (int k = 0; k < 16 && err > 3.14159265358979f; k++) err -= 6.28318530717959f;
+      for (int k = 0; k < 16 && err < -3.14159265358979f; k++) err += 6.28318530717959f;
     }
     kp = cfg.c.jkp[d]; kd = cfg.c.jkd[d];
     rhs = -w.bias[d] - kp * err - kd * qv;

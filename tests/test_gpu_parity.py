@@ -875,6 +875,32 @@ def test_single_contact_mesh_mode(obj, oracle_lib):
     sim.close(); multi.close()
 
 
+def test_runaway_state_fails_the_step_instead_of_hanging_the_launch(box_blob, setup):
+    """A state that has run away (possible in test mode, which has no termination) must end as fail = True -- MuJoCo's
+    "Nan, Inf or huge value" warning, which the reference's env turns into fail (ho_im4.py:635-637) -- and the launch must
+    come back: the angle wrap of compute_torque (ho_im4.py:476-481) is a while loop in the reference, and with |error| beyond
+    2^24 * 2 pi a float32 while loop never ends (round 3 found a wavefront spinning there, with every later launch queued behind
+    it).  Envs with huge wrist velocities / positions and non-finite entries next to ordinary ones."""
+    cfg, ex, thresh = setup
+    N = 16
+    sim = _sim(box_blob, N, cfg, ex, thresh)
+    sim.set_mode(False)
+    sim.reset(np.arange(N) % 4, np.full(N, 50))
+    q, v, _ = sim.get_state()
+    q = q.clone(); v = v.clone()
+    v[1, 4] = 3e11; v[2, 3] = -7e9; q[3, 5] = 4e9; v[4, 10] = float("inf"); q[5, 4] = float("nan"); v[6, 30] = 2e10
+    sim.set_state(q, v)
+    act = torch.zeros(N, 32, device="cuda")
+    for _ in range(2):
+        out = sim.step(act)
+    torch.cuda.synchronize()
+    fl = out[3].cpu().numpy()
+    assert fl[[1, 3, 4, 5, 6], 0].all(), fl[:8]                    # the runaway envs failed ...
+    assert not fl[[0, 7, 8, 9, 10, 11], 0].any()                     # ... the ordinary ones did not
+    assert torch.isfinite(out[0][[0, 7, 8, 9]]).all() and torch.isfinite(out[1][[0, 7, 8, 9]]).all()
+    sim.close()
+
+
 def test_longest_first_launch_order_changes_no_result(box_blob, setup, monkeypatch):
     """Longest-first dispatch (the default; HOIC_REORDER=0 = block index order) only changes which
     CU runs an env: states and outputs stay bit-identical; hoic_env_durations reports the sort keys."""
