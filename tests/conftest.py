@@ -27,6 +27,22 @@ def pytest_collection_modifyitems(config, items):
                 it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _release_device_objects_between_tests():
+    """Simulators / agents a test leaves behind hold HIP streams and events until the garbage collector gets to them; a
+    session of ~70 GPU tests otherwise runs its later tests beside dozens of idle streams of earlier ones.  Collect after
+    every test and let the device drain, so that every test starts from a quiet device."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def box_blob():
     from hoic_amd import mjcf
