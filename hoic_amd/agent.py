@@ -163,7 +163,7 @@ class PPOLearner:
             veng = self._split_engines()[0]
             self._v_first = veng.forward(states)
             with torch.no_grad():
-                values = self.value_net.value_head(self._v_first.detach())
+                values = self.value_net.head(self._v_first.detach())
         else:
             with torch.no_grad(), self._autocast():
                 values = self.value_net(states).float()
@@ -201,7 +201,7 @@ class PPOLearner:
             for ep in range(self.opt_num_epochs):
                 # epoch 0 reuses the forward pass update_params made for the returns (same weights, same input)
                 h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
-                loss = (self.value_net.value_head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
+                loss = (self.value_net.head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
                 self.optimizer_value.zero_grad(set_to_none=True)
                 (loss * weight if weight != 1.0 else loss).backward()
                 veng.backward(h.grad)
@@ -241,7 +241,7 @@ class PPOLearner:
             p_pending, p_waiting = None, False
             for ep in range(self.opt_num_epochs):
                 h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
-                value_loss = (self.value_net.value_head(h) - returns).pow(2).mean()
+                value_loss = (self.value_net.head(h) - returns).pow(2).mean()
                 self.optimizer_value.zero_grad(set_to_none=True)
                 (value_loss * weight if weight != 1.0 else value_loss).backward()
                 veng.backward(h.grad)
@@ -265,7 +265,9 @@ class PPOLearner:
             # The two networks' chains are independent within an update: the value chain goes to a side stream and the GPU
             # runs workgroups of both.  Unlike the float32 library GEMMs of round 1 (which filled the GPU: no gain), the
             # f16x3 kernels leave partial rounds (1664 workgroups on 512 slots) and HBM-bound epilogues for the other
-            # chain's workgroups to fill.
+            # chain's workgroups to fill.  Nothing in either chain may be a library GEMM: the heads run on hoic_mlp_head /
+            # hoic_mlp_head_backward (rl.Value.head, PolicyGaussian.get_log_prob) because the BLAS library's stream-K kernel
+            # for a head's weight gradient, launched by both chains at once, spun forever on its flags.
             cur = torch.cuda.current_stream(self.device)
             if self._value_stream is None:
                 self._value_stream = torch.cuda.Stream(self.device)

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(64) void hoic_head_kernel(int M, int K, int N, cons
   // groups, so every operand is a 16-byte load and both matrices are read as stored.
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x, r = lane & 15, g = lane >> 4, row0 = blockIdx.x * 16;
-  const float* hp = h + (long long)(row0 + r) * ldh + 4 * g;
+  const float* hp = h + (long long)min(row0 + r, M - 1) * ldh + 4 * g;       // rows past M are computed (from row M - 1) and not written
   const float* w0 = W + (long long)(r < N ? r : 0) * K + 4 * g;
   const float* w1 = W + (long long)(16 + r < N ? 16 + r : 0) * K + 4 * g;
   const float m0 = r < N ? 1.f : 0.f, m1 = 16 + r < N ? 1.f : 0.f;
@@ -1076,11 +1076,76 @@ __global__ __launch_bounds__(64) void hoic_head_kernel(int M, int K, int N, cons
 }
 extern "C" int32_t hoic_mlp_head(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_bias,
                                  const float* d_std, const float* d_eps, int64_t lde, float* d_out, int64_t ldo, void* stream) {
-  if (M <= 0 || (M & 15) || K <= 0 || (K & 15) || N <= 0 || N > 32 || !d_h || !d_W || !d_out || (ldh & 3) || ((size_t)d_h & 15) || ((size_t)d_W & 15)) {
-    hoic_set_error("hoic_mlp_head: M % 16 == 0, K % 16 == 0, N <= 32, 16-byte aligned h / W with ldh % 4 == 0"); return HOIC_ERR_ARG;
+  if (M <= 0 || K <= 0 || (K & 15) || N <= 0 || N > 32 || !d_h || !d_W || !d_out || (ldh & 3) || ((size_t)d_h & 15) || ((size_t)d_W & 15)) {
+    hoic_set_error("hoic_mlp_head: K % 16 == 0, N <= 32, 16-byte aligned h / W with ldh % 4 == 0"); return HOIC_ERR_ARG;
   }
-  hipLaunchKernelGGL(hoic_head_kernel, dim3((unsigned)(M >> 4)), dim3(64), 0, (hipStream_t)stream, M, K, N, d_h, (long long)ldh, d_W, d_bias, d_std, d_eps,
+  hipLaunchKernelGGL(hoic_head_kernel, dim3((unsigned)((M + 15) >> 4)), dim3(64), 0, (hipStream_t)stream, M, K, N, d_h, (long long)ldh, d_W, d_bias, d_std, d_eps,
                      (long long)lde, d_out, (long long)ldo);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- the heads' backward pass
+// The head of either network is out = h W^T + b with N <= 32 outputs on the K-wide output of the MLP body (action_mean of
+// policy_gaussian.py:16-25, value_head of the value MLP).  Given g = dLoss/dout [M, N] this launch makes, in ONE pass over h,
+//   dh[m][k] = sum_n g[m][n] W[n][k]                       (what the body's backward pass starts from)
+//   part[blk][n][k] = sum_{m in blk} g[m][n] h[m][k]       (weight gradient, finished by hoic_colpart_finish_kernel in fixed order)
+//   part[blk][N K + n] = sum_{m in blk} g[m][n]            (bias gradient)
+// in float32 FMAs.  A thread owns two adjacent columns k: the W entries of its columns and its 2 N partial sums stay in
+// registers, g[m][:] is one row of <= 32 floats every thread of the block reads from the same address (a broadcast), h and
+// dh move as coalesced 8-byte accesses -- the launch is bound by reading h and writing dh once (2 x 4 K bytes per row).
+// It replaces three library GEMMs per head and step; those were the only library GEMMs inside the update's two concurrent
+// chains, and the library's stream-K kernel for the weight gradient is not safe to run on two streams at once.
+#define HEADB_NT 256
+template <int NMAX>
+__global__ __launch_bounds__(HEADB_NT) void hoic_head_bwd_kernel(int M, int K, int N, int rows_per_block, const float* __restrict__ h, long long ldh,
+                                                                 const float* __restrict__ W, const float* __restrict__ g, long long ldg,
+                                                                 float* __restrict__ dh, long long lddh, float* __restrict__ part) {
+  const int tid = threadIdx.x, m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float* mypart = part + (long long)blockIdx.x * (((long long)N * K + N + 1) & ~1LL);      // even stride: 8-byte stores
+  for (int k0 = 2 * tid; k0 < K; k0 += 2 * HEADB_NT) {
+    float w0[NMAX], w1[NMAX], a0[NMAX], a1[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; n++) {
+      const float2 w = n < N ? *(const float2*)(W + (long long)n * K + k0) : make_float2(0.f, 0.f);
+      w0[n] = w.x; w1[n] = w.y; a0[n] = 0.f; a1[n] = 0.f;
+    }
+    for (int m = m0; m < m1; m++) {
+      const float2 hv = *(const float2*)(h + (long long)m * ldh + k0);
+      const float* gr = g + (long long)m * ldg;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int n = 0; n < NMAX; n++) {
+        const float gn = n < N ? gr[n] : 0.f;
+        d0 = fmaf(gn, w0[n], d0); d1 = fmaf(gn, w1[n], d1);
+        a0[n] = fmaf(gn, hv.x, a0[n]); a1[n] = fmaf(gn, hv.y, a1[n]);
+      }
+      *(float2*)(dh + (long long)m * lddh + k0) = make_float2(d0, d1);
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; n++)
+      if (n < N) *(float2*)(mypart + (long long)n * K + k0) = make_float2(a0[n], a1[n]);
+  }
+  if (tid < N) {
+    float sb = 0.f;
+    for (int m = m0; m < m1; m++) sb += g[(long long)m * ldg + tid];
+    mypart[(long long)N * K + tid] = sb;
+  }
+}
+extern "C" int32_t hoic_mlp_head_backward(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_g, int64_t ldg,
+                                          float* d_dh, int64_t lddh, float* d_grad, float* d_part, int32_t nblocks, void* stream) {
+  if (M <= 0 || K <= 0 || (K & 1) || N <= 0 || N > 32 || nblocks <= 0 || !d_h || !d_W || !d_g || !d_dh || !d_grad || !d_part || (ldh & 1) || (lddh & 1) ||
+      ((size_t)d_h & 7) || ((size_t)d_W & 7) || ((size_t)d_dh & 7) || ((size_t)d_part & 7)) {
+    hoic_set_error("hoic_mlp_head_backward: K even, N <= 32, 8-byte aligned h / W / dh / part with even leading dimensions"); return HOIC_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (M + nblocks - 1) / nblocks, nb = (M + rows - 1) / rows;       // nb <= nblocks blocks, the last one ragged
+  if (N <= 8)
+    hipLaunchKernelGGL(hoic_head_bwd_kernel<8>, dim3(nb), dim3(HEADB_NT), 0, st, M, K, N, rows, d_h, (long long)ldh, d_W, d_g, (long long)ldg, d_dh, (long long)lddh, d_part);
+  else
+    hipLaunchKernelGGL(hoic_head_bwd_kernel<32>, dim3(nb), dim3(HEADB_NT), 0, st, M, K, N, rows, d_h, (long long)ldh, d_W, d_g, (long long)ldg, d_dh, (long long)lddh, d_part);
+  const int C = (N * K + N + 1) & ~1;       // the stride of a block's partial sums
+  hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, d_part, nb, C, d_grad);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

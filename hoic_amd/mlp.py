@@ -75,6 +75,8 @@ class _Kernels:
         L.hoic_mlp_forward_tiled.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         L.hoic_mlp_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
         L.hoic_mlp_head.restype = i32
+        L.hoic_mlp_head_backward.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, vp]
+        L.hoic_mlp_head_backward.restype = i32
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
                   "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel",
                   "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled"):
@@ -433,10 +435,10 @@ class SplitMLP:
 
 def action_head(hidden, weight, bias, std=None, eps=None, out=None):
     """mean = hidden @ weight^T + bias, or the Gaussian sample mean + std * eps when ``eps`` is given, in one LDS-free float32
-    launch (hoic_mlp_head); hidden [M, K] float32 with M % 16 == 0 and K % 16 == 0, weight [N <= 32, K]."""
+    launch (hoic_mlp_head); hidden [M, K] float32 with K % 16 == 0, weight [N <= 32, K]."""
     M_, K_ = hidden.shape
     N_ = weight.shape[0]
-    assert hidden.dtype == torch.float32 and hidden.stride(1) == 1 and weight.is_contiguous() and M_ % 16 == 0 and K_ % 16 == 0 and N_ <= 32
+    assert hidden.dtype == torch.float32 and hidden.stride(1) == 1 and weight.is_contiguous() and K_ % 16 == 0 and N_ <= 32
     if out is None:
         out = torch.empty(M_, N_, dtype=torch.float32, device=hidden.device)
     assert out.stride(1) == 1 and (eps is None or (eps.stride(1) == 1 and eps.shape == (M_, N_)))
@@ -446,6 +448,47 @@ def action_head(hidden, weight, bias, std=None, eps=None, out=None):
         K.chk(K.L.hoic_mlp_head(M_, K_, N_, _ptr(hidden), hidden.stride(0), _ptr(weight), _ptr(bias), _ptr(std1), _ptr(eps),
                                 0 if eps is None else eps.stride(0), _ptr(out), out.stride(0), _stream(hidden.device)), "hoic_mlp_head")
     return out
+
+
+HEAD_BWD_BLOCKS = 512        # row blocks of the heads' backward launch (two per CU; their partial sums: 512 x (N K + N) floats)
+
+
+class _HeadLinear(torch.autograd.Function):
+    """hidden @ weight^T + bias with the forward AND the backward pass on this package's own float32 kernels (hoic_mlp_head,
+    hoic_mlp_head_backward) -- the nn.Linear at the end of either network (policy_gaussian.py:16-25 action_mean; the value
+    MLP's value_head) as the update of the f16x3 engine runs it.  No library GEMM is left inside the update's chains: the
+    library's stream-K kernel for the weight gradient (34 workgroups that wait for one another's flags) deadlocked when the
+    two chains ran it at the same time on two streams."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias):
+        ctx.save_for_backward(hidden, weight)
+        return action_head(hidden, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        hidden, weight = ctx.saved_tensors
+        M_, K_ = hidden.shape
+        N_ = weight.shape[0]
+        g = g.contiguous()
+        S = (N_ * K_ + N_ + 1) & ~1
+        dh = torch.empty(M_, K_, dtype=torch.float32, device=hidden.device)
+        grad = torch.empty(S, dtype=torch.float32, device=hidden.device)
+        part = torch.empty(HEAD_BWD_BLOCKS * S, dtype=torch.float32, device=hidden.device)
+        Kn = kernels()
+        with torch.cuda.device(hidden.device):
+            Kn.chk(Kn.L.hoic_mlp_head_backward(M_, K_, N_, _ptr(hidden), hidden.stride(0), _ptr(weight), _ptr(g), g.stride(0), _ptr(dh), dh.stride(0),
+                                               _ptr(grad), _ptr(part), HEAD_BWD_BLOCKS, _stream(hidden.device)), "hoic_mlp_head_backward")
+        return dh, grad[:N_ * K_].view(N_, K_), grad[N_ * K_:N_ * K_ + N_]
+
+
+def head_linear(hidden, linear):
+    """``linear(hidden)`` for the nn.Linear head of a network whose body ran on the f16x3 engine (float32 CUDA ``hidden`` with
+    K % 16 == 0 and <= 32 outputs: the HIP head kernels, differentiable); anything else goes to the module itself."""
+    if (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.dim() == 2 and hidden.stride(1) == 1 and hidden.shape[1] % 16 == 0
+            and hidden.stride(0) % 4 == 0 and linear.weight.shape[0] <= 32 and linear.weight.is_contiguous() and linear.bias is not None):
+        return _HeadLinear.apply(hidden, linear.weight, linear.bias)
+    return linear(hidden)
 
 
 class TiledForward:

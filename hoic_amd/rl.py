@@ -59,7 +59,7 @@ class PolicyGaussian(nn.Module):
         of this batch made up front -- head and sample are then ONE LDS-free launch (hoic_mlp_head) instead of a library
         GEMM that queues for the CUs' LDS behind the simulator plus two elementwise kernels"""
         std = torch.exp(self.action_log_std) if std is None else std
-        if eps is not None and hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[0] % 16 == 0 and hidden.shape[1] % 16 == 0:
+        if eps is not None and hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[1] % 16 == 0:
             from .mlp import action_head
             return action_head(hidden, self.action_mean.weight.detach(), self.action_mean.bias.detach(), std, eps, out)
         if eps is not None:
@@ -73,7 +73,8 @@ class PolicyGaussian(nn.Module):
         if hidden is None:
             mean, log_std = self.forward(x)
         else:
-            mean = self.action_mean(hidden)
+            from .mlp import head_linear       # float32 CUDA hidden: the HIP head kernels (forward and backward), else the nn.Linear
+            mean = head_linear(hidden, self.action_mean)
             log_std = self.action_log_std.expand_as(mean)
         var = torch.exp(2 * log_std)
         lp = -((action - mean) ** 2) / (2 * var) - log_std - 0.5 * math.log(2 * math.pi)
@@ -90,6 +91,11 @@ class Value(nn.Module):
 
     def forward(self, x):
         return self.value_head(self.net(x))
+
+    def head(self, hidden):
+        """value_head on the body's output computed elsewhere (the f16x3 GEMM path): the HIP head kernels for float32 CUDA input"""
+        from .mlp import head_linear
+        return head_linear(hidden, self.value_head)
 
 
 # ----------------------------------------------------------------------------- advantages

@@ -257,10 +257,18 @@ int32_t hoic_mlp_forward_tiled(int32_t M, int32_t N, int32_t K, const void* d_X,
                                void* stream);
 /* hoic_mlp_head: d_out[m][n] = sum_k d_h[m][k] d_W[n][k] + d_bias[n] (+ d_std[n] * d_eps[m][n] when d_eps is given): the action
  * head on the policy body's output and the Gaussian sample in one LDS-free float32 launch (PolicyGaussian.forward /
- * select_action, uhc/khrylib/rl/core/policy_gaussian.py:27-33; mean + std * N(0, 1), distributions.py:11-13).  M % 16 ==
- * K % 16 == 0, N <= 32; row strides ldh / lde / ldo in floats; d_bias, d_std, d_eps may be NULL. */
+ * select_action, uhc/khrylib/rl/core/policy_gaussian.py:27-33; mean + std * N(0, 1), distributions.py:11-13); with N = 1 the
+ * value head (the value MLP's last nn.Linear, uhc/khrylib/rl/core/critic.py).  K % 16 == 0, N <= 32; row strides ldh / lde /
+ * ldo in floats; d_bias, d_std, d_eps may be NULL.
+ * hoic_mlp_head_backward: the same head's backward pass in one pass over d_h, given d_g = dLoss/d_out [M x N]:
+ *   d_dh[m][k] = sum_n d_g[m][n] d_W[n][k];  d_grad[n K + k] = sum_m d_g[m][n] d_h[m][k] (weight gradient, [N x K] row-major),
+ *   d_grad[N K + n] = sum_m d_g[m][n] (bias gradient).  What torch.autograd does for nn.Linear in the reference's
+ *   loss.backward() (agent_ppo.py:46-56, agent_pg.py:18-25), in float32 FMAs with a fixed summation order.  K even, N <= 32;
+ *   d_grad holds S = (N K + N + 1) & ~1 floats, d_part (scratch) nblocks * S floats; nblocks = row blocks of the partial sums. */
 int32_t hoic_mlp_head(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_bias,
                       const float* d_std, const float* d_eps, int64_t lde, float* d_out, int64_t ldo, void* stream);
+int32_t hoic_mlp_head_backward(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_g, int64_t ldg,
+                               float* d_dh, int64_t lddh, float* d_grad, float* d_part, int32_t nblocks, void* stream);
 int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
                              float scale, void* stream);
 int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot,

@@ -323,7 +323,7 @@ def test_f16x3_overflow_in_either_network_fails_the_update(which):
 
 
 @gpu
-@pytest.mark.parametrize("rows,n_out", [(2048, 32), (96, 32), (64, 1)])
+@pytest.mark.parametrize("rows,n_out", [(2048, 32), (96, 32), (64, 1), (1003, 32)])
 def test_action_head_kernel_matches_float64(rows, n_out):
     """hoic_mlp_head (the rollout's action head + Gaussian sample, one LDS-free float32 MFMA launch) against a float64
     evaluation of mean = h W^T + b and of mean + std * eps: float32 accumulation error only (1e-6 of sum |h||w|), strided
@@ -349,3 +349,33 @@ def test_action_head_kernel_matches_float64(rows, n_out):
             a_k = pol.select_action_from_hidden(h, eps=eps)                                      # kernel path
             a_t = torch.addcmul(pol.action_mean(h), torch.exp(pol.action_log_std).expand(rows, 32), eps)
         assert (a_k - a_t).abs().max().item() < 2e-6 * (1 + a_t.abs().max().item())
+
+
+@gpu
+@pytest.mark.parametrize("rows,n_out", [(50176, 32), (50176, 1), (1003, 32), (37, 1), (600, 6)])
+def test_head_linear_forward_and_backward_match_float64_autograd(rows, n_out):
+    """mlp.head_linear (hoic_mlp_head + hoic_mlp_head_backward: the heads of the f16x3 update, no library GEMM) against
+    torch.autograd on a float64 nn.Linear with the same parameters and the same upstream gradient: output, gradient of the
+    hidden activation, weight and bias gradients within float32 accumulation error (relative to the sum of magnitudes that
+    each entry accumulates); ragged row counts (whole-episode batches), the value head's single output."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    lin = torch.nn.Linear(512, n_out).cuda()
+    h = torch.randn(rows, 512, device="cuda", generator=g).requires_grad_(True)
+    up = torch.randn(rows, n_out, device="cuda", generator=g) / rows
+    out = M.head_linear(h, lin)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_HeadLinear")      # the kernels, not the module
+    (out * up).sum().backward()
+    lin64 = torch.nn.Linear(512, n_out).cuda().double()
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    h64 = h.detach().double().requires_grad_(True)
+    out64 = lin64(h64)
+    (out64 * up.double()).sum().backward()
+    eps = 2e-6
+    assert (out.double() - out64).abs().max().item() < eps * (h64.abs() @ lin64.weight.abs().T).max().item()
+    assert (h.grad.double() - h64.grad).abs().max().item() < eps * (up.double().abs() @ lin64.weight.abs()).max().item() + 1e-30
+    mag_w = (up.double().abs().T @ h64.detach().abs())
+    assert ((lin.weight.grad.double() - lin64.weight.grad).abs() / mag_w).max().item() < 20 * eps      # sums over up to 50176 rows
+    assert ((lin.bias.grad.double() - lin64.bias.grad).abs() / up.double().abs().sum(0)).max().item() < 20 * eps
+    # under no_grad the forward kernel alone runs (the old policy's log-probabilities of epoch 0)
+    with torch.no_grad():
+        assert torch.equal(M.head_linear(h, lin), out.detach())
