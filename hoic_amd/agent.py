@@ -195,16 +195,36 @@ class PPOLearner:
         (wait_value_update)."""
         veng, peng = self._split_engines()
         v_first, self._v_first = getattr(self, "_v_first", None), None
+        from . import mlp as M
+
+        # Head + loss + their backward pass of one epoch: four launches of this package's kernels each (mlp.value_head_step /
+        # ppo_head_step), no autograd graph and no library GEMM; the autograd form (same arithmetic through PyTorch's
+        # elementwise kernels around mlp.head_linear) is what runs when the heads do not fit the kernels (> 32 outputs).
+        def value_step(h):
+            if M.heads_fusable(h, self.value_net.value_head):
+                return M.value_head_step(h, self.value_net, returns, weight)
+            loss = (self.value_net.head(h) - returns).pow(2).mean()
+            (loss * weight if weight != 1.0 else loss).backward()
+            return loss.detach(), h.grad
+
+        def policy_step_head(h, fixed_log_probs):
+            if M.heads_fusable(h, self.policy_net.action_mean):
+                return M.ppo_head_step(h, self.policy_net, actions, advantages, fixed_log_probs, self.clip_epsilon, weight)
+            if fixed_log_probs is None:
+                with torch.no_grad():
+                    fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
+            loss = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
+            (loss * weight if weight != 1.0 else loss).backward()
+            return loss.detach(), h.grad, fixed_log_probs
 
         def value_phase():
             loss = None
             for ep in range(self.opt_num_epochs):
                 # epoch 0 reuses the forward pass update_params made for the returns (same weights, same input)
                 h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
-                loss = (self.value_net.head(h) - returns).pow(2).mean()                 # agent_pg.py:18-25
                 self.optimizer_value.zero_grad(set_to_none=True)
-                (loss * weight if weight != 1.0 else loss).backward()
-                veng.backward(h.grad)
+                loss, dh = value_step(h)                                                # agent_pg.py:18-25
+                veng.backward(dh)
                 self._allreduce_finish(self._allreduce_start(vparams))
                 self.optimizer_value.step()
             return loss.detach()
@@ -213,13 +233,10 @@ class PPOLearner:
             fixed_log_probs, loss = None, None
             for ep in range(self.opt_num_epochs):
                 h = peng.forward(inp)
-                if fixed_log_probs is None:      # the old policy's log-probabilities are epoch 0's own (ratio = 1 there, agent_ppo.py:18-20)
-                    with torch.no_grad():
-                        fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
-                loss = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
                 self.optimizer_policy.zero_grad(set_to_none=True)
-                (loss * weight if weight != 1.0 else loss).backward()
-                peng.backward(h.grad)
+                # the old policy's log-probabilities are epoch 0's own (ratio = 1 there, agent_ppo.py:18-20)
+                loss, dh, fixed_log_probs = policy_step_head(h, fixed_log_probs)
+                peng.backward(dh)
                 policy_step(self._allreduce_start(pparams))
             return loss.detach()
 
@@ -241,21 +258,16 @@ class PPOLearner:
             p_pending, p_waiting = None, False
             for ep in range(self.opt_num_epochs):
                 h = v_first if (ep == 0 and v_first is not None and veng.inp is inp) else veng.forward(inp)
-                value_loss = (self.value_net.head(h) - returns).pow(2).mean()
                 self.optimizer_value.zero_grad(set_to_none=True)
-                (value_loss * weight if weight != 1.0 else value_loss).backward()
-                veng.backward(h.grad)
+                value_loss, dh = value_step(h)
+                veng.backward(dh)
                 v_pending = self._allreduce_start(vparams)
                 if p_waiting:
                     policy_step(p_pending); p_waiting = False
                 h = peng.forward(inp)
-                if fixed_log_probs is None:
-                    with torch.no_grad():
-                        fixed_log_probs = self.policy_net.get_log_prob(None, actions, hidden=h.detach())
-                surr = ppo_loss(self.policy_net, None, actions, advantages, fixed_log_probs, self.clip_epsilon, hidden=h)
                 self.optimizer_policy.zero_grad(set_to_none=True)
-                (surr * weight if weight != 1.0 else surr).backward()
-                peng.backward(h.grad)
+                surr, dh, fixed_log_probs = policy_step_head(h, fixed_log_probs)
+                peng.backward(dh)
                 p_pending, p_waiting = self._allreduce_start(pparams), True
                 self._allreduce_finish(v_pending)
                 self.optimizer_value.step()

@@ -24,6 +24,7 @@
 // LDS image lane-linear, XOR swizzle applied to the SOURCE address and to the ds_read), v_mfma_f32_32x32x16_f16.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include "../../include/hoic.h"
 
@@ -1146,6 +1147,92 @@ extern "C" int32_t hoic_mlp_head_backward(int32_t M, int32_t K, int32_t N, const
     hipLaunchKernelGGL(hoic_head_bwd_kernel<32>, dim3(nb), dim3(HEADB_NT), 0, st, M, K, N, rows, d_h, (long long)ldh, d_W, d_g, (long long)ldg, d_dh, (long long)lddh, d_part);
   const int C = (N * K + N + 1) & ~1;       // the stride of a block's partial sums
   hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, d_part, nb, C, d_grad);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- the two losses of the update
+// hoic_ppo_loss_kernel: everything between the action head's output and its gradient in ONE launch --
+//   log pi(a|s) = sum_j [ -(a_j - mean_j)^2 / (2 exp(2 s_j)) - s_j - log sqrt(2 pi) ]   (policy_gaussian.py / distributions.py log_prob, s = action_log_std)
+//   ratio = exp(log pi - fixed),  surr1 = ratio A,  surr2 = clamp(ratio, 1 - eps, 1 + eps) A,  L = -mean(min(surr1, surr2))   (agent_ppo.py:58-64)
+// and the backward pass torch.autograd makes of it: dL/dmean -> g, the sums over the rows for dL/ds_j and L itself as per-block
+// partial sums (finished in fixed order by hoic_colpart_finish_kernel).  fixed == NULL is epoch 0 of agent_ppo.py:18-20: the
+// old policy IS the current one, ratio = exp(0) = 1 exactly, and the log-probabilities go to logp_out for the later epochs.
+// A row is a 32-lane half wavefront (lane = action dimension): 128-byte row accesses, the sum over j by 5 shuffles.
+// The gradient of min / clamp follows PyTorch's rules: minimum passes the gradient to the smaller argument (half to each at a
+// tie), clamp passes it inside the closed interval -- together: pass iff surr1 < surr2 or ratio in [1 - eps, 1 + eps].
+#define LOSS_PART 34         // per-block partial sums: 32 x dL/ds_j, L, one pad
+__global__ __launch_bounds__(256) void hoic_ppo_loss_kernel(int M, int N, const float* __restrict__ mean, long long ldm, const float* __restrict__ act, long long lda,
+                                                            const float* __restrict__ adv, const float* __restrict__ fixed, const float* __restrict__ log_std,
+                                                            float clip, float scale, float inv_m, float* __restrict__ g, long long ldg,
+                                                            float* __restrict__ logp_out, float* __restrict__ part) {
+  __shared__ float red[8][LOSS_PART];
+  const int j = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const bool on = j < N;
+  const float ls = on ? log_std[j] : 0.f, var = expf(2.f * ls);
+  float acc_ls = 0.f, acc_loss = 0.f;
+  for (long long m = (long long)blockIdx.x * 8 + hw; m < M; m += (long long)gridDim.x * 8) {
+    const float d = on ? act[m * lda + j] - mean[m * ldm + j] : 0.f;
+    float lp = on ? -(d * d) / (2.f * var) - ls - 0.91893853320467274f : 0.f;
+#pragma unroll
+    for (int o = 16; o; o >>= 1) lp += __shfl_xor(lp, o, 32);
+    const float r = fixed ? expf(lp - fixed[m]) : 1.f, A = adv[m];
+    const float s1 = r * A, s2 = fminf(fmaxf(r, 1.f - clip), 1.f + clip) * A;
+    const bool pass = s1 < s2 || (r >= 1.f - clip && r <= 1.f + clip);
+    const float dlp = pass ? -scale * A * r : 0.f;
+    if (on) {
+      g[m * ldg + j] = dlp * d / var;
+      acc_ls = fmaf(dlp, d * d / var - 1.f, acc_ls);
+    }
+    if (j == 0) { acc_loss -= fminf(s1, s2) * inv_m; if (logp_out) logp_out[m] = lp; }
+  }
+  red[hw][j] = acc_ls;
+  if (j == 0) { red[hw][32] = acc_loss; red[hw][33] = 0.f; }
+  __syncthreads();
+  if (threadIdx.x < LOSS_PART) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) t += red[q][threadIdx.x];
+    part[(long long)blockIdx.x * LOSS_PART + threadIdx.x] = t;
+  }
+}
+// hoic_value_loss_kernel: L = mean((v - ret)^2) (agent_pg.py:18-25 update_value), g = dL/dv = 2 (v - ret) weight / M
+__global__ __launch_bounds__(256) void hoic_value_loss_kernel(int M, const float* __restrict__ v, const float* __restrict__ ret, float scale2, float inv_m,
+                                                              float* __restrict__ g, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    const float e = v[m] - ret[m];
+    g[m] = scale2 * e;
+    acc = fmaf(e * inv_m, e, acc);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+extern "C" int32_t hoic_mlp_ppo_loss(int32_t M, int32_t N, const float* d_mean, int64_t ldm, const float* d_act, int64_t lda, const float* d_adv,
+                                     const float* d_fixed, const float* d_log_std, float clip, float weight, float* d_g, int64_t ldg, float* d_logp_out,
+                                     float* d_sums, float* d_part, int32_t nblocks, void* stream) {
+  if (M <= 0 || N <= 0 || N > 32 || nblocks <= 0 || !d_mean || !d_act || !d_adv || !d_log_std || !d_g || !d_sums || !d_part || (!d_fixed && !d_logp_out)) {
+    hoic_set_error("hoic_mlp_ppo_loss: N <= 32, and without fixed log-probabilities (epoch 0) a place to put them"); return HOIC_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)std::min<long long>(nblocks, ((long long)M + 7) / 8);
+  hipLaunchKernelGGL(hoic_ppo_loss_kernel, dim3(nb), dim3(256), 0, st, M, N, d_mean, (long long)ldm, d_act, (long long)lda, d_adv, d_fixed, d_log_std, clip,
+                     weight / (float)M, 1.f / (float)M, d_g, (long long)ldg, d_logp_out, d_part);
+  hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3(1), dim3(1024), 0, st, d_part, nb, LOSS_PART, d_sums);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_mlp_value_loss(int32_t M, const float* d_v, const float* d_ret, float weight, float* d_g, float* d_loss, float* d_part,
+                                       int32_t nblocks, void* stream) {
+  if (M <= 0 || nblocks <= 0 || !d_v || !d_ret || !d_g || !d_loss || !d_part) { hoic_set_error("hoic_mlp_value_loss: bad arguments"); return HOIC_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)std::min<long long>(nblocks, ((long long)M + 255) / 256);
+  hipLaunchKernelGGL(hoic_value_loss_kernel, dim3(nb), dim3(256), 0, st, M, d_v, d_ret, 2.f * weight / (float)M, 1.f / (float)M, d_g, d_part);
+  hipLaunchKernelGGL(hoic_colpart_finish_kernel, dim3(1), dim3(1024), 0, st, d_part, nb, 1, d_loss);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

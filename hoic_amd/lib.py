@@ -45,7 +45,8 @@ EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic
            "hoic_append_expert_frame", "hoic_get_diagnostics", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps",
            "hoic_mlp_gemm", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed", "hoic_mlp_set_pipeline", "hoic_mlp_gemm_tn",
            "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel", "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled",
-           "hoic_set_async_reward", "hoic_sync_rewards", "hoic_mlp_head", "hoic_mlp_head_backward"]
+           "hoic_set_async_reward", "hoic_sync_rewards", "hoic_mlp_head", "hoic_mlp_head_backward", "hoic_mlp_ppo_loss",
+           "hoic_mlp_value_loss"]
 
 
 def build(force: bool = False) -> str:

@@ -77,6 +77,10 @@ class _Kernels:
         L.hoic_mlp_head.restype = i32
         L.hoic_mlp_head_backward.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, vp]
         L.hoic_mlp_head_backward.restype = i32
+        L.hoic_mlp_ppo_loss.argtypes = [i32, i32, vp, i64, vp, i64, vp, vp, vp, f32, f32, vp, i64, vp, vp, vp, i32, vp]
+        L.hoic_mlp_ppo_loss.restype = i32
+        L.hoic_mlp_value_loss.argtypes = [i32, vp, vp, f32, vp, vp, vp, i32, vp]
+        L.hoic_mlp_value_loss.restype = i32
         for n in ("hoic_mlp_gemm", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed",
                   "hoic_mlp_gemm_tn", "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel",
                   "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled"):
@@ -468,18 +472,8 @@ class _HeadLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         hidden, weight = ctx.saved_tensors
-        M_, K_ = hidden.shape
-        N_ = weight.shape[0]
-        g = g.contiguous()
-        S = (N_ * K_ + N_ + 1) & ~1
-        dh = torch.empty(M_, K_, dtype=torch.float32, device=hidden.device)
-        grad = torch.empty(S, dtype=torch.float32, device=hidden.device)
-        part = torch.empty(HEAD_BWD_BLOCKS * S, dtype=torch.float32, device=hidden.device)
-        Kn = kernels()
         with torch.cuda.device(hidden.device):
-            Kn.chk(Kn.L.hoic_mlp_head_backward(M_, K_, N_, _ptr(hidden), hidden.stride(0), _ptr(weight), _ptr(g), g.stride(0), _ptr(dh), dh.stride(0),
-                                               _ptr(grad), _ptr(part), HEAD_BWD_BLOCKS, _stream(hidden.device)), "hoic_mlp_head_backward")
-        return dh, grad[:N_ * K_].view(N_, K_), grad[N_ * K_:N_ * K_ + N_]
+            return _head_backward(hidden, weight, g.contiguous())
 
 
 def head_linear(hidden, linear):
@@ -489,6 +483,86 @@ def head_linear(hidden, linear):
             and hidden.stride(0) % 4 == 0 and linear.weight.shape[0] <= 32 and linear.weight.is_contiguous() and linear.bias is not None):
         return _HeadLinear.apply(hidden, linear.weight, linear.bias)
     return linear(hidden)
+
+
+LOSS_BLOCKS = 1024           # row blocks of the loss launches (per-block partial sums, finished in fixed order)
+
+
+def _head_backward(hidden, weight, g):
+    M_, K_ = hidden.shape
+    N_ = weight.shape[0]
+    S = (N_ * K_ + N_ + 1) & ~1
+    dh = torch.empty(M_, K_, dtype=torch.float32, device=hidden.device)
+    grad = torch.empty(S, dtype=torch.float32, device=hidden.device)
+    part = torch.empty(HEAD_BWD_BLOCKS * S, dtype=torch.float32, device=hidden.device)
+    Kn = kernels()
+    Kn.chk(Kn.L.hoic_mlp_head_backward(M_, K_, N_, _ptr(hidden), hidden.stride(0), _ptr(weight), _ptr(g), g.stride(0), _ptr(dh), dh.stride(0),
+                                       _ptr(grad), _ptr(part), HEAD_BWD_BLOCKS, _stream(hidden.device)), "hoic_mlp_head_backward")
+    return dh, grad[:N_ * K_].view(N_, K_), grad[N_ * K_:N_ * K_ + N_]
+
+
+def heads_fusable(hidden, linear):
+    """whether ppo_head_step / value_head_step can run on ``hidden`` (what head_linear needs)"""
+    return (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.dim() == 2 and hidden.stride(1) == 1 and hidden.shape[1] % 16 == 0
+            and hidden.stride(0) % 4 == 0 and linear.weight.shape[0] <= 32 and linear.weight.is_contiguous() and linear.bias is not None
+            and linear.weight.dtype == torch.float32)
+
+
+def ppo_head_step(hidden, policy, actions, advantages, fixed_log_probs, clip_epsilon, weight=1.0):
+    """One policy epoch's head, loss and their backward pass without autograd: action head (hoic_mlp_head), PPO-clip loss with its
+    gradient (hoic_mlp_ppo_loss), head backward (hoic_mlp_head_backward) -- four launches for what agent_ppo.py:46-64 runs as
+    ~35 elementwise kernels and three library GEMMs.  ``fixed_log_probs`` None = epoch 0 (the old policy is the current one,
+    agent_ppo.py:18-20).  Sets ``.grad`` of action_mean.weight / .bias and (when it is trainable) action_log_std (to d(weight * loss)); returns
+    (loss [device scalar, unweighted], d(weight * loss)/d hidden, fixed_log_probs [M, 1])."""
+    lin = policy.action_mean
+    dev = hidden.device
+    M_, N_ = hidden.shape[0], lin.weight.shape[0]
+    hidden = hidden.detach()
+    actions = actions if actions.stride(1) == 1 else actions.contiguous()
+    adv = advantages.reshape(-1).contiguous()
+    assert actions.shape == (M_, N_) and adv.numel() == M_ and actions.dtype == adv.dtype == torch.float32
+    Kn = kernels()
+    with torch.cuda.device(dev), torch.no_grad():
+        mean = action_head(hidden, lin.weight, lin.bias)
+        g = torch.empty(M_, N_, dtype=torch.float32, device=dev)
+        sums = torch.empty(34, dtype=torch.float32, device=dev)
+        part = torch.empty(LOSS_BLOCKS * 34, dtype=torch.float32, device=dev)
+        new_fixed = None
+        if fixed_log_probs is None:
+            new_fixed = torch.empty(M_, 1, dtype=torch.float32, device=dev)
+        else:
+            fixed_log_probs = fixed_log_probs.reshape(-1).contiguous()
+        log_std = policy.action_log_std.detach().reshape(-1).contiguous()
+        Kn.chk(Kn.L.hoic_mlp_ppo_loss(M_, N_, _ptr(mean), mean.stride(0), _ptr(actions), actions.stride(0), _ptr(adv), _ptr(fixed_log_probs), _ptr(log_std),
+                                      float(clip_epsilon), float(weight), _ptr(g), g.stride(0), _ptr(new_fixed), _ptr(sums), _ptr(part), LOSS_BLOCKS,
+                                      _stream(dev)), "hoic_mlp_ppo_loss")
+        dh, dW, db = _head_backward(hidden, lin.weight, g)
+        lin.weight.grad, lin.bias.grad = dW, db
+        if policy.action_log_std.requires_grad:          # fix_std configurations keep it constant (policy_gaussian.py:19)
+            policy.action_log_std.grad = sums[:N_].view_as(policy.action_log_std)
+    return sums[32], dh, (new_fixed if new_fixed is not None else fixed_log_probs.view(M_, 1))
+
+
+def value_head_step(hidden, value_net, returns, weight=1.0):
+    """One value epoch's head, loss and their backward pass without autograd (agent_pg.py:18-25): value head, mean squared error
+    with its gradient (hoic_mlp_value_loss), head backward.  Sets ``.grad`` of value_head.weight / .bias; returns
+    (loss [device scalar, unweighted], d(weight * loss)/d hidden)."""
+    lin = value_net.value_head
+    dev = hidden.device
+    M_ = hidden.shape[0]
+    hidden = hidden.detach()
+    ret = returns.reshape(-1).contiguous()
+    assert ret.numel() == M_ and ret.dtype == torch.float32
+    Kn = kernels()
+    with torch.cuda.device(dev), torch.no_grad():
+        v = action_head(hidden, lin.weight, lin.bias)
+        g = torch.empty(M_, 1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        part = torch.empty(LOSS_BLOCKS, dtype=torch.float32, device=dev)
+        Kn.chk(Kn.L.hoic_mlp_value_loss(M_, _ptr(v), _ptr(ret), float(weight), _ptr(g), _ptr(loss), _ptr(part), LOSS_BLOCKS, _stream(dev)), "hoic_mlp_value_loss")
+        dh, dW, db = _head_backward(hidden, lin.weight, g)
+        lin.weight.grad, lin.bias.grad = dW, db
+    return loss[0], dh
 
 
 class TiledForward:

@@ -269,6 +269,20 @@ int32_t hoic_mlp_head(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t
                       const float* d_std, const float* d_eps, int64_t lde, float* d_out, int64_t ldo, void* stream);
 int32_t hoic_mlp_head_backward(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_g, int64_t ldg,
                                float* d_dh, int64_t lddh, float* d_grad, float* d_part, int32_t nblocks, void* stream);
+/* The update's two losses with their backward pass, one launch each (plus the fixed-order finish of the per-block sums):
+ * hoic_mlp_ppo_loss: the PPO-clip surrogate on the action head's output d_mean [M x N <= 32] -- Gaussian log-probability of
+ *   d_act under (d_mean, exp(d_log_std)) (policy_gaussian.py get_log_prob, distributions.py log_prob), ratio to d_fixed
+ *   [M], clipped surrogate with d_adv [M] (uhc/khrylib/rl/agents/agent_ppo.py:58-64) -> d_g = d(weight L)/d_mean [M x N],
+ *   d_sums[0..N) = d(weight L)/d_log_std, d_sums[32] = L (unweighted).  d_fixed == NULL: epoch 0 (agent_ppo.py:18-20: the
+ *   old policy is the current one, ratio = 1), the log-probabilities are written to d_logp_out [M].  d_sums: 34 floats,
+ *   d_part: nblocks * 34 floats of scratch.
+ * hoic_mlp_value_loss: L = mean((d_v - d_ret)^2) (agent_pg.py:18-25) -> d_g = d(weight L)/d_v [M], d_loss[0] = L;
+ *   d_part: nblocks floats. */
+int32_t hoic_mlp_ppo_loss(int32_t M, int32_t N, const float* d_mean, int64_t ldm, const float* d_act, int64_t lda, const float* d_adv,
+                          const float* d_fixed, const float* d_log_std, float clip, float weight, float* d_g, int64_t ldg, float* d_logp_out,
+                          float* d_sums, float* d_part, int32_t nblocks, void* stream);
+int32_t hoic_mlp_value_loss(int32_t M, const float* d_v, const float* d_ret, float weight, float* d_g, float* d_loss, float* d_part,
+                            int32_t nblocks, void* stream);
 int32_t hoic_mlp_slab_reduce(const float* d_slabs, int32_t S, int32_t rows, int32_t cols, float* d_out, int32_t out_cols, int64_t ldo,
                              float scale, void* stream);
 int32_t hoic_mlp_rowsum_packed(const void* d_P, int32_t rows, int32_t Cp, float* d_out, const int32_t* d_exps, int32_t slot,

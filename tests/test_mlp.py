@@ -379,3 +379,86 @@ def test_head_linear_forward_and_backward_match_float64_autograd(rows, n_out):
     # under no_grad the forward kernel alone runs (the old policy's log-probabilities of epoch 0)
     with torch.no_grad():
         assert torch.equal(M.head_linear(h, lin), out.detach())
+
+
+@gpu
+@pytest.mark.parametrize("rows", [50176, 1003])
+def test_fused_head_steps_match_autograd(rows):
+    """mlp.ppo_head_step / value_head_step (head, loss and their backward pass on this package's kernels, no autograd) against
+    torch.autograd on the reference formulation in float64 (ppo_loss: agent_ppo.py:58-64, get_log_prob: policy_gaussian.py;
+    value loss: agent_pg.py:18-25): loss, gradient of the hidden activation, and every head parameter's gradient.  The old
+    log-probabilities are those of a perturbed policy, so ratios fall on both sides of the clip interval and advantages of
+    both signs exercise both arguments of the min; epoch 0 (no old log-probabilities: ratio = 1, log-probabilities returned)
+    is checked as well; weight != 1 (a rank's share of the batch)."""
+    import copy
+    from hoic_amd.config import Config
+    from hoic_amd.rl import MLP, PolicyGaussian, Value, ppo_loss
+    cfg = Config("box_future5_light_add_geom")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pol = PolicyGaussian(cfg, 32, 617).cuda()
+    M.ppo_head_step(torch.randn(64, 512, device="cuda", generator=g), pol, torch.zeros(64, 32, device="cuda"), torch.ones(64, 1, device="cuda"), None, 0.2)
+    assert not pol.action_log_std.requires_grad and pol.action_log_std.grad is None       # fix_std: constant, no gradient made up for it
+    pol.action_log_std.requires_grad_(True)                                                 # the trainable form for the rest
+    with torch.no_grad():
+        pol.action_log_std.add_(torch.randn(1, 32, device="cuda", generator=g) * 0.2)
+        pol.action_mean.weight.mul_(3.0)
+    val = Value(MLP(617, cfg.value_hsize, cfg.value_htype)).cuda()
+    h = torch.randn(rows, 512, device="cuda", generator=g)
+    std = torch.exp(pol.action_log_std.detach())
+    actions = pol.action_mean(h).detach() + std * torch.randn(rows, 32, device="cuda", generator=g)
+    adv = torch.randn(rows, 1, device="cuda", generator=g)
+    returns = torch.randn(rows, 1, device="cuda", generator=g)
+    old = copy.deepcopy(pol)
+    with torch.no_grad():
+        old.action_mean.weight.add_(torch.randn(32, 512, device="cuda", generator=g) * 2e-4)
+        fixed = old.get_log_prob(None, actions, hidden=h)
+    weight, clip = 0.75, 0.2
+    pol64, val64 = copy.deepcopy(pol).double(), copy.deepcopy(val).double()
+
+    def reference(fixed_lp):
+        for p_ in pol64.parameters():
+            p_.grad = None
+        h64 = h.double().requires_grad_(True)
+        if fixed_lp is None:
+            with torch.no_grad():
+                fixed_lp = pol64.get_log_prob(None, actions.double(), hidden=h64.detach())
+        loss = ppo_loss(pol64, None, actions.double(), adv.double(), fixed_lp.double(), clip, hidden=h64)
+        (loss * weight).backward()
+        return loss.item(), h64.grad, fixed_lp
+
+    def close(a, b, rel, what):
+        err, mag = (a.double() - b).abs().max().item(), b.abs().max().item()
+        assert err <= rel * mag + 1e-12, f"{what}: {err:.3e} against magnitude {mag:.3e}"
+
+    for fixed_in in (None, fixed):
+        loss, dh, fixed_out = M.ppo_head_step(h, pol, actions, adv, fixed_in, clip, weight)
+        rl, rdh, rfixed = reference(fixed_in)
+        if fixed_in is not None:
+            with torch.no_grad():
+                ratio = torch.exp(pol64.get_log_prob(None, actions.double(), hidden=h.double()) - fixed.double())
+            frac_clipped = ((ratio < 1 - clip) | (ratio > 1 + clip)).double().mean().item()
+            assert 0.05 < frac_clipped < 0.95, frac_clipped         # the case really has rows on both sides of the clip
+        assert abs(loss.item() - rl) <= 2e-5 * max(1.0, abs(rl))
+        close(fixed_out, rfixed, 2e-6, "log-probabilities")
+        # a row whose ratio sits within rounding of a clip bound may pass its gradient on one side and not on the other:
+        # compare all rows but those (|ratio - bound| < 1e-5)
+        if fixed_in is not None:
+            near = (((ratio - (1 - clip)).abs() < 1e-5) | ((ratio - (1 + clip)).abs() < 1e-5)).reshape(-1)
+            assert near.double().mean().item() < 1e-3
+            keep = ~near
+        else:
+            keep = torch.ones(rows, dtype=torch.bool, device="cuda")
+        close(dh[keep], rdh[keep], 5e-5, "d loss / d hidden")
+        tol = 5e-4 if bool((~keep).any()) else 5e-5
+        close(pol.action_mean.weight.grad, pol64.action_mean.weight.grad, tol, "action_mean.weight.grad")
+        close(pol.action_mean.bias.grad, pol64.action_mean.bias.grad, tol, "action_mean.bias.grad")
+        close(pol.action_log_std.grad, pol64.action_log_std.grad, tol, "action_log_std.grad")
+        assert pol.action_log_std.grad.shape == pol.action_log_std.shape
+    loss, dh = M.value_head_step(h, val, returns, weight)
+    h64 = h.double().requires_grad_(True)
+    l64 = (val64.value_head(h64) - returns.double()).pow(2).mean()
+    (l64 * weight).backward()
+    assert abs(loss.item() - l64.item()) <= 2e-6 * l64.item()
+    close(dh, h64.grad, 2e-6, "value d loss / d hidden")
+    close(val.value_head.weight.grad, val64.value_head.weight.grad, 2e-5, "value_head.weight.grad")
+    close(val.value_head.bias.grad, val64.value_head.bias.grad, 2e-5, "value_head.bias.grad")
