@@ -567,6 +567,7 @@ class AgentHandMimic:
         async_reward = direct and self.async_reward
         if async_reward:
             self.env.sim.set_async_reward(True)
+        gemm_done = None
         t_host0 = time.perf_counter()
         for t in range(T):
             for gi, (first, count) in enumerate(groups):
@@ -580,7 +581,14 @@ class AgentHandMimic:
                         if fwd is not None:
                             action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl], std=std, eps=noise_all[t, sl])
                         else:
+                            # library GEMMs: never from two streams at once (the BLAS library's stream-K kernels share their
+                            # flag workspace per handle and deadlock when two of them interleave) -- a range's
+                            # forward waits for the other range's previous one; the simulator launches still overlap
+                            if use_streams and gemm_done is not None:
+                                self._streams[gi].wait_event(gemm_done)
                             action = self.policy_net.select_action(state, out=actions[t, sl])
+                            if use_streams:
+                                gemm_done = torch.cuda.Event(); gemm_done.record(self._streams[gi])
                         self.env.step(action, nseq_all[t, sl], nstart_all[t, sl], first, count,
                                       out=(rewards[t, sl], rinfo_all[t, sl], flags_all[t, sl], pct[sl]), want_info=False)
                     else:

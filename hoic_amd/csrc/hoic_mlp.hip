@@ -1133,6 +1133,85 @@ __global__ __launch_bounds__(HEADB_NT) void hoic_head_bwd_kernel(int M, int K, i
     mypart[(long long)N * K + tid] = sb;
   }
 }
+// The same launch for 8 < N <= 32 outputs (the action head) on the matrix core: per row the two products are 2 x 32 x 512
+// multiply-adds -- 227 us per launch as FMAs, where reading h and writing dh once take ~55.  A block of eight wavefronts walks
+// its rows in tiles of 32; wavefront w owns columns [64 w, 64 w + 64) as two 32-column blocks.  Per tile and block, as
+// v_mfma_f32_32x32x2_f32 (A: lane i + 32 s holds A[i][s], B: B[s][j], D[i][j]: lane j + 32 s holds rows 8 q + 4 s + r):
+//   dh tile [32 rows x 32 cols] = sum_t  g[row i][n = 2 t + s]  x  W[n = 2 t + s][col j]        (16 steps; W in 32 registers)
+//   dW block [32 n x 32 cols]  += sum_t  g[row 2 t + s][n = i]  x  h[row 2 t + s][col j]        (16 steps; 2 x 16 accumulators)
+// Both operand layouts of the g tile come from one 32 x 33 float LDS image; h, dh and the partial sums move as 128-byte row
+// segments.  The f32 MFMA is an exact float32 multiply-add chain, so this is the arithmetic of the FMA form in another order.
+#define HEADM_NC 2          // 32-column blocks per wavefront
+#define HEADM_NT 512        // 8 wavefronts x 64 columns = 512 columns per pass
+__global__ __launch_bounds__(HEADM_NT) void hoic_head_bwd_mfma_kernel(int M, int K, int N, int rows_per_block, const float* __restrict__ h, long long ldh,
+                                                                    const float* __restrict__ W, const float* __restrict__ g, long long ldg,
+                                                                    float* __restrict__ dh, long long lddh, float* __restrict__ part) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  __shared__ float gl[32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, s = lane >> 5;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float* mypart = part + (long long)blockIdx.x * (((long long)N * K + N + 1) & ~1LL);
+  for (int kbase = 0; kbase < K; kbase += 512) {
+    const int kc = kbase + wave * 32 * HEADM_NC;
+    float wreg[HEADM_NC][16];
+    f32x16 acc[HEADM_NC];
+#pragma unroll
+    for (int c = 0; c < HEADM_NC; c++) {
+      const int col = min(kc + 32 * c + l32, K - 1);
+#pragma unroll
+      for (int t = 0; t < 16; t++) wreg[c][t] = 2 * t + s < N ? W[(long long)(2 * t + s) * K + col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
+    }
+    float bsum = 0.f;        // bias gradient: wavefront 0, lane n (first pass over the columns only)
+    for (int mt = m0; mt < m1; mt += 32) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < 1024; e += HEADM_NT) {
+        const int r = e >> 5, c = e & 31, row = mt + r;
+        gl[r][c] = (row < m1 && c < N) ? g[(long long)row * ldg + c] : 0.f;
+      }
+      __syncthreads();
+      float ga[16], gb[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) { ga[t] = gl[l32][2 * t + s]; gb[t] = gl[2 * t + s][l32]; }
+      if (kbase == 0 && wave == 0 && s == 0) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) bsum += gl[r][l32];
+      }
+#pragma unroll
+      for (int c = 0; c < HEADM_NC; c++) {
+        if (kc + 32 * c >= K) continue;
+        const int col = kc + 32 * c + l32;
+        float hb[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) hb[t] = h[(long long)min(mt + 2 * t + s, M - 1) * ldh + col];
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+          d = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[t], wreg[c][t], d, 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(gb[t], hb[t], acc[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = mt + 8 * (r >> 2) + 4 * s + (r & 3);
+          if (row < m1) dh[(long long)row * lddh + col] = d[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < HEADM_NC; c++) {
+      if (kc + 32 * c >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = 8 * (r >> 2) + 4 * s + (r & 3);
+        if (n < N) mypart[(long long)n * K + kc + 32 * c + l32] = acc[c][r];
+      }
+    }
+    if (kbase == 0 && wave == 0 && s == 0 && l32 < N) mypart[(long long)N * K + l32] = bsum;
+  }
+}
 extern "C" int32_t hoic_mlp_head_backward(int32_t M, int32_t K, int32_t N, const float* d_h, int64_t ldh, const float* d_W, const float* d_g, int64_t ldg,
                                           float* d_dh, int64_t lddh, float* d_grad, float* d_part, int32_t nblocks, void* stream) {
   if (M <= 0 || K <= 0 || (K & 1) || N <= 0 || N > 32 || nblocks <= 0 || !d_h || !d_W || !d_g || !d_dh || !d_grad || !d_part || (ldh & 1) || (lddh & 1) ||
@@ -1140,8 +1219,13 @@ extern "C" int32_t hoic_mlp_head_backward(int32_t M, int32_t K, int32_t N, const
     hoic_set_error("hoic_mlp_head_backward: K even, N <= 32, 8-byte aligned h / W / dh / part with even leading dimensions"); return HOIC_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int rows = (M + nblocks - 1) / nblocks, nb = (M + rows - 1) / rows;       // nb <= nblocks blocks, the last one ragged
-  if (N <= 8)
+  const int rows = (M + nblocks - 1) / nblocks;
+  int nb = (M + rows - 1) / rows;       // nb <= nblocks blocks, the last one ragged
+  if (N > 8 && (K & 31) == 0) {       // matrix-core form: rows in tiles of 32
+    const int tiles = (M + 31) / 32, nbm = std::min(nblocks, 256), tpb = (tiles + nbm - 1) / nbm;      // one 8-wavefront block per CU
+    nb = (tiles + tpb - 1) / tpb;
+    hipLaunchKernelGGL(hoic_head_bwd_mfma_kernel, dim3(nb), dim3(HEADM_NT), 0, st, M, K, N, 32 * tpb, d_h, (long long)ldh, d_W, d_g, (long long)ldg, d_dh, (long long)lddh, d_part);
+  } else if (N <= 8)
     hipLaunchKernelGGL(hoic_head_bwd_kernel<8>, dim3(nb), dim3(HEADB_NT), 0, st, M, K, N, rows, d_h, (long long)ldh, d_W, d_g, (long long)ldg, d_dh, (long long)lddh, d_part);
   else
     hipLaunchKernelGGL(hoic_head_bwd_kernel<32>, dim3(nb), dim3(HEADB_NT), 0, st, M, K, N, rows, d_h, (long long)ldh, d_W, d_g, (long long)ldg, d_dh, (long long)lddh, d_part);

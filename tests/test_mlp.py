@@ -352,7 +352,7 @@ def test_action_head_kernel_matches_float64(rows, n_out):
 
 
 @gpu
-@pytest.mark.parametrize("rows,n_out", [(50176, 32), (50176, 1), (1003, 32), (37, 1), (600, 6)])
+@pytest.mark.parametrize("rows,n_out", [(50176, 32), (50176, 1), (1003, 32), (37, 1), (600, 6), (4100, 20), (31, 32)])
 def test_head_linear_forward_and_backward_match_float64_autograd(rows, n_out):
     """mlp.head_linear (hoic_mlp_head + hoic_mlp_head_backward: the heads of the f16x3 update, no library GEMM) against
     torch.autograd on a float64 nn.Linear with the same parameters and the same upstream gradient: output, gradient of the
