@@ -114,11 +114,15 @@ def test_forward_dynamics_parity(obj, oracle_lib):
                 continue
         e.set("qacc_warmstart", np.zeros(32)); e.sim_step()
         worst["state"] = max(worst["state"], _rel(out["qpos_out"][i], e.get("qpos")[:33]), _rel(out["qvel_out"][i], e.get("qvel")))
-    assert with_contacts > N // 3 and ncon_mismatch <= 2 and face_ties <= N // 12, (ncon_mismatch, face_ties)
+    print(f"{obj}: envs with contacts {with_contacts}/{N}, contact-count mismatches {ncon_mismatch}, face ties {face_ties}, worst {worst}")
+    # measured (round 3): 0 / 2 / 0 contact-count mismatches and 0 / 0 / 1 face ties for box / bottle / banana
+    assert with_contacts > N // 3 and ncon_mismatch <= 2 and face_ties <= 2, (ncon_mismatch, face_ties)
     assert worst["kin"] < 2e-6 and worst["M"] < 2e-6 and worst["bias"] < 2e-6, worst
     # (mesh objects: hundreds of hull faces, so more selections sit within float32 rounding of a tie; the contact frame
     #  then differs by up to the 2e-5 admitted above and the state after the substep follows it)
-    assert worst["a0"] < 2e-3 and worst["qacc"] < 2e-3 and worst["state"] < (6e-5 if obj == "box" else 2e-4), worst
+    # measured: a0 5.9e-5, qacc 5.8e-4 (relative to the largest entry: float32 solves of a 32 x 32 system with
+    # condition ~1e4), state after the substep 1.2e-5 / 5.3e-5 / 1.1e-5 -- the bounds are twice that
+    assert worst["a0"] < 1.5e-4 and worst["qacc"] < 1.2e-3 and worst["state"] < (3e-5 if obj == "box" else 1.1e-4), worst
 
 
 def test_box_box_contact_sets(box_blob, oracle_lib, setup):
