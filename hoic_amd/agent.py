@@ -185,8 +185,9 @@ class PPOLearner:
         return time.time() - t0
 
     def _optimize_f16x3(self, inp, actions, advantages, returns, weight, policy_step, vparams, pparams):
-        """optimize() with both MLP bodies on the f16x3 GEMMs: the bodies' forward returns the last hidden activation as
-        a leaf, PyTorch runs head + loss + their backward, the bodies' backward fills the MLP gradients.
+        """optimize() with both MLP bodies on the f16x3 GEMMs: the bodies' forward returns the last hidden activation,
+        head + loss + their backward pass are four float32 launches of this package (mlp.ppo_head_step / value_head_step),
+        the bodies' backward fills the MLP gradients; Adam is PyTorch's fused step.
 
         ``overlap_value_update``: the two networks never feed each other during the epochs (the advantages were formed
         before them), so the five policy steps run first and the five value steps are enqueued on a side stream: the

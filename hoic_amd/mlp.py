@@ -5,9 +5,11 @@ for a fixed batch through ``hoic_mlp_gemm``: every float32 operand is carried as
 (x 2^e = hi + lo, 22 significand bits) and every product sum is three f16 MFMAs into one float32 accumulator, so the
 result has float32-class accuracy at 16/3 of the f32 MFMA rate.  Bias + GELU + GELU' + the split of the next operand are
 fused into the forward epilogue, ``* GELU'`` + split into the backward one; weight gradients are split-K GEMMs over
-the batch with a fixed-order slab reduction (deterministic).  The small heads (512 -> 32, 512 -> 1), the losses and the
-optimisers stay in PyTorch: ``forward()`` returns the last hidden activation as a float32 leaf, ``backward(dH)``
-consumes its gradient and fills ``.grad`` of the MLP's parameters.
+the batch with a fixed-order slab reduction (deterministic).  ``forward()`` returns the last hidden activation as a float32
+tensor, ``backward(dH)`` consumes its gradient and fills ``.grad`` of the MLP's parameters.  The small heads (512 -> 32,
+512 -> 1), the two losses and their backward pass are float32 kernels of their own (``ppo_head_step``, ``value_head_step``:
+``hoic_mlp_head``, ``hoic_mlp_ppo_loss``, ``hoic_mlp_value_loss``, ``hoic_mlp_head_backward``; ``head_linear`` is the same
+head as a differentiable function for callers that build their loss with autograd); the optimisers stay PyTorch's.
 
 There is no fallback in here: without the HIP library / a GPU the constructor raises.
 """
