@@ -3,9 +3,12 @@ quality gate behind scripts/eval_handmimic.py:135-306.
 
 The reference walks the qpos sequence frame by frame through ``MjSim.forward()`` and loops over ``data.contact`` in
 Python.  Here all T frames go through ONE launch of the probe kernel (``BatchedSim.probe_forward``: kinematics +
-collision of T independent states on the GPU) and the metric arithmetic is vectorised NumPy; the non-negative QP
-of ``solve_force`` is solved exactly (NNLS on the Cholesky factor — the problem is strictly convex, so the optimum
-is the one daqp returns).  ``frames`` lets tests feed recorded contacts instead of a simulator.
+collision of T independent states on the GPU) and the metric arithmetic is vectorised NumPy.  The non-negative QP
+of ``solve_force`` is the residual-force QP of the env (same objective, mu = 1, no linear term): with a simulator the QPs
+of all frames are ONE launch of the step kernel's own float64 solver (``hoic_probe_qp``; SURVEY.md §8(f) rank 1 "the same
+NNQP kernel"), without one (``frames=``) each is solved exactly on the host (NNLS on the Cholesky factor) — the problem is
+strictly convex, so either optimum is the one daqp returns.  ``frames`` lets tests feed recorded contacts instead of a
+simulator.
 
 Same method names and return values as the reference.  ``eval_penetration`` (signed distance to the *visual* mesh
 through pysdf) is replaced by the hull form: depth below the nearest face of the object's convex collision hulls
@@ -44,6 +47,7 @@ class PhysMetrics:
         self.obj_mass = float(A["body_mass"][ob]); self.obj_inertia = np.asarray(A["body_inertia"][ob], dtype=np.float64)
         og = self.obj_geom_range[0]
         self.box_size = np.asarray(A["geom_size"][og], dtype=np.float64)
+        self.sim = sim
         if frames is None:
             if sim is None:
                 raise ValueError("PhysMetrics needs a simulator (sim=) or recorded frames (frames=)")
@@ -154,11 +158,44 @@ class PhysMetrics:
         x = _exact_nnqp(Q, p)
         return float(np.linalg.norm(Jf @ x - target_force) + np.linalg.norm(Jt @ x - target_torque))
 
-    def eval_stable(self):                                  # :233-251
+    QP_MAX_CONTACTS = 19          # hoic_probe_qp: <= 380 columns = 19 contacts x 5 points x 4 cone edges
+
+    def rest_forces_device(self, F, tau):
+        """solve_force of every frame in one hoic_probe_qp launch: the columns (cone edge; r x cone edge) of the 5 points x 4
+        edges of every hand-object contact, float32 as the kernel takes them, the QP itself in float64 on the device.
+        Frames with more hand-object contacts than the kernel's column capacity go through the host solver."""
+        T, K = self.contacts.shape[:2]
+        m = self._ho_mask()
+        order = np.argsort(~m, axis=1, kind="stable")                       # the frame's hand-object contacts first
+        c = np.take_along_axis(self.contacts, order[:, :, None], 1)
+        n_c = m.sum(1)
+        Kq = int(min(max(n_c.max(), 1), self.QP_MAX_CONTACTS))
+        pos, fr = c[:, :Kq, 3:6], c[:, :Kq, 6:15].reshape(T, Kq, 3, 3)
+        mu, dx = 1.0, 0.0025
+        inv = 1.0 / np.sqrt(1.0 + mu * mu)
+        A = np.stack([fr[:, :, 0] + mu * fr[:, :, 1], fr[:, :, 0] - mu * fr[:, :, 1],
+                      fr[:, :, 0] + mu * fr[:, :, 2], fr[:, :, 0] - mu * fr[:, :, 2]], 2) * inv          # [T, Kq, 4, 3]
+        z = np.zeros_like(fr[:, :, 1])
+        d = np.stack([z, fr[:, :, 1] * dx, -fr[:, :, 1] * dx, fr[:, :, 2] * dx, -fr[:, :, 2] * dx], 2)    # [T, Kq, 5, 3]
+        r = pos[:, :, None] + d - self.qpos_seq[:, None, None, -7:-4]                                     # [T, Kq, 5, 3]
+        cols = np.zeros((T, Kq, 5, 4, 7), dtype=np.float32)
+        cols[..., 0:3] = A[:, :, None]
+        cols[..., 3:6] = np.cross(r[:, :, :, None], A[:, :, None])
+        lam, _ = self.sim.probe_qp(cols.reshape(T, Kq * 20, 7), (20 * np.minimum(n_c, Kq)).astype(np.int32), np.concatenate([F, tau], 1))
+        rest = 0.5 * (np.linalg.norm(lam[:, :3], axis=1) + np.linalg.norm(lam[:, 3:], axis=1))
+        for t in np.nonzero((n_c > self.QP_MAX_CONTACTS) | (n_c == 0))[0]:
+            rest[t] = self.solve_force(F[t], tau[t], self.contacts[t][m[t]][:, 3:15], self.qpos_seq[t, -7:-4])
+        return rest
+
+    def eval_stable(self, device=None):                     # :233-251
+        """``device``: solve the frames' QPs on the GPU (default: whenever a simulator was given)"""
         F, tau = self.obtain_target_ft()
         m = self._ho_mask()
-        rest = np.array([self.solve_force(F[t], tau[t], self.contacts[t][m[t]][:, 3:15], self.qpos_seq[t, -7:-4])
-                         for t in range(self.qpos_seq.shape[0])]) / self.obj_mass
+        if (self.sim is not None) if device is None else device:
+            rest = self.rest_forces_device(F, tau) / self.obj_mass
+        else:
+            rest = np.array([self.solve_force(F[t], tau[t], self.contacts[t][m[t]][:, 3:15], self.qpos_seq[t, -7:-4])
+                             for t in range(self.qpos_seq.shape[0])]) / self.obj_mass
         out = rest.copy()
         out[rest > 0.01] = 1
         out[rest < 0.01] = 0

@@ -79,6 +79,33 @@ def test_metrics_on_device_match_oracle_contacts(box_blob, box_model, oracle_lib
 
 
 @pytest.mark.gpu
+def test_eval_stable_solves_its_qps_on_the_device(box_blob, box_model):
+    """PhysMetrics.eval_stable with a simulator: the force-closure QPs of all frames in one hoic_probe_qp launch (the step
+    kernel's own float64 active-set solver on float32 columns) against the exact host solution (NNLS on the Cholesky factor)
+    of the same problems -- residuals to 5e-5 of the target wrench (measured 2e-5: the columns enter in float32), identical stable / unstable labels away from the
+    threshold; frames without hand-object contact and with contacts are both present."""
+    from hoic_amd import lib, motions
+    ex = motions.synthetic_expert(box_model, 2, 300, grasp="closed")
+    s = ex[0]
+    T = 120
+    q = np.concatenate([s["hand_dof_seq"][100:100 + T], s["obj_pose_seq"][100:100 + T]], 1)
+    sim = lib.BatchedSim(box_blob, 2)
+    pm = metrics.PhysMetrics(box_model, q, sim=sim)
+    n_c = np.array(pm.eval_contact_point())
+    assert (n_c > 0).sum() > 20 and n_c.max() >= 3
+    F, tau = pm.obtain_target_ft()
+    m = pm._ho_mask()
+    host = np.array([pm.solve_force(F[t], tau[t], pm.contacts[t][m[t]][:, 3:15], q[t, -7:-4]) for t in range(T)])
+    dev = pm.rest_forces_device(F, tau)
+    scale = np.linalg.norm(F, axis=1) + np.linalg.norm(tau, axis=1)
+    assert np.abs(dev - host).max() < 5e-5 * scale.max(), np.abs(dev - host).max()
+    a, b = pm.eval_stable(), pm.eval_stable(device=False)
+    away = np.abs(host / pm.obj_mass - 0.01) > 1e-4
+    assert np.array_equal(a[away], b[away]) and away.mean() > 0.9
+    assert np.all(dev <= scale + 1e-9) and (dev[n_c > 0] < 0.9 * scale[n_c > 0]).any()      # contacts do explain part of the wrench
+
+
+@pytest.mark.gpu
 def test_preprocess_seq_on_device(box_blob, box_model):
     """Expert preprocessing: the FK of every frame through one probe-kernel launch
     equals the float64 host FK."""
