@@ -534,8 +534,7 @@ class AgentHandMimic:
         # The batch is stepped as n_groups independent env ranges, each on its own stream: the physics launch of one
         # range ends with a tail of a few long-running envs (contacts), during which the GPU runs the other range's
         # policy forward and physics.  The reference's sampler is asynchronous in the same way (one worker per
-        # thread, each with its own env).  The running observation filter is shared: its updates are chained
-        # range after range with events, so every state is normalised with the statistics of all earlier ranges.
+        # thread, each with its own env).  Every range updates its own fork of the running observation filter (below).
         groups = self._groups()
         G = len(groups)
         use_streams = G > 1
@@ -554,15 +553,20 @@ class AgentHandMimic:
         pct = torch.empty(N, device=dev, dtype=torch.float32)
         nseq_all, nstart_all = self._draw_episodes(T * N)
         nseq_all, nstart_all = nseq_all.view(T, N), nstart_all.view(T, N)
-        if use_streams:
-            main = torch.cuda.current_stream(dev)
-            for st_ in self._streams:
-                st_.wait_stream(main)
         # The observation filter of a pipelined rollout: every env range updates its own fork of the filter with its own
         # observations (the reference's sampler threads each run their own copy, agent.py:64-120) and the forks are merged
         # after the rollout -- the same final statistics as one shared filter, and no dependency between the ranges'
         # chains (with a shared filter every range's update waited for the previous range's: a convoy).
-        forks = [self.running_state.fork() for _ in groups] if use_streams else None
+        # The forks are made on the main stream BEFORE the side streams take their wait point on it: a fork's state is
+        # the first thing a range's chain reads.
+        racy = bool(os.environ.get("HOIC_FORK_AFTER_WAIT"))      # attribution switch only (tools/reward_curve.py "+racy"): round 3's order
+        forks = [self.running_state.fork() for _ in groups] if (use_streams and not racy) else None
+        if use_streams:
+            main = torch.cuda.current_stream(dev)
+            for st_ in self._streams:
+                st_.wait_stream(main)
+        if use_streams and racy:
+            forks = [self.running_state.fork() for _ in groups]
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
         async_reward = direct and self.async_reward

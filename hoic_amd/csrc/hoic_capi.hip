@@ -1,7 +1,7 @@
 // hoic_capi.hip — kernels + the C-ABI of include/hoic.h (libhoic_hip.so, gfx950 only).
 //
 // One workgroup = one wavefront = one environment; a launch covers all envs (grid = n_envs).  Inside a
-// launch the whole env step (HandObjMimic4.step, uhc/envs/ho_im4.py:611-662) runs fused: 15 substeps of
+// launch the whole env step (HandObjMimic4.step, uhc/envs/ho_im4.py:611-662) runs as two kernels: 15 substeps of
 // control glue + dynamics + contact solve + integration, then contact averaging, the residual-force QP,
 // termination, reward and the 617-float observation.  There is no CPU path in this library.
 #include <hip/hip_runtime.h>
@@ -28,43 +28,41 @@ extern "C" const char* hoic_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------------ kernels
 __device__ __forceinline__ void load_state(const DevModel& m, const DevState& st, Work& w, int env) {
   const int tid = threadIdx.x;
-  if (tid < NQP) { w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid]; w.qlag[tid] = as_global(st.qlag)[(size_t)env * NQP + tid]; }
+  if (tid < NQP) w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
   if (tid < NV) {
-    w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid]; w.vlag[tid] = as_global(st.vlag)[(size_t)env * NV + tid];
-    w.warm[tid] = as_global(st.warm)[(size_t)env * NV + tid];
-    w.ctrl[tid] = 0.f; w.applied[tid] = 0.f; w.qacc[tid] = 0.f;
+    w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid];
+    w.qacc[tid] = as_global(st.warm)[(size_t)env * NV + tid];       // the warm start of the first solve
+    w.applied[tid] = 0.f;
   }
-  if (tid < NHG) { for (int i = 0; i < 12; i++) w.rec_sum[tid][i] = 0.f; w.rec_cnt[tid] = 0; }
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; w.capped = 0; }
   wsync();
 }
-__device__ __forceinline__ void store_state(const DevState& st, const Work& w, int env) {
+// lag_too: the state is also the state before the last integration (after a reset)
+template <class W> __device__ __forceinline__ void store_state(const DevState& st, const W& w, int env, bool lag_too) {
   const int tid = threadIdx.x;
-  if (tid < NQP) { as_global(st.qpos)[(size_t)env * NQP + tid] = w.qpos[tid]; as_global(st.qlag)[(size_t)env * NQP + tid] = w.qlag[tid]; }
+  if (tid < NQP) { as_global(st.qpos)[(size_t)env * NQP + tid] = w.qpos[tid]; if (lag_too) as_global(st.qlag)[(size_t)env * NQP + tid] = w.qpos[tid]; }
   if (tid < NV) {
-    as_global(st.qvel)[(size_t)env * NV + tid] = w.qvel[tid]; as_global(st.vlag)[(size_t)env * NV + tid] = w.vlag[tid];
-    as_global(st.warm)[(size_t)env * NV + tid] = w.warm[tid];
+    as_global(st.qvel)[(size_t)env * NV + tid] = w.qvel[tid]; if (lag_too) as_global(st.vlag)[(size_t)env * NV + tid] = w.qvel[tid];
+    as_global(st.warm)[(size_t)env * NV + tid] = w.qacc[tid];
   }
 }
 
-// velocity / acceleration stages of mj_forward on the state in w.qpos/w.qvel with w.ctrl / w.applied / w.warm set
-// (dev_forward_kin has run on the same state)
-__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M) {
+// velocity / acceleration stages of mj_forward on the state in w.qpos/w.qvel with w.applied (applied + actuator forces) and the
+// warm start (w.qacc) set (dev_forward_kin has run on the same state); a0_out: the unconstrained acceleration of dof lane & 31
+__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, float* a0_out) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   float fs = 0.f;
-  if (d < m.nv) {
-    const int ai = w.k_act[d];
-    const float act = ai >= 0 ? w.ctrl[ai] : 0.f;
-    fs = -w.k_damp[d] * w.qvel[d] - w.bias[d] + w.applied[d] + act;   // passive (joint damping) - bias + applied + actuation
-  }
-  if (tid < NV) w.fsmooth[tid] = fs;
+  if (d < m.nv) fs = -m.dof_damping[d] * w.qvel[d] - w.bias[d] + w.applied[d];   // passive (joint damping) - bias + applied + actuation
   PT(20);
   float a0 = dev_hsolve<false>(m, w, M, 0.f, m.nv, fs); PT(8);     // unconstrained acceleration
-  if (tid < NV) w.asmooth[tid] = (tid < m.nv) ? a0 : 0.f;
+  a0 = (d < m.nv) ? a0 : 0.f;
+  if (a0_out) *a0_out = a0;
+  if (tid < NV) w.sc.vec.x[tid] = a0;           // a_smooth as an LDS vector for the first row evaluation (dead once Newton starts)
   wsync();
   RowK rk;
-  dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
-  dev_solve(m, w, M, rk, cfg.c.solver_iterations); PT(9);
+  float aref_c[NCSLOT];
+  dev_make_constraint(m, w, rk, aref_c, w.qpos, w.qvel); PT(7);
+  dev_solve(m, w, M, rk, aref_c, fs, a0, cfg.c.solver_iterations); PT(9);
   // mj_checkPos / mj_checkVel / mj_checkAcc [MJ-doc]: a non-finite or huge (> 1e10) entry of qpos, qvel or qacc is MuJoCo's
   // "Nan, Inf or huge value" warning, which mujoco_py raises and the env turns into fail = True (ho_im4.py:635-637)
   float bad = 0.f;
@@ -72,20 +70,23 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
     const float a = w.qacc[tid], v = w.qvel[tid];
     bad = (isfinite(a) && fabsf(a) < 1e10f && isfinite(v) && fabsf(v) < 1e10f) ? 0.f : 1.f;
   }
-  if (tid >= 32 && tid - 32 < m.nq) { const float q = w.qpos[tid - 32]; if (!(isfinite(q) && fabsf(q) < 1e10f)) bad = 1.f; }
+  for (int i = tid; i < m.nq; i += NT) { const float q = w.qpos[i]; if (!(isfinite(q) && fabsf(q) < 1e10f)) bad = 1.f; }
   return !(wave_max(bad) > 0.f);
 }
 
-// semi-implicit Euler with implicit joint damping; also records the pre-integration state (lag) and warm start
-__device__ __forceinline__ void dev_euler(const DevModel& m, Work& w, const MReg& M) {
+// semi-implicit Euler with implicit joint damping; the pre-integration state goes to (gqlag, gvlag) in global memory (the env's
+// rows of DevState::qlag / vlag; null: not recorded), the acceleration stays in w.qacc as the next warm start
+__device__ __forceinline__ void dev_euler(const DevModel& m, Work& w, const MReg& M, GPTR(float) gqlag, GPTR(float) gvlag) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const float h = m.timestep;
-  const float rhs = (d < m.nv) ? (w.fsmooth[d] + w.fcon[d]) : 0.f;
+  const float rhs = (d < m.nv) ? w.ftot[d] : 0.f;
+  const float damp = (d < m.nv) ? m.dof_damping[d] : 0.f;
   PT(20);
-  const float acc = dev_hsolve<false>(m, w, M, h * w.k_damp[d], m.nv, rhs);
-  if (tid < NQP) w.qlag[tid] = w.qpos[tid];
-  if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = w.qacc[tid]; }
-  wsync();
+  const float acc = dev_hsolve<false>(m, w, M, h * damp, m.nv, rhs);
+  if (gqlag) {
+    if (tid < NQP) gqlag[tid] = w.qpos[tid];
+    if (tid < NV) gvlag[tid] = w.qvel[tid];
+  }
   if (tid < m.nv) w.qvel[tid] += h * acc;
   wsync();
   if (tid < m.njnt) {
@@ -109,33 +110,35 @@ __device__ __forceinline__ void dev_euler(const DevModel& m, Work& w, const MReg
 
 // ---- what follows the substeps of an env step (HandObjMimic4.step after do_simulation, ho_im4.py:631-662): contact
 // averaging, the residual-force QP (float64), termination, reward, the optional in-launch reset and the 617-float
-// observation.  Expects in the workspace: final qpos / qvel, the clipped action, body / geom poses and the contact sums
-// of the last forward pass, the 15-substep finite differences in sc.post.
-// PART: POST_ALL = all of it (one kernel behind the substeps, or fused into the substep kernel); the split form
-// (hoic_set_async_reward) runs POST_A -- termination, in-launch reset, observation: what the next policy forward waits for --
-// at the end of the substep kernel and POST_B -- contact classification, residual-force QP, reward: needed only when the
+// observation.  Expects in the workspace: final qpos / qvel, body / geom poses of the last forward pass and -- for the reward
+// parts -- the clipped action, the contact sums and the 15-substep finite differences in sc.post.
+// PART: POST_ALL = all of it (one kernel behind the substeps); the split form (hoic_set_async_reward) runs POST_A --
+// termination, in-launch reset, observation: what the next policy forward waits for -- at the end of the substep kernel (on
+// its slim workspace W = Work) and POST_B -- contact classification, residual-force QP, reward: needed only when the
 // rollout's rewards are read -- in the post-step kernel on a side stream, from the hand-over record `rec` (which then also
 // carries the pre-reset state and expert view).  Same arithmetic in every form; POST_B cannot fail a step retroactively
 // (a non-finite QP score, never observed, zeroes the score in every form and fails the step in POST_ALL only).
 enum { POST_ALL = 0, POST_A = 1, POST_B = 2 };
-template <int PART>
-__device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig& cfg, Work& w, const DevExpert& ex, const DevState& st,
+template <int PART, class W>
+__device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig& cfg, W& w, const DevExpert& ex, const DevState& st,
                                              ExpertView& ev, int env, int io, bool ok, int solver_iter, const float* vf, const float* vt,
                                              float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
                                              int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
                                              const int* __restrict__ next_start, GPTR(float) rec) {
   const int tid = threadIdx.x;
   float rfc_score = 0.f;
-  if (PART != POST_A && ok) {
-    dev_classify_contact(m, w);                                                                // :562
-    if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
-    if (!isfinite(rfc_score)) { if (PART == POST_ALL) ok = false; rfc_score = 0.f; }
+  if constexpr (PART != POST_A) {
+    if (ok) {
+      dev_classify_contact(m, w);                                                                // :562
+      if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
+      if (!isfinite(rfc_score)) { if (PART == POST_ALL) ok = false; rfc_score = 0.f; }
+    }
+    asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
   }
-  if (PART != POST_A) asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
   if (PART != POST_B) ev.cur_t += 1;                                                            // :641 (POST_B: the record's view is advanced already)
   const int expert_len = ev.len - ev.start;
   const bool end = ev.cur_t >= expert_len - cfg.c.future_w_size - 1;                            // :657
-  if (PART != POST_A) {
+  if constexpr (PART != POST_A) {
     float rw[10];
     dev_reward(m, cfg, w, ev, rfc_score, rw);
     float r = rw[0];
@@ -176,7 +179,7 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
     if (PART == POST_ALL && tid == 6) as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0;
     ev.off = as_global(ex.seq_off)[ns]; ev.len = as_global(ex.seq_len)[ns]; ev.start = nst; ev.cur_t = 0;
     if (tid == 0) { as_global(st.seq)[env] = ns; as_global(st.start)[env] = nst; as_global(st.lag_valid)[env] = 0; }
-    store_state(st, w, env);
+    store_state(st, w, env, true);
   }
   dev_write_obs(m, w, ev, obs + (size_t)io * HOIC_OBS_DIM);
   if (tid == 0) as_global(st.cur_t)[env] = ev.cur_t;
@@ -185,18 +188,15 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
 // ---- kernel 1 of a step: the 15 substeps (control glue + dynamics + contact solve + integration), f32.
 // Leaves the new state in HBM and a hand-over record (lagged body / geom poses, contact sums, 15-substep finite
 // differences) for the post-step kernel.
-template <int MODE>      // 0: substeps + hand-over record, 1: + the whole post-step work (FUSED), 2: + its part POST_A (split form)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+// THREE wavefronts per SIMD: the 12.5 KB workspace puts 12 envs on a CU and the kernel is held to 168 registers (round 3:
+// 19.98 KB, 200 registers, two wavefronts); the work is a long dependent chain per env, throughput follows resident waves.
+template <int MODE>      // 0: substeps + hand-over record, 2: + the post-step part POST_A (split form)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void hoic_substep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                           const DevExpert* __restrict__ exq, const DevState* __restrict__ stq,
                                                           const float* __restrict__ action, int first, int use_order, int use_lag,
                                                           float* __restrict__ obs, float* __restrict__ reward, float* __restrict__ reward_info,
                                                           int* __restrict__ flags, float* __restrict__ percent, const int* __restrict__ next_seq,
                                                           const int* __restrict__ next_start, int n_envs, int post_buf) {
-  // FUSED (HOIC_FUSED_STEP=1): the post-step work (dev_poststep) runs at the end of this launch, on the
-  // workspace as it stands, instead of in hoic_poststep_kernel behind a 2.8 KB hand-over record per env.  One launch
-  // per env step, but 153 KB of code, 256 registers and 288 B of scratch; measured equal to the two-launch form both
-  // for whole-batch steps and in the two-range rollout, so the two-launch form stays the default.
-  constexpr bool fused = MODE == 1;
   // the expert / state pointer tables stay in device memory (22 pointers would otherwise be pinned in SGPRs)
   __shared__ Work w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp; const DevExpert& ex = *exq; const DevState& st = *stq;
@@ -215,19 +215,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (tid == 0) { for (int i = 0; i < 24; i++) w.pt[i] = 0; w.pt_last = (long long)__builtin_readcyclecounter(); }
   wsync();
 #endif
-  if (tid < NV) w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);   // ho_im4.py:613
-  wsync();
+  GPTR(const float) act = as_global(action) + (size_t)io * HOIC_ACT_DIM;       // clipped where it is read (ho_im4.py:613)
   const int seq = as_global(st.seq)[env];
   ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], as_global(st.start)[env], as_global(st.cur_t)[env]};
   float vf[3], vt[3];
   for (int i = 0; i < 3; i++) {
-    vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * w.action[m.nu + i] : 0.f;     // :622-623
-    vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * w.action[m.nu + 3 + i] : 0.f;
+    vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * fminf(fmaxf(act[m.nu + i], -1.f), 1.f) : 0.f;     // :622-623
+    vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * fminf(fmaxf(act[m.nu + 3 + i], -1.f), 1.f) : 0.f;
   }
   int* ovf = (int*)&as_global(st.diag)[2 * env];
   int ncapped = 0;
   GPTR(float) post = as_global(st.post) + ((size_t)post_buf * n_envs + env) * PB_SIZE;
   GPTR(float) oldg = as_global(st.oldg) + (size_t)env * OG_SIZE;
+  GPTR(float) gqlag = as_global(st.qlag) + (size_t)env * NQP;
+  GPTR(float) gvlag = as_global(st.vlag) + (size_t)env * NV;
+  // record_contact's sums of this env step accumulate in the record itself
+  for (int k = tid; k < NHG * 13; k += NT) post[PB_REC + k] = 0.f;
+  static_assert(PB_RECCNT == PB_REC + NHG * 12, "contact sums and counts are contiguous");
   // One loop, three modes, so that every stage has a single (inlined) call site:
   //   mode 0  the forward pass on the lagged state: quantities of the previous forward pass (one-substep lag,
   //           SURVEY.md row Q1) are recomputed instead of being persisted
@@ -269,23 +273,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const DevModel& ml = *(const DevModel*)mq; const DevConfig& cl = *(const DevConfig*)cq;
     PT(0);
     if (mode == 1) {
-      dev_record_contact(ml, w); PT(2);           // :543 (contacts of the previous forward pass)
-      dev_pd_torque(ml, cl, w, M, ev); PT(1);     // :518-523
-      dev_applied(ml, cl, w, vf, vt);             // :526-540
+      dev_record_contact(ml, w, post); PT(2);          // :543 (contacts of the previous forward pass)
+      dev_pd_torque(ml, cl, w, M, ev, act); PT(1);     // :518-523
+      dev_applied(ml, cl, w, vf, vt);                  // :526-540
     }
-    dev_forward_kin(ml, cl, w, M, mode == 0 ? w.qlag : w.qpos, mode == 0 ? w.vlag : w.qvel, tid == 0 ? ovf : nullptr);
+    if (mode == 0) {   // the lagged pass runs on (qlag, vlag): into the workspace's state for the pass, the state proper comes back below
+      if (tid < NQP) w.qpos[tid] = gqlag[tid];
+      if (tid < NV) w.qvel[tid] = gvlag[tid];
+      wsync();
+    }
+    dev_forward_kin(ml, cl, w, M, w.qpos, w.qvel, tid == 0 ? ovf : nullptr);
     if (mode == 0) {
       for (int g = tid; g < ml.ngeom; g += NT) {
         for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
         for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
       }
+      if (tid < NQP) w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
+      if (tid < NV) w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid];
+      wsync();
       old_objvel = (tid < 6) ? w.qvel[ml.nv - 6 + tid] : 0.f;
       mode = 1;
       if (nsub <= 0) break;
       continue;
     }
     if (mode == 2) break;
-    ok = dev_forward_dyn(ml, cl, w, M);       // :545 mj_step = forward ...
+    ok = dev_forward_dyn(ml, cl, w, M, nullptr);       // :545 mj_step = forward ...
     ncapped += w.capped;
 #ifdef HOIC_TRACE_DISPATCH
     trace_ncon += w.ncon; trace_iter += w.solver_iter; trace_ncon_max = max(trace_ncon_max, w.ncon);
@@ -293,52 +305,54 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (done_sub >= nsub - 1) trace_last = w.solver_iter * 100 + w.ncon;
 #endif
     if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
-      if (tid < NQP) w.qpos[tid] = w.qlag[tid];
-      if (tid < NV) { w.qvel[tid] = w.vlag[tid]; w.warm[tid] = 0.f; }
+      if (tid < NQP) w.qpos[tid] = gqlag[tid];
+      if (tid < NV) { w.qvel[tid] = gvlag[tid]; w.qacc[tid] = 0.f; }
       wsync();
       mode = 2;
       continue;
     }
-    dev_euler(ml, w, M); PT(10);              //              ... + Euler
+    dev_euler(ml, w, M, gqlag, gvlag); PT(10);       //              ... + Euler
     if (++done_sub >= nsub) break;
   }
   PT(0);
-  {   // 15-substep finite differences (:554-559): to the post-step workspace (fused) or the hand-over record
+  {   // 15-substep finite differences (:554-559) -> the hand-over record; the geom poses of the last forward pass -> oldg
     const float dt = (float)nsub * m.timestep, idt = ok ? 1.f / dt : 0.f;
-    if (tid < 6) {
-      const float v = ok ? (w.qvel[m.nv - 6 + tid] - old_objvel) * idt : 0.f;                           // :554
-      if (fused) w.sc.post.obj_avg_acc[tid] = v; else post[PB_OBJACC + tid] = v;
-    }
+    const bool hand_over = ok && nsub > 0;
+    if (tid < 6) post[PB_OBJACC + tid] = ok ? (w.qvel[m.nv - 6 + tid] - old_objvel) * idt : 0.f;                   // :554
     for (int g = tid; g < m.ngeom; g += NT) {
       float gv[3] = {0.f, 0.f, 0.f}, ga[3] = {0.f, 0.f, 0.f};
       if (ok) {
+        // the geom's rotation matrix from its body's pose (the LDS copy of the forward pass lived only until the collision
+        // stage: same arithmetic as dev_kinematics step 3c)
+        const int b = m.geom_bodyid[g];
+        const float gq[4] = {m.geom_quat[g][0], m.geom_quat[g][1], m.geom_quat[g][2], m.geom_quat[g][3]};
+        float qg[4], Rg[9];
+        mulquat(w.xquat[b], gq, qg);
+        quat2mat(qg, Rg);
         for (int i = 0; i < 3; i++) gv[i] = (w.gxpos[g][i] - oldg[g * 12 + i]) * idt;                  // :555
         float Rd[9], aa[3], Ro[9];
         for (int i = 0; i < 9; i++) Ro[i] = oldg[g * 12 + 3 + i];
         for (int i = 0; i < 3; i++)
           for (int j = 0; j < 3; j++) {
             float sm = 0.f;
-            for (int k = 0; k < 3; k++) sm += w.gxmat[g][3 * i + k] * Ro[3 * j + k];
+            for (int k = 0; k < 3; k++) sm += Rg[3 * i + k] * Ro[3 * j + k];
             Rd[3 * i + j] = sm;
           }
         dev_matrix_to_axis_angle(Rd, aa);                                                         // :556-559
         for (int i = 0; i < 3; i++) ga[i] = aa[i] * idt;
+        if (hand_over) {     // (it ran on the state that is now qlag, vlag: the next launch's "poses at launch start")
+          for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
+          for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = Rg[i];
+        }
       }
-      for (int i = 0; i < 3; i++) {
-        if (fused) { w.sc.post.gvel[g][i] = gv[i]; w.sc.post.gangvel[g][i] = ga[i]; }
-        else { post[PB_GVEL + g * 3 + i] = gv[i]; post[PB_GANGVEL + g * 3 + i] = ga[i]; }
-      }
+      for (int i = 0; i < 3; i++) { post[PB_GVEL + g * 3 + i] = gv[i]; post[PB_GANGVEL + g * 3 + i] = ga[i]; }
     }
   }
-  if (!fused) {
-    if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
-    for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
-    for (int k = tid; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
-    for (int k = tid; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
-    for (int k = tid; k < NHG * 12; k += NT) post[PB_REC + k] = w.rec_sum[k / 12][k % 12];
-    if (tid < NHG) post[PB_RECCNT + tid] = (float)w.rec_cnt[tid];
-  }
-  store_state(st, w, env);
+  if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
+  for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
+  for (int k = tid; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
+  for (int k = tid; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
+  store_state(st, w, env, false);
   if (ok && nsub > 0) {       // hand the last forward pass over to the next launch (it ran on the state that is now qlag, vlag)
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) lag[LG_M + reg * NT + tid] = M.r[reg];
@@ -351,19 +365,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int i = 0; i < 9; i++) lag[LG_CFRAME + tid * 9 + i] = w.c_frame[tid][i];
       lag[LG_CGEOM + tid] = (float)((int)w.c_g1[tid] | ((int)w.c_g2[tid] << 8));
     }
-    for (int g = tid; g < m.ngeom; g += NT) {
-      for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
-      for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
-    }
   }
   if (tid == 0) { as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0; if (ncapped) as_global(st.diag)[2 * env + 1] += ncapped; }
   const long long clk1 = (long long)__builtin_readcyclecounter();
   if (tid == 0) as_global(st.cost)[env] = (unsigned)((clk1 - clk0) >> 6);
   if (MODE != 0) {
     wsync();
-    dev_poststep<MODE == 1 ? POST_ALL : POST_A>(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, vf, vt, obs, reward, reward_info, flags, percent,
-                                                next_seq, next_start, post);
-    if (MODE == 1 && tid == 0) as_global(st.cost)[n_envs + env] = (unsigned)(((long long)__builtin_readcyclecounter() - clk1) >> 6);
+    dev_poststep<POST_A>(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, vf, vt, obs, reward, reward_info, flags, percent,
+                         next_seq, next_start, post);
   }
 #ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock
   if (tid == 0) {
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
                                                            float* __restrict__ percent, const int* __restrict__ next_seq,
                                                            const int* __restrict__ next_start, int first, int use_order, int n_envs, int post_buf) {
-  __shared__ Work w;
+  __shared__ PostWork w;
   const DevModel& m = *mp; const DevConfig& cfg = *cp;
   const int env = use_order ? as_global(st.order)[n_envs + blockIdx.x] : first + (int)blockIdx.x, io = env - first, tid = threadIdx.x;
   const long long clk0 = (long long)__builtin_readcyclecounter();
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (tid < NQP) w.qpos[tid] = PART == POST_B ? post[PB_QPOS + tid] : as_global(st.qpos)[(size_t)env * NQP + tid];
   if (tid < NV) {
     w.qvel[tid] = PART == POST_B ? post[PB_QVEL + tid] : as_global(st.qvel)[(size_t)env * NV + tid];
+    w.qacc[tid] = PART == POST_B ? 0.f : as_global(st.warm)[(size_t)env * NV + tid];     // (goes back with the state after an in-launch reset only)
     w.action[tid] = fminf(fmaxf(action[(size_t)io * HOIC_ACT_DIM + tid], -1.f), 1.f);
   }
   for (int k = tid; k < m.nbody * 3; k += NT) w.xpos[k / 3][k % 3] = post[PB_XPOS + k];
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(ORDER_NT) void hoic_order_kernel(const unsigned* __
 __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restrict__ mp, DevExpert ex, DevState st,
                                                         const int* __restrict__ env_ids, const int* __restrict__ seqs,
                                                         const int* __restrict__ starts, float* __restrict__ obs, int n_envs) {
-  __shared__ Work w;
+  __shared__ PostWork w;
   const DevModel& m = *mp;
   const int k = blockIdx.x, tid = threadIdx.x;
   const int env = env_ids ? env_ids[k] : k;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(NT) void hoic_reset_kernel(const DevModel* __restri
   dev_kinematics(m, w, w.qpos);
   ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], start, 0};
   if (obs) dev_write_obs(m, w, ev, obs + (size_t)env * HOIC_OBS_DIM);
-  store_state(st, w, env);
+  store_state(st, w, env, true);
   if (tid == 0) { as_global(st.lag_valid)[env] = 0; as_global(st.cur_t)[env] = 0; as_global(st.start)[env] = start; as_global(st.seq)[env] = seq; as_global(st.rfc_score)[env] = 0.f; as_global(st.qp_lam)[(size_t)env * 8 + 6] = 0.0; }
 }
 
@@ -545,20 +555,25 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   if (tid < NQP) w.qpos[tid] = tid < m.nq ? a.qpos[(size_t)env * m.nq + tid] : 0.f;
   if (tid < NV) {
     w.qvel[tid] = tid < m.nv ? a.qvel[(size_t)env * m.nv + tid] : 0.f;
-    w.ctrl[tid] = (a.ctrl && tid < m.nu) ? a.ctrl[(size_t)env * m.nu + tid] : 0.f;
-    w.applied[tid] = (a.applied && tid < m.nv) ? a.applied[(size_t)env * m.nv + tid] : 0.f;
-    w.warm[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;
+    float f = (a.applied && tid < m.nv) ? a.applied[(size_t)env * m.nv + tid] : 0.f;
+    const int ai = tid < m.nv ? m.dof_actid[tid] : -1;
+    if (a.ctrl && ai >= 0) f += a.ctrl[(size_t)env * m.nu + ai];
+    w.applied[tid] = f;                                                              // applied + actuator forces, as dev_applied leaves them
+    w.qacc[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;      // warm start
   }
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.capped = 0; }
   wsync();
   dev_load_constants(m, w);
   MReg M;
   dev_forward_kin(m, cfg, w, M, w.qpos, w.qvel, nullptr);
-  const bool ok = dev_forward_dyn(m, cfg, w, M);
+  // (the geom rotation matrices live in the collision stage's region: read them before the solver reuses it)
+  if (a.gxmat) for (int k = tid; k < m.ngeom * 9; k += NT) a.gxmat[(size_t)env * m.ngeom * 9 + k] = w.gxmat[k / 9][k % 9];
+  wsync();
+  float a0 = 0.f;
+  const bool ok = dev_forward_dyn(m, cfg, w, M, &a0);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
   if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
-  if (a.gxmat) for (int k = tid; k < m.ngeom * 9; k += NT) a.gxmat[(size_t)env * m.ngeom * 9 + k] = w.gxmat[k / 9][k % 9];
   if (a.qM && (tid & 31) < m.nv) {
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
     }
   }
   if (a.bias && tid < m.nv) a.bias[(size_t)env * m.nv + tid] = w.bias[tid];
-  if (a.asmooth && tid < m.nv) a.asmooth[(size_t)env * m.nv + tid] = w.asmooth[tid];
+  if (a.asmooth && tid < m.nv) a.asmooth[(size_t)env * m.nv + tid] = a0;
   if (a.qacc && tid < m.nv) a.qacc[(size_t)env * m.nv + tid] = w.qacc[tid];
   if (a.ncon && tid == 0) a.ncon[env] = w.ncon;
   if (a.iters && tid == 0) a.iters[env] = ok ? w.solver_iter : -1;
@@ -583,14 +598,13 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
       } else for (int i = 0; i < 16; i++) r[i] = 0.f;
     }
   }
-  if (a.do_step && ok) dev_euler(m, w, M);
+  if (a.do_step && ok) dev_euler(m, w, M, (GPTR(float))nullptr, (GPTR(float))nullptr);
   if (a.qpos_out && tid < m.nq) a.qpos_out[(size_t)env * m.nq + tid] = w.qpos[tid];
   if (a.qvel_out && tid < m.nv) a.qvel_out[(size_t)env * m.nv + tid] = w.qvel[tid];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 struct hoic_sim {
-  bool fused = false;        // HOIC_FUSED_STEP=1: post-step work at the end of the substep launch (measured: no gain)
   bool reorder = false;
   bool use_lag = true;       // HOIC_NO_LAGREC=1: recompute the lagged forward pass at every launch (development aid)
   int n_envs = 0, device = 0;
@@ -859,6 +873,16 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     m.pair_mpos[p] = m.body_dofmask[b2] & ~m.body_dofmask[b1]; m.pair_mneg[p] = m.body_dofmask[b1] & ~m.body_dofmask[b2];
     if (m.pair_type1[p] == HOIC_GEOM_MESH) { set_err("model blob: a mesh must be the second geom of a pair"); return false; }
   }
+  {   // pool entries of the collision staging (hoic_collide.h LaneContacts): the pair types whose narrow phase can produce more
+      // than COLSLOT contacts -- plane-box (4), box-box (4), box-mesh (4), plane-mesh (3) -- numbered within their pass of 64 pairs
+    int used[(NPAIR + NT - 1) / NT] = {};
+    for (int p = 0; p < m.npair; p++) {
+      const int t1 = m.pair_type1[p], t2 = m.pair_type2[p];
+      const bool big = ((t1 == HOIC_GEOM_PLANE || t1 == HOIC_GEOM_BOX) && (t2 == HOIC_GEOM_BOX || t2 == HOIC_GEOM_MESH));
+      m.pair_pool[p] = big ? used[p / NT]++ : -1;
+      if (used[p / NT] > COLPOOL) { set_err("model blob: more than 32 pairs of one pass can produce four contacts (collision staging pool)"); return false; }
+    }
+  }
   std::vector<int> mva, mvn, mpa, mpn; std::vector<double> mv, mpl;
   if (b.i32("mesh_vertadr", mva) && b.i32("mesh_vertnum", mvn) && b.f64("mesh_vert", mv) &&
       b.i32("mesh_planeadr", mpa) && b.i32("mesh_planenum", mpn) && b.f64("mesh_plane", mpl)) {
@@ -966,7 +990,6 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   // 2048-env launch, rollout +3 % (+4 % on a tracking policy).  Whole-batch launches gain nothing measurable.
   s->reorder = !(getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '0');
   s->use_lag = getenv("HOIC_NO_LAGREC") == nullptr;
-  s->fused = getenv("HOIC_FUSED_STEP") != nullptr && getenv("HOIC_FUSED_STEP")[0] == '1';
   hipDeviceSynchronize();
   return s;
 }
@@ -1121,10 +1144,15 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
   // duration; the post-step order only exists for whole-batch launches of the default form
   const int use_order = s->reorder ? 1 : 0;
   const bool whole = first == 0 && count == s->n_envs;
-  const bool split = s->async_reward && !s->fused;
+  const bool split = s->async_reward;
   // (split form: the order of a range's next launch is made on the side stream right behind the substeps that measured the
   //  durations, off the caller's chain; see below)
-  if (use_order && !split) hipLaunchKernelGGL(hoic_order_kernel, dim3(whole ? 2 : 1), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs, first, count);
+  if (use_order && !split) {
+    // this launch rewrites order[first, first + count): a split-mode range that overlaps it must not trust the order made
+    // behind its previous step any more (it would run foreign envs: rows outside its I/O buffers, envs stepped twice)
+    for (auto& q : s->ranges) if (q.first < first + count && first < q.first + q.count) q.order_ready = false;
+    hipLaunchKernelGGL(hoic_order_kernel, dim3(whole ? 2 : 1), dim3(ORDER_NT), 0, st, s->st.cost, s->st.order, s->n_envs, first, count);
+  }
   if (split) {
     // Split form: termination, reset and observation at the end of the substep kernel (what the caller's next policy forward
     // needs), the reward part (contact classification, residual-force QP, reward) on the range's side stream from the
@@ -1141,6 +1169,8 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
       HIPCHK(hipEventCreateWithFlags(&r->ord_done, hipEventDisableTiming));
       for (int b = 0; b < 2; b++) HIPCHK(hipEventCreateWithFlags(&r->rew_done[b], hipEventDisableTiming));
     }
+    // the order kernel behind this step rewrites order[first, first + count): other ranges that overlap it lose theirs
+    for (auto& q : s->ranges) if (&q != r && q.first < first + count && first < q.first + q.count) q.order_ready = false;
     const int buf = r->next_buf; r->next_buf ^= 1;
     if (r->pending[buf]) HIPCHK(hipStreamWaitEvent(st, r->rew_done[buf], 0));      // the reward part of step t - 2 read this record
     const int have_order = (use_order && r->order_ready) ? 1 : 0;
@@ -1163,18 +1193,12 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
     return HOIC_OK;
   }
   if (e) hipEventRecord(e[0], st);
-  if (s->fused) {     // one launch: the post-step work runs at the end of the substep kernel
-    hipLaunchKernelGGL(hoic_substep_kernel<1>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
-                       s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs, 0);
-    if (e) hipEventRecord(e[1], st);
-  } else {
-    hipLaunchKernelGGL(hoic_substep_kernel<0>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
-                       s->use_lag ? 1 : 0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
-                       (const int*)nullptr, (const int*)nullptr, s->n_envs, 0);
-    if (e) hipEventRecord(e[1], st);
-    hipLaunchKernelGGL(hoic_poststep_kernel<POST_ALL>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, (use_order && whole) ? 1 : 0, s->n_envs, 0);
-  }
+  hipLaunchKernelGGL(hoic_substep_kernel<0>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, use_order,
+                     s->use_lag ? 1 : 0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
+                     (const int*)nullptr, (const int*)nullptr, s->n_envs, 0);
+  if (e) hipEventRecord(e[1], st);
+  hipLaunchKernelGGL(hoic_poststep_kernel<POST_ALL>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                     d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, (use_order && whole) ? 1 : 0, s->n_envs, 0);
   if (e) { hipEventRecord(e[2], st); s->n_timed++; }
   HIPCHK(hipGetLastError());
   return HOIC_OK;
@@ -1252,9 +1276,9 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_probe_qp_kernel(const float* __restrict__ cols, const int* __restrict__ ncols,
                                                                                                 const double* __restrict__ rhs, int max_col,
                                                                                                 double* __restrict__ lam_out, int* __restrict__ stat_out) {
-  __shared__ Work w;
+  __shared__ PostWork w;
   const int k = blockIdx.x, tid = threadIdx.x, ncol = ncols[k];
-  float* qc = w.col_lc;
+  float* qc = w.qp_col;
   const float* src = cols + (size_t)k * max_col * 7;
   for (int c = tid; c < ncol; c += NT)
     for (int i = 0; i < 7; i++) qc[i * QP_MAXCOL + c] = src[(size_t)c * 7 + i];

@@ -8,20 +8,23 @@
 #include "hoic_types.h"
 #include "hoic_math.h"
 
-// Contacts found by one lane (= one pair): staged in LDS (Work::col_lc, one column per lane), so that the narrow
-// phase holds neither 28 more registers nor a scratch-memory copy (dynamic indexing of a register array would put
-// it there; scratch round trips go to L2/HBM and used to dominate this stage).
+// Contacts found by one lane (= one pair): staged in LDS (Work::col_lc, one column per lane, COLSLOT contacts; a pair that
+// can produce more -- plane-box, box-box, box-mesh, plane-mesh: DevModel::pair_pool -- owns a pool entry for contacts 2 and 3),
+// so that the narrow phase holds neither 28 more registers nor a scratch-memory copy (dynamic indexing of a register array
+// would put it there; scratch round trips go to L2/HBM and used to dominate this stage).
 struct LaneContacts {
   int n;
   float* b;   // &col_lc[lane]
+  float* b2;  // the pair's pool entry (any entry when cap == COLSLOT: never written)
+  int cap;    // contacts this lane can stage: COLSLOT, or COLSLOT + 2 with a pool entry
 };
-HD float& lc_at(const LaneContacts& o, int q, int k) { return o.b[(q * 7 + k) * NT]; }
+HD float& lc_at(const LaneContacts& o, int q, int k) { return q < COLSLOT ? o.b[(q * 7 + k) * NT] : o.b2[(q - COLSLOT) * 7 + k]; }
 HD void lc_put(LaneContacts& o, int slot, float dist, const float* pos, const float* n) {
-  if (slot < 0) return;
+  if (slot < 0 || slot >= o.cap) return;      // (build_model gives every pair type that can produce more than COLSLOT contacts a pool entry)
   lc_at(o, slot, 0) = dist;
   for (int i = 0; i < 3; i++) { lc_at(o, slot, 1 + i) = pos[i]; lc_at(o, slot, 4 + i) = n[i]; }
 }
-HD void lc_push(LaneContacts& o, float dist, const float* pos, const float* n) { lc_put(o, o.n, dist, pos, n); o.n++; }
+HD void lc_push(LaneContacts& o, float dist, const float* pos, const float* n) { if (o.n < o.cap) { lc_put(o, o.n, dist, pos, n); o.n++; } }
 
 HD void col_plane_sphere(const float* pp, const float* pn, const float* c, float r, LaneContacts& o) {
   float d[3] = {c[0] - pp[0], c[1] - pp[1], c[2] - pp[2]};
@@ -652,7 +655,8 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
   wsync();
   for (int ps = 0; ps * NT < m.npair; ps++) {
     const int p = ps * NT + tid;
-    LaneContacts lc{0, &w.col_lc[tid]};
+    const int pool = p < m.npair ? m.pair_pool[p] : -1;
+    LaneContacts lc{0, &w.col_lc[tid], w.col_pool[max(pool, 0)], pool >= 0 ? COLSLOT + 2 : COLSLOT};
     int g1 = 0, g2 = 0;
     bool isbb = false, ismesh = false;
     if (p < m.npair) {
@@ -735,9 +739,10 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         float Pa[3], RA[9], Ha[3], Pb[3], RB[9], Hb[3];
         for (int i = 0; i < 3; i++) { Pa[i] = w.gxpos[ga][i]; Pb[i] = w.gxpos[gb][i]; Ha[i] = m.pair_size1[pp][i]; Hb[i] = m.pair_size2[pp][i]; }
         for (int i = 0; i < 9; i++) { RA[i] = w.gxmat[ga][i]; RB[i] = w.gxmat[gb][i]; }
-        const LaneContacts owner{0, &w.col_lc[L]};
+        const int pl_ = m.pair_pool[pp];
+        const LaneContacts owner{0, &w.col_lc[L], w.col_pool[max(pl_, 0)], pl_ >= 0 ? COLSLOT + 2 : COLSLOT};
         const int nn = col_box_box_wave(Pa, RA, Ha, Pb, RB, Hb, owner, w.col_poly);
-        if (tid == L) lc.n = nn;
+        if (tid == L) lc.n = min(nn, lc.cap);
       }
       wsync();
     }
@@ -752,7 +757,8 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         float Pa[3], RA[9], Sa[3], Pb[3], RB[9];
         for (int i = 0; i < 3; i++) { Pa[i] = w.gxpos[ga][i]; Pb[i] = w.gxpos[gb][i]; Sa[i] = m.pair_size1[pp][i]; }
         for (int i = 0; i < 9; i++) { RA[i] = w.gxmat[ga][i]; RB[i] = w.gxmat[gb][i]; }
-        const LaneContacts owner{0, &w.col_lc[L]};
+        const int pl_ = m.pair_pool[pp];
+        const LaneContacts owner{0, &w.col_lc[L], w.col_pool[max(pl_, 0)], pl_ >= 0 ? COLSLOT + 2 : COLSLOT};
         int nn;
         if (ta == HOIC_GEOM_CAPSULE) nn = col_capsule_mesh_wave(hull, Pa, RA, Sa, Pb, RB, owner);
         else if (ta == HOIC_GEOM_BOX) nn = col_box_mesh_wave(hull, Pa, RA, Sa, Pb, RB, m.geom_rbound[gb], owner);
@@ -765,7 +771,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
           wsync();
           nn = 1;
         }
-        if (tid == L) lc.n = nn;
+        if (tid == L) lc.n = min(nn, lc.cap);
       }
       wsync();
     }
@@ -798,5 +804,19 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
       w.ncon = nn;
     }
     wsync();
+  }
+  // Constraint rows: 4 per condim-3 contact, 6 per condim-4 (object on the table), 1 per condim-1; the solver holds NCROW = 4
+  // MAXCON of them.  The list is cut where the rows run out (a full list with condim-4 contacts in it): counted with the
+  // contact overflows, never observed in a rollout (hoic_get_diagnostics).
+  {
+    const int nc = w.ncon;
+    int nr = 0;
+    if (tid < nc) { const int dim = m.pair_condim[w.c_pair[tid]]; nr = dim == 1 ? 1 : 2 * (dim - 1); }
+    const int incl = wave_incl_scan(nr);
+    const int nfit = __popcll(__ballot(tid < nc && incl <= NCROW));
+    if (nfit < nc) {
+      if (tid == 0) { w.ncon = nfit; if (overflow) *overflow += 1; }
+      wsync();
+    }
   }
 }

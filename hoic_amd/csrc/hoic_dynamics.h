@@ -16,14 +16,10 @@
 #include "hoic_types.h"
 #include "hoic_math.h"
 
-// model constants used every pass -> LDS (once per launch)
+// the packed dof paths of the bodies -> LDS (once per launch): read several times per Newton iteration; every other per-dof
+// constant is re-read from the L1/L2-resident DevModel where it is used (one load level, issued ahead of its use)
 __device__ __forceinline__ void dev_load_constants(const DevModel& m, Work& w) {
   const int t = threadIdx.x;
-  if (t < NV) {
-    const bool v = t < m.nv;
-    w.k_arm[t] = v ? m.dof_armature[t] : 0.f; w.k_damp[t] = v ? m.dof_damping[t] : 0.f; w.k_floss[t] = v ? m.dof_frictionloss[t] : 0.f;
-    w.k_flR[t] = v ? m.dof_flR[t] : 1.f; w.k_flB[t] = v ? m.dof_flB[t] : 0.f; w.k_act[t] = v ? m.dof_actid[t] : -1;
-  }
   if (t < NB) for (int i = 0; i < 3; i++) w.k_bpath[t][i] = t < m.nbody ? m.body_path[t][i] : 0xFFFFFFFFu;
   wsync();
 }
@@ -53,7 +49,7 @@ template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[
 }
 
 // ---- kinematics: body frames, geoms, motion axes S, body inertias about the origin
-__device__ __forceinline__ void dev_kinematics(const DevModel& m, Work& w, const float* q) {
+template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel& m, W& w, const float* q) {
   const int tid = opaque(threadIdx.x);
   const bool isb = tid < m.nbody;
   float P[3] = {0.f, 0.f, 0.f}, Q[4] = {1.f, 0.f, 0.f, 0.f};
@@ -249,13 +245,19 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
   if (tid < 32) for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[d][i] = fSi[i];
   wsync();
   const unsigned am = vd ? (m.dof_amask[d] | (1u << d)) : 0u, dm = vd ? m.dof_dmask[d] : 0u;
+  const float arm = vd ? m.dof_armature[d] : 0.f;
   const int hi = tid >> 5;
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     const int j = MREG_ROW(reg, hi);          // per half-wave uniform: LDS broadcasts
     const float a = dot6(w.S[j], fSi), bb = dot6(Si, w.sc.dyn.u.f.fS[j]);
     float v = ((am >> j) & 1u) ? a : (((dm >> j) & 1u) ? bb : 0.f);
-    if (j == d) v += w.k_arm[d];
+    if (j == d) v += arm;
+    // The entry is pinned where it is computed: on the path that leaves the substep loop after a failed substep M is not read
+    // again, so the optimiser would otherwise sink the 16 x 12 multiply-adds behind the collision stage (past that exit) and keep
+    // the 192 LDS values they read alive across it -- 231 spilled registers at the 168-register budget.  (The armature used to be
+    // a conditional LDS read per entry, which happened to hold the arithmetic in place.)
+    asm volatile("" : "+v"(v));
     M.r[reg] = v;
   }
   wsync();

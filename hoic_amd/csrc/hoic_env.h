@@ -32,14 +32,15 @@ __device__ __forceinline__ void dev_forward_kin(const DevModel& m, const DevConf
 }
 
 // ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass
-__device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev) {
+// act: this env's row of the action buffer (global memory; clipped on the fly, ho_im4.py:613)
+__device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev, GPTR(const float) act) {
   const int tid = opaque(threadIdx.x), d = tid & 31, n = m.hand_nv;
   const float dt = m.timestep;
   float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
   if (d < n) {
     GPTR(const float) ref = as_global(ev.ex->hand_dof) + (size_t)ev.frame(cfg.c.pd_ref_offset) * m.hand_nq;   // 0; 1 in the streaming env
     float target;
-    const float a = w.action[d];
+    const float a = fminf(fmaxf(act[d], -1.f), 1.f);
     if (d < 3) target = ref[d] + 0.1f * a;
     else if (d < 6) target = ref[d] + 0.3f * a;
     else target = (cfg.c.pd_rel ? ref[d] : cfg.base_pose[d]) + cfg.ctrl_scale[d] * a;
@@ -64,12 +65,13 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
       const float lim = cfg.c.torque_lim[tid];
       tq = fminf(fmaxf(tq, -lim), lim);
     }
-    w.ctrl[tid] = tq;
+    w.sc.vec.ctrl[tid] = tq;        // consumed by dev_applied before the next forward pass reuses the scratch
   }
   wsync();
 }
 
-// ---- generalized applied forces: gravity compensation + residual object wrench, lagged Jacobians
+// ---- generalized applied forces: gravity compensation + residual object wrench (lagged Jacobians) + the PD torques of
+// dev_pd_torque (sc.vec.ctrl)
 __device__ __forceinline__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
   const int tid = opaque(threadIdx.x);
   if (tid < NV) {
@@ -78,27 +80,41 @@ __device__ __forceinline__ void dev_applied(const DevModel& m, const DevConfig& 
       const float f[3] = {0.f, 0.f, m.hand_mass * 9.8f}, z[3] = {0.f, 0.f, 0.f};
       s = dev_apply_ft_dof(m, w, tid, 3, f, z, w.gxpos[2]);                       // ho_im4.py:527-535
       if (cfg.c.residual_force) s += dev_apply_ft_dof(m, w, tid, m.obj_body, vf, vt, &w.qpos[m.hand_nq]);  // :492-500
+      const int ai = m.dof_actid[tid];
+      if (ai >= 0) s += w.sc.vec.ctrl[ai];                                        // actuation (motor on the dof, gear 1)
     }
     w.applied[tid] = s;
   }
   wsync();
 }
 
-// ---- record_contact (ho_im4.py:883-889): lane = hand geom, deterministic accumulation order
-__device__ __forceinline__ void dev_record_contact(const DevModel& m, Work& w) {
+// ---- record_contact (ho_im4.py:883-889): lane = hand geom, deterministic accumulation order.  The sums of the env step live
+// in the hand-over record itself (rec = the env's record, zeroed at launch start): a lane touches its 13 floats only in a
+// substep in which its geom has a contact with the object (8 % of the envs have one at all).
+__device__ __forceinline__ void dev_record_contact(const DevModel& m, Work& w, GPTR(float) rec) {
   const int tid = opaque(threadIdx.x);
   if (tid < NHG) {
     const int g = m.hand_geom0 + tid;
+    float acc[12]; float cnt = 0.f; bool any = false;
     for (int c = 0; c < w.ncon; c++) {
       const int g1 = w.c_g1[c], g2 = w.c_g2[c];
       if (g1 == g && g2 >= m.obj_geom0 && g2 <= m.obj_geom1) {
-        for (int i = 0; i < 3; i++) w.rec_sum[tid][i] += w.c_pos[c][i];
-        for (int i = 0; i < 9; i++) w.rec_sum[tid][3 + i] += w.c_frame[c][i];
-        w.rec_cnt[tid]++;
+        if (!any) {
+#pragma unroll
+          for (int i = 0; i < 12; i++) acc[i] = rec[PB_REC + tid * 12 + i];
+          cnt = rec[PB_RECCNT + tid]; any = true;
+        }
+        for (int i = 0; i < 3; i++) acc[i] += w.c_pos[c][i];
+        for (int i = 0; i < 9; i++) acc[3 + i] += w.c_frame[c][i];
+        cnt += 1.f;
       }
     }
+    if (any) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) rec[PB_REC + tid * 12 + i] = acc[i];
+      rec[PB_RECCNT + tid] = cnt;
+    }
   }
-  wsync();
 }
 
 // uhc/utils/transforms.py:414 matrix_to_axis_angle
@@ -121,7 +137,7 @@ HD void dev_matrix_to_axis_angle(const float* mm, float* aa) {
 }
 
 // ---- classify_contact (ho_im4.py:567-597)
-__device__ void dev_classify_contact(const DevModel& m, Work& w) {
+__device__ void dev_classify_contact(const DevModel& m, PostWork& w) {
   const int tid = threadIdx.x;
   const bool has = tid < NHG && w.rec_cnt[tid] > 0;
   const unsigned long long mask = __ballot(has);
@@ -218,7 +234,7 @@ HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (ov
 // ---- the residual-force QP proper: columns a_k (6) and offsets c_k (k < ncol) in LDS at qc[i * QP_MAXCOL + k],
 // right-hand side b; returns the dual optimum lambda = 2 (A x - b).  stat (optional, lane-uniform): column entries,
 // small solves are not counted; [0] = active-set iterations, [1] = dual-Newton iterations of the fallback.
-__device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, const double (&b)[6], double (&lam)[6], int* stat) {
+__device__ __forceinline__ void dev_nnqp(PostWork& w, const float* qc, int ncol, const double (&b)[6], double (&lam)[6], int* stat) {
   const int tid = threadIdx.x;
   const double eps = 1e-7;
   const int nslot = (ncol + NT - 1) / NT;         // columns per lane actually present (typically 1-2 of at most 6)
@@ -433,7 +449,7 @@ __device__ __forceinline__ void dev_nnqp(Work& w, const float* qc, int ncol, con
   if (stat) stat[1] = n_dual;
 }
 
-__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt, double* warm_lam) {
+__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, PostWork& w, const float* vf, const float* vt, double* warm_lam) {
   const int tid = threadIdx.x;
   const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025;
   if (!cfg.c.explain_force)
@@ -472,7 +488,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
   // columns a_i (6) and offsets c_i live in LDS as float32 (their inputs are float32 quantities; all arithmetic on
   // them is float64): the QP then needs ~130 registers instead of ~460, and its loops run over the columns that
   // exist instead of six unrolled slots per lane
-  float* qc = w.col_lc;
+  float* qc = w.qp_col;
   const double obj_p[3] = {w.qpos[nq - 7], w.qpos[nq - 6], w.qpos[nq - 5]};
   const double obj_v[3] = {w.sc.post.gvel[lastg][0], w.sc.post.gvel[lastg][1], w.sc.post.gvel[lastg][2]};
   for (int jj = 0; jj < nslot; jj++) {
@@ -532,7 +548,7 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, Work& w,
 }
 
 // ---- termination diffs (calc_ho_diff, ho_im4.py:664-688); out: pos, rot, jpos, obj, obj_rot(=0)
-__device__ __forceinline__ void dev_ho_diff(const DevModel& m, const Work& w, const ExpertView& ev, float* out) {
+template <class W> __device__ __forceinline__ void dev_ho_diff(const DevModel& m, const W& w, const ExpertView& ev, float* out) {
   const int tid = threadIdx.x, hb0 = m.hand_body0, fr = ev.frame(0);
   GPTR(const float) ep = as_global(ev.ex->body_pos) + (size_t)fr * NHB * 3; GPTR(const float) eq = as_global(ev.ex->body_quat) + (size_t)fr * NHB * 4;
   float s = 0.f;
@@ -553,7 +569,7 @@ __device__ __forceinline__ void dev_ho_diff(const DevModel& m, const Work& w, co
 }
 
 // ---- ho_mimic_reward_9 (uhc/envs/ho_reward.py:943-1047); out[0] reward, out[1..9] info
-__device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& w, const ExpertView& ev, float rfc_score, float* out) {
+__device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const PostWork& w, const ExpertView& ev, float rfc_score, float* out) {
   const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0, fr = ev.frame(0);
   const float* wk = cfg.rp.wk;
   GPTR(const float) eq = as_global(ev.ex->hand_dof) + (size_t)fr * nh; GPTR(const float) evel = as_global(ev.ex->hand_dof_vel) + (size_t)fr * nh;
@@ -593,7 +609,7 @@ __device__ void dev_reward(const DevModel& m, const DevConfig& cfg, const Work& 
 }
 
 // ---- get_full_obs_v5(5) (ho_im4.py:280-356): 617 floats written straight to HBM, coalesced per segment
-__device__ __forceinline__ void dev_write_obs(const DevModel& m, const Work& w, const ExpertView& ev, float* __restrict__ obs) {
+template <class W> __device__ __forceinline__ void dev_write_obs(const DevModel& m, const W& w, const ExpertView& ev, float* __restrict__ obs) {
   const int tid = threadIdx.x, nh = m.hand_nq, hb0 = m.hand_body0;
   const DevExpert& x = *ev.ex;
   float R[9], Rqi[4];
@@ -649,16 +665,16 @@ __device__ __forceinline__ void dev_write_obs(const DevModel& m, const Work& w, 
 #undef RT
 }
 
-// ---- reset_model (ho_im4.py:690-716): state <- expert frame `start` of sequence `seq`
-__device__ __forceinline__ void dev_reset_state(const DevModel& m, Work& w, const DevExpert& x, int seq, int start) {
+// ---- reset_model (ho_im4.py:690-716): state <- expert frame `start` of sequence `seq`; the warm start is cleared.  The caller
+// stores the state as the lagged state as well (store_state with lag_too)
+template <class W> __device__ __forceinline__ void dev_reset_state(const DevModel& m, W& w, const DevExpert& x, int seq, int start) {
   const int tid = threadIdx.x;
   const int len = x.seq_len[seq], off = x.seq_off[seq];
   const int fr = off + (start < len - 1 ? start : len - 1), nh = m.hand_nq;
   if (tid < nh) { w.qpos[tid] = x.hand_dof[(size_t)fr * nh + tid]; w.qvel[tid] = x.hand_dof_vel[(size_t)fr * nh + tid]; }
   if (tid < 7) w.qpos[nh + tid] = x.obj_pose[(size_t)fr * 7 + tid];
   if (tid < 3) { w.qvel[m.hand_nv + tid] = x.obj_vel[(size_t)fr * 3 + tid]; w.qvel[m.hand_nv + 3 + tid] = x.obj_angvel[(size_t)fr * 3 + tid]; }
-  wsync();
-  if (tid < NQP) w.qlag[tid] = tid < m.nq ? w.qpos[tid] : 0.f;
-  if (tid < NV) { w.vlag[tid] = w.qvel[tid]; w.warm[tid] = 0.f; w.qacc[tid] = 0.f; }
+  if (tid >= m.nq && tid < NQP) w.qpos[tid] = 0.f;
+  if (tid < NV) w.qacc[tid] = 0.f;
   wsync();
 }

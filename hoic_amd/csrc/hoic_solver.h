@@ -156,13 +156,17 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
       const int nr = w.c_nrow[c], r0 = w.c_row0[c];
       const float sg = (float)((w.c_mpos[c] >> col) & 1u) - (float)((w.c_mneg[c] >> col) & 1u);
       const float* fr = w.c_frame[c];
-      const float vn = dot3(Sc, w.c_pxf[c][0]) + dot3(Sc + 3, fr);
+      // velocity of the contact point per unit velocity of this lane's dof: S_lin + S_ang x p; a row is f_k . that
+      float wl[3];
+      cross3(Sc, w.c_pos[c], wl);
+      wl[0] += Sc[3]; wl[1] += Sc[4]; wl[2] += Sc[5];
+      const float vn = dot3(wl, fr);
       for (int p = 0; 2 * p < nr; p++) {       // edges 2p (low half of the wave) and 2p+1 (high half)
         const float cu0 = w.cr_curv[r0 + 2 * p], cu1 = (2 * p + 1 < nr) ? w.cr_curv[r0 + 2 * p + 1] : 0.f;
         if (cu0 == 0.f && cu1 == 0.f) continue;
         float v = vn;
         if (nr > 1) {
-          const float vt = (p < 2) ? dot3(Sc, w.c_pxf[c][1 + p]) + dot3(Sc + 3, fr + 3 * (1 + p)) : dot3(Sc, fr);
+          const float vt = (p < 2) ? dot3(wl, fr + 3 * (1 + p)) : dot3(Sc, fr);
           v += (hi ? -w.c_mu[c][p] : w.c_mu[c][p]) * vt;
         }
         v *= sg;
@@ -239,17 +243,19 @@ __device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const 
   for (int t = tid; t < nb; t += NT) {
     const int c = t >> 2, k = t & 3;
     const int b1 = w.c_b1[c], b2 = w.c_b2[c];
-    float dV[6];
+    float dV[6], vp[3];
 #pragma unroll
     for (int i = 0; i < 6; i++) dV[i] = w.bV[b2][i] - w.bV[b1][i];
-    w.u[t] = (k < 3) ? dot3(w.c_pxf[c][k], dV) + dot3(w.c_frame[c] + 3 * k, dV + 3) : dot3(w.c_frame[c], dV);
+    cross3(dV, w.c_pos[c], vp);                 // relative velocity of the two bodies at the contact point: v + w x p
+    vp[0] += dV[3]; vp[1] += dV[4]; vp[2] += dV[5];
+    w.u[t] = (k < 3) ? dot3(w.c_frame[c] + 3 * k, vp) : dot3(w.c_frame[c], dV);
   }
   wsync();
 }
 
 // J_r . x for contact row r (u must hold dev_basis_dot(x))
 HD float dev_crow_times(const Work& w, int r) {
-  const int c = w.cr_con[r], e = w.cr_edge[r];
+  const int ce = w.cr_ce[r], c = ce >> 3, e = ce & 7;
   const float un = w.u[c * 4];
   if (w.c_nrow[c] == 1) return un;
   const int k = e >> 1;
@@ -270,14 +276,15 @@ HD float cost_onesided(float D, float jar, float& force, float& curv) {
 }
 
 // ---- constraint rows for the current kinematics / contacts
-__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, const float* qpos, const float* qvel) {
+// aref_c: reference accelerations of this lane's contact rows (row lane + 64 k, the mapping of RowEval::jar_c)
+__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, float (&aref_c)[NCSLOT], const float* qpos, const float* qvel) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   // friction loss and joint limit of dof d (one side per joint can be active: every range is wider than twice
   // the margin; slide and hinge joints have exactly one dof)
   rk.f_aref = 0.f; rk.l_sign = 0.f; rk.l_D = 0.f; rk.l_aref = 0.f;
   if (d < m.nv) {
     const float qv = qvel[d];
-    rk.f_aref = -w.k_flB[d] * qv;
+    rk.f_aref = -m.dof_flB[d] * qv;
     if (m.dof_limited[d]) {
       const float q = qpos[m.dof_qadr[d]], margin = m.dof_margin[d];
       const float dl = q - m.dof_range[d][0], du = m.dof_range[d][1] - q;
@@ -312,14 +319,12 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
       const int b1 = m.pair_b1[p], b2 = m.pair_b2[p];
       w.c_b1[c] = (unsigned char)b1; w.c_b2[c] = (unsigned char)b2;
       w.c_mpos[c] = m.pair_mpos[p]; w.c_mneg[c] = m.pair_mneg[p];
-      const float* f = w.c_frame[c];
-      for (int k = 0; k < 3; k++) cross3(w.c_pos[c], f + 3 * k, w.c_pxf[c][k]);
     }
     const int incl_sum = wave_incl_scan(nrow);
     const int row0 = incl_sum - nrow;
     if (c < w.ncon) {
       w.c_row0[c] = (unsigned char)row0;
-      for (int e = 0; e < nrow; e++) { w.cr_con[row0 + e] = (unsigned char)c; w.cr_edge[row0 + e] = (unsigned char)e; }
+      for (int e = 0; e < nrow; e++) w.cr_ce[row0 + e] = (unsigned char)((c << 3) | e);     // (dev_collision cut the list so that the rows fit)
     }
     const int total = __builtin_amdgcn_readlane(incl_sum, NT - 1);
     if (tid == 0) w.nrow = total;
@@ -327,9 +332,12 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
   wsync();
   // reference accelerations of the contact rows
   dev_basis_dot(m, w, qvel);
-  for (int r = tid; r < w.nrow; r += NT) {
-    const int c = w.cr_con[r];
-    w.cr_aref[r] = -w.c_B[c] * dev_crow_times(w, r) + w.c_aref0[c];
+  const int nrow_ = w.nrow;
+#pragma unroll
+  for (int k = 0; k < NCSLOT; k++) {
+    const int r = tid + k * NT;
+    aref_c[k] = 0.f;
+    if (r < nrow_) { const int c = w.cr_ce[r] >> 3; aref_c[k] = -w.c_B[c] * dev_crow_times(w, r) + w.c_aref0[c]; }
   }
   wsync();
 }
@@ -337,7 +345,7 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
 // ---- row state.  jar = J x - aref of every row: per-dof rows in the registers of lane & 31 = dof (both
 // half-waves), contact rows NCSLOT per lane.  dev_rows_jar needs one Jacobian product (dev_basis_dot);
 // dev_rows_cost turns jar into cost, forces and curvatures (contact rows: LDS cr_force / cr_curv) and is cheap.
-__device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const RowK& rk, const float* x, bool with_aref, RowEval& ev) {
+__device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const RowK& rk, const float (&aref_c)[NCSLOT], const float* x, bool with_aref, RowEval& ev) {
   const int tid = opaque(threadIdx.x);
   dev_basis_dot(m, w, x);
   const float xd = ((tid & 31) < m.nv) ? x[tid & 31] : 0.f;
@@ -349,7 +357,7 @@ __device__ __forceinline__ void dev_rows_jar(const DevModel& m, Work& w, const R
     ev.jar_c[k] = 0.f;
     if (k * NT < nrow) {
       const int r = tid + k * NT;
-      if (r < nrow) ev.jar_c[k] = dev_crow_times(w, r) - (with_aref ? w.cr_aref[r] : 0.f);
+      if (r < nrow) ev.jar_c[k] = dev_crow_times(w, r) - (with_aref ? aref_c[k] : 0.f);
     }
   }
 }
@@ -393,10 +401,9 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
       for (int e = 0; e < nr; e++) g[0] += w.cr_force[r0 + e];
       if (nr > 1) for (int k = 1; 2 * k - 1 < nr; k++) g[k] = w.c_mu[c][k - 1] * (w.cr_force[r0 + 2 * (k - 1)] - w.cr_force[r0 + 2 * (k - 1) + 1]);
       const float* fr = w.c_frame[c];
-      for (int i = 0; i < 3; i++) {
-        G[i] = g[0] * w.c_pxf[c][0][i] + g[1] * w.c_pxf[c][1][i] + g[2] * w.c_pxf[c][2][i] + g[3] * fr[i];
-        G[3 + i] = g[0] * fr[i] + g[1] * fr[3 + i] + g[2] * fr[6 + i];
-      }
+      for (int i = 0; i < 3; i++) G[3 + i] = g[0] * fr[i] + g[1] * fr[3 + i] + g[2] * fr[6 + i];     // contact force F
+      cross3(w.c_pos[c], G + 3, G);                                                                   // its moment about the origin: p x F
+      for (int i = 0; i < 3; i++) G[i] += g[3] * fr[i];                                               //   + the torsional moment
     }
     for (int i = 0; i < 6; i++) w.c_G[c][i] = G[i];   // zero padding up to a multiple of 4 contacts
   }
@@ -422,26 +429,27 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
 #ifndef HOIC_IMPROVEMENT_TOL
 #define HOIC_IMPROVEMENT_TOL 1e-6f
 #endif
-// ---- Newton with exact line search.  In: M, fsmooth, asmooth, warm, rows.  Out: qacc, fcon (LDS).
+// ---- Newton with exact line search.  In: M, f_smooth / a_smooth of lane & 31 (fs, a0; a_smooth also in sc.vec.x), the warm
+// start (w.qacc), rows.  Out: w.qacc, w.ftot = f_smooth + J'f (LDS).
 // The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
 // line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
-__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, int maxit) {
+__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const float (&aref_c)[NCSLOT], float fs, float a0, int maxit) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const bool vd = d < m.nv;
   const float scale = 1.f / (m.meaninertia * (float)max(m.nv, 1));
-  const float fs = w.fsmooth[d], a0 = w.asmooth[d], wm = w.warm[d];
+  const float wm = w.qacc[d];
   const int nrow = w.nrow;
-  const DofK dk{w.k_floss[d], w.k_flR[d]};
+  const DofK dk{vd ? m.dof_frictionloss[d] : 0.f, vd ? m.dof_flR[d] : 1.f};
   float D_c[NCSLOT];
 #pragma unroll
-  for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; D_c[k] = (r < nrow) ? w.c_D[w.cr_con[r]] : 0.f; }
+  for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; D_c[k] = (r < nrow) ? w.c_D[w.cr_ce[r] >> 3] : 0.f; }
   // warm start choice: cost(warm) vs cost(asmooth)
-  const float Mw = vd ? dev_Mx(M, w.warm) : 0.f;
+  const float Mw = vd ? dev_Mx(M, w.qacc) : 0.f;
   const float gw = wave_sum((tid < m.nv) ? 0.5f * (Mw - fs) * (wm - a0) : 0.f);
   RowEval ev, evw;
-  dev_rows_jar(m, w, rk, w.asmooth, true, ev);
+  dev_rows_jar(m, w, rk, aref_c, w.sc.vec.x, true, ev);
   const float cs = dev_rows_cost(m, w, dk, rk, D_c, ev);
-  dev_rows_jar(m, w, rk, w.warm, true, evw);
+  dev_rows_jar(m, w, rk, aref_c, w.qacc, true, evw);
   const float cw = gw + dev_rows_cost(m, w, dk, rk, D_c, evw);
   const bool usewarm = cw < cs;
   float cost_prev = usewarm ? cw : cs;
@@ -460,15 +468,15 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     PT(20);
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
     const float sd = dev_hsolve<true>(m, w, M, ev.curv_f + ev.curv_l, m.nv, -g);
-    if (tid < NV) w.search[tid] = vd ? sd : 0.f;
+    if (tid < NV) w.sc.vec.x[tid] = vd ? sd : 0.f;      // (a_smooth is in registers by now; T is dead between two solves)
     wsync();
     // line-search quantities
-    const float Ms = vd ? dev_Mx(M, w.search) : 0.f;
+    const float Ms = vd ? dev_Mx(M, w.sc.vec.x) : 0.f;
     float gq = 0.f, hh = 0.f, g0 = 0.f;
     if (tid < m.nv) { gq = (Ma - fs) * sd; hh = sd * Ms; g0 = g * sd; }
     gq = wave_sum(gq); hh = wave_sum(hh); g0 = wave_sum(g0);
     RowEval jv;
-    dev_rows_jar(m, w, rk, w.search, false, jv);
+    dev_rows_jar(m, w, rk, aref_c, w.sc.vec.x, false, jv);
     float a = 0.f, lo = 0.f, hi = -1.f, alpha = 0.f;
     for (int ls = 0; ls < 10; ls++) {
       float dphi = 0.f, ddphi = 0.f, f, cv;
@@ -507,7 +515,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   }
   // forces at the final acceleration (the row state already belongs to it)
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);
-  if (tid < NV) { w.fcon[tid] = vd ? jtf : 0.f; w.qacc[tid] = qacc; }
+  if (tid < NV) { w.ftot[tid] = vd ? fs + jtf : 0.f; w.qacc[tid] = qacc; }
   if (tid == 0) { w.solver_iter = it; w.capped = capped ? 1 : 0; }
   wsync();
 }

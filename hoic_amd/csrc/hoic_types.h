@@ -25,7 +25,7 @@
 #define NG HOIC_MAX_GEOM // 28
 #define NPAIR 128
 #define MAXCON 32        // contacts kept per env per substep
-#define NCROW (MAXCON * 6)   // contact rows (pyramid edges): 4 per condim-3 contact, 6 per condim-4, 1 per condim-1
+#define NCROW (MAXCON * 4)   // contact rows (pyramid edges): 4 per condim-3 contact, 6 per condim-4, 1 per condim-1; contacts whose rows do not fit are cut
 #define NCSLOT (NCROW / NT)  // contact rows handled per lane
 #define LD 33            // padded leading dimension of 32-wide LDS matrices (bank-conflict free)
 #define NHB HOIC_NHANDBODY
@@ -79,6 +79,7 @@ struct DevModel {
   unsigned pair_mpos[NPAIR], pair_mneg[NPAIR];   // dofs moving body2 only / body1 only
   float pair_mu[NPAIR][3], pair_K[NPAIR], pair_B[NPAIR], pair_solimp[NPAIR][5], pair_margin[NPAIR], pair_gap[NPAIR];
   float pair_Rscale[NPAIR];  // R = max(MINVAL,(1-imp)/imp) * Rscale  (pyramidal: 2 mu^2 tran (1+mu^2); condim 1: tran)
+  int pair_pool[NPAIR];      // pool entry of a pair that can produce more than COLSLOT contacts (index within its pass of 64 pairs), else -1
   // convex meshes (hull vertices and face planes in the geom frame)
   int mesh_vertadr[HOIC_MAX_MESH], mesh_vertnum[HOIC_MAX_MESH], mesh_planeadr[HOIC_MAX_MESH], mesh_planenum[HOIC_MAX_MESH];
   __attribute__((aligned(16))) float mesh_vert[MAXMESHV][4];    // hull vertices (x, y, z, 0), geom frame; float4 loads
@@ -166,79 +167,109 @@ struct DevState {
 struct MReg { float r[16]; };
 #define MREG_ROW(reg, hi) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hi))
 
-// per-dof / per-body model constants used every pass live in LDS (Work::k_*): a read costs one LDS latency, not a
-// global / scratch round trip, and no register is pinned for the whole launch
 struct DofK { float floss, flR; };   // friction-loss row constants of dof (lane & 31), held in registers only inside the solve
 
-// per-env LDS workspace
+// ---- per-env LDS workspace of the substep kernel (and of the probe kernel): 12.5 KB, i.e. TWELVE environments per CU =
+// three wavefronts per SIMD (the gfx950 LDS allocation granule is 1280 B: <= 12800 B buys the twelfth workgroup).
+// Round 3's struct held 19.98 KB (eight per CU).  What went where:
+//   * the state before the last integration (qlag, vlag) and the contact sums of record_contact live in global memory only
+//     (written once per substep / touched only when a hand-object contact exists); the clipped action is re-read from it;
+//   * qacc doubles as the warm start of the next solve (they were copies of each other);
+//   * per-dof model constants other than the body paths are re-read from the L1/L2-resident DevModel;
+//   * vectors that live only between two matrix-core solves (a_smooth, the search direction, the PD torques) sit in the
+//     solves' own scratch (sc.vec overlays sc.T);
+//   * contact rows: four per contact (NCROW = 128; the rare condim-4 contacts take six, the list is cut when the rows run out,
+//     counted in diag[0] like a contact overflow), reference accelerations in registers, p x f_k formed on the fly from c_pos;
+//   * the collision phase stages two contacts per lane (+ a pool for the pairs that can produce four) and the geom rotation
+//     matrices in the region that the dynamics scratch and the solver arrays occupy at other times.
+// scratch of phases that never overlap: dynamics temporaries / the columns of L during a matrix-core solve / vectors that
+// live only between two solves
+union WorkScratch {
+  struct {
+    float I10[NB][10], Ic[NB][10];   // body / composite spatial inertias about the origin (Ic later: subtree forces)
+    union {
+      struct { float fS[NV][6], cfrc[NB][6]; } f;   // Ic*S (later: velocity-product accelerations), body bias forces
+      struct { float jax[NJ][3], janc[NJ][3]; } j;  // joint axes / anchors in the parent-body frame
+    } u;
+  } dyn;
+  float T[NV * LD];                  // columns of L during the matrix-core solves
+  struct { float x[NV], ctrl[NV]; } vec;   // between two solves: a_smooth / the search direction; the PD torques
+};
+#define COLSLOT 2                // contacts staged per lane (= pair) in col_lc
+#define COLPOOL 32               // pairs per pass that can produce more than COLSLOT contacts (DevModel::pair_pool): 2 more each
 struct Work {
-  float qpos[NQP], qvel[NV], qacc[NV], warm[NV], qlag[NQP], vlag[NV], action[NV];
+  float qpos[NQP], qvel[NV], qacc[NV];        // qacc: result of the last solve = warm start of the next one
   // kinematics of the last forward pass
   float xpos[NB][3], xquat[NB][4];
   float gxpos[NG][3];
-  // scratch shared by phases that never overlap
   union {
     struct {
-      float I10[NB][10], Ic[NB][10];   // body / composite spatial inertias about the origin (Ic later: subtree forces)
+      WorkScratch sc;                      // scratch shared by phases that never overlap
+      // ---- solver phase: derived per-contact data, contact rows.
+      // Jacobian-free contacts: row (c,k) of the contact Jacobian is
+      //   sg(dof,c) * S[dof] . W[c][k],   W[c][k] = [p x f_k ; f_k] (k = n,t1,t2),  [f_n ; 0] (spin)
+      // with p = c_pos and f_k = c_frame; p x f_k is never stored (f_k . (v + w x p) instead).
+      float c_mu[MAXCON][3], c_D[MAXCON], c_aref0[MAXCON], c_B[MAXCON];
+      unsigned char c_nrow[MAXCON], c_b1[MAXCON], c_b2[MAXCON], c_row0[MAXCON];
+      unsigned c_mpos[MAXCON], c_mneg[MAXCON];   // dofs moving body2 only (+1) / body1 only (-1)
       union {
-        struct { float fS[NV][6], cfrc[NB][6]; } f;   // Ic*S (later: velocity-product accelerations), body bias forces
-        struct { float jax[NJ][3], janc[NJ][3]; } j;  // joint axes / anchors in the parent-body frame
+        struct { float bV[NB][6]; float u[MAXCON * 4]; };   // body spatial velocities for J.x products; u = (contact-frame J) x
+        float c_G[MAXCON][6];                                // per-contact wrench of J'f (after the rows that read u)
+      };
+      float cr_force[NCROW], cr_curv[NCROW];     // contact rows (pyramid edges)
+      unsigned char cr_ce[NCROW];                // contact << 3 | edge
+    };
+    // ---- collision phase: every lane (= pair) stages up to COLSLOT contacts of 7 floats (dist, pos, normal), element
+    // (q, k) of lane l at col_lc[(q * 7 + k) * NT + l]; pairs that can produce more own a pool entry for contacts 2, 3;
+    // clipping scratch of the wave-cooperative box-box; geom rotation matrices (kinematics -> collision only)
+    struct { float col_lc[COLSLOT * 7 * NT]; float col_pool[COLPOOL][2 * 7]; float col_poly[32]; float gxmat[NG][9]; };
+  };
+  // contacts of the current forward pass
+  int ncon, nrow, solver_iter, fail, capped;
+  float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
+  unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
+  unsigned k_bpath[NB][3];             // packed dof paths of the bodies (model constant, loaded once per launch)
+  float applied[NV], bias[NV], ftot[NV];   // applied + actuator forces; bias forces; f_smooth + J'f of the last solve
+  float S[NV][6];                      // motion axes [angular; linear at the world origin]
+#ifdef HOIC_PHASE_TIMING
+  long long pt[24], pt_last;
+#endif
+};
+#ifndef HOIC_PHASE_TIMING
+static_assert(sizeof(Work) <= 12800, "Work must stay within 10 LDS granules of 1280 B: 12 environments per CU");
+#endif
+static_assert(offsetof(Work, gxmat) >= offsetof(Work, c_mu), "gxmat must not overlay the dynamics scratch (written while it is live)");
+static_assert(offsetof(Work, col_poly) + sizeof(((Work*)0)->col_poly) <= offsetof(Work, gxmat), "collision staging layout");
+
+// ---- workspace of the post-step kernel, the reset kernel and the QP probe (float64 QP, kinematics of a reset): the
+// residual-force QP keeps its columns in qp_col (up to 19 contacts x 5 points x 4 edges, 7 floats each, column c of component
+// k at qp_col[k * QP_MAXCOL + c])
+#define QP_MAXCOL (NHG * 5 * 4)
+#define QP_COL_FLOATS (7 * QP_MAXCOL)
+struct PostWork {
+  float qpos[NQP], qvel[NV], qacc[NV], action[NV];
+  float xpos[NB][3], xquat[NB][4];
+  float gxpos[NG][3];
+  union {
+    struct {
+      float I10[NB][10], Ic[NB][10];
+      union {
+        struct { float fS[NV][6], cfrc[NB][6]; } f;
+        struct { float jax[NJ][3], janc[NJ][3]; } j;
       } u;
     } dyn;
-    float T[NV * LD];                  // columns of L during the matrix-core solves
-    struct {                           // post-step kernel only
+    struct {
       double qp_G[36];                 // residual-force QP: Gram matrix of the passive columns (packed lower 8 x 8)
       float qp_a[8][8];                //                    the passive columns themselves (a[6], c, pad)
       float avg_cps[NHG][12]; int avg_geom[NHG]; float avg_ts[NHG]; int n_avg;
       float gvel[NG][3], gangvel[NG][3], obj_avg_acc[6];
     } post;
   } sc;
-  // ---- from here to gxmat: not used by the post-step kernel before its reset path; its residual-force QP keeps
-  // its columns there (qp_cols(), QP_COL_FLOATS floats from col_lc on; layout asserted below)
-  union {
-    // ---- solver phase: derived per-contact data, contact rows, search direction.
-    // Jacobian-free contacts: row (c,k) of the contact Jacobian is
-    //   sg(dof,c) * S[dof] . W[c][k],   W[c][k] = [p x f_k ; f_k] (k = n,t1,t2),  [f_n ; 0] (spin)
-    // with p x f_k kept in c_pxf and f_k in c_frame.
-    struct {
-      float c_pxf[MAXCON][3][3], c_mu[MAXCON][3], c_D[MAXCON], c_aref0[MAXCON], c_B[MAXCON];
-      unsigned char c_nrow[MAXCON], c_b1[MAXCON], c_b2[MAXCON], c_row0[MAXCON];
-      unsigned c_mpos[MAXCON], c_mneg[MAXCON];   // dofs moving body2 only (+1) / body1 only (-1)
-      float c_G[MAXCON][6];
-      float u[MAXCON * 4];
-      float bV[NB][6];                           // body spatial velocities for J.x products
-      float cr_aref[NCROW], cr_force[NCROW], cr_curv[NCROW];   // contact rows (pyramid edges)
-      unsigned char cr_con[NCROW], cr_edge[NCROW];
-      float search[NV];
-    };
-    // ---- collision phase: every lane (= pair) stages up to 4 contacts of 7 floats (dist, pos, normal), element
-    // (q, k) of lane l at col_lc[(q * 7 + k) * NT + l]; clipping scratch of the wave-cooperative box-box
-    struct { float col_lc[4 * 7 * NT]; float col_poly[32]; };
-  };
-  // contacts of the current forward pass
-  int ncon, nrow, solver_iter, fail, capped;
-  float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
-  unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
-  // model constants used every pass (loaded once per launch)
-  float k_arm[NV], k_damp[NV], k_floss[NV], k_flR[NV], k_flB[NV]; int k_act[NV];
-  unsigned k_bpath[NB][3];
-  float ctrl[NV], applied[NV], bias[NV], fsmooth[NV], asmooth[NV], fcon[NV];
-  float S[NV][6];                      // motion axes [angular; linear at the world origin]
+  float qp_col[QP_COL_FLOATS];
+  float S[NV][6];
   float gxmat[NG][9];
-  // contact bookkeeping over the env step (record_contact)
   float rec_sum[NHG][12]; int rec_cnt[NHG];
-#ifdef HOIC_PHASE_TIMING
-  long long pt[24], pt_last;
-#endif
 };
-#ifndef HOIC_PHASE_TIMING
-static_assert(sizeof(Work) <= 20480, "Work must stay under 20 KB: 8 environments per CU");
-#endif
-// residual-force QP columns (post-step kernel): up to 19 contacts x 5 points x 4 edges, 7 floats each, column c of
-// component k at qp_cols[k * QP_MAXCOL + c]
-#define QP_MAXCOL (NHG * 5 * 4)
-#define QP_COL_FLOATS (7 * QP_MAXCOL)
-static_assert(offsetof(Work, gxmat) + sizeof(((Work*)0)->gxmat) - offsetof(Work, col_lc) >= QP_COL_FLOATS * 4, "QP column overlay");
 
 #ifdef HOIC_PHASE_TIMING
 #define PT(i) do { long long t_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) { w.pt[i] += t_ - w.pt_last; w.pt_last = t_; } } while (0)

@@ -102,7 +102,9 @@ def set_pipeline(mode: int):
     and write no transposed copies, the weight gradients come from the row-major kernel (hoic_mlp_gemm_tn); 2 = the same
     4-wavefront K16 main loop in the other orientation with transposed copies (the independently laid out form the tests
     compare against).  HOIC_GEMM_MODE overrides the default."""
-    mode = 3 if int(mode) >= 3 else 2
+    if int(mode) not in (2, 3):
+        raise ValueError(f"GEMM pipeline mode {mode}: only 2 and 3 exist (the 8-wavefront forms 0 / 1 were removed in round 3)")
+    mode = int(mode)
     global GEMM_MODE
     GEMM_MODE = int(mode)
     kernels().L.hoic_mlp_set_pipeline(int(mode))
@@ -118,7 +120,9 @@ def kernels():
         import os
         global GEMM_MODE
         if os.environ.get("HOIC_GEMM_MODE"):
-            GEMM_MODE = 3 if int(os.environ["HOIC_GEMM_MODE"]) >= 3 else 2
+            if int(os.environ["HOIC_GEMM_MODE"]) not in (2, 3):
+                raise ValueError("HOIC_GEMM_MODE must be 2 or 3")
+            GEMM_MODE = int(os.environ["HOIC_GEMM_MODE"])
         _K.L.hoic_mlp_set_pipeline(GEMM_MODE)
     return _K
 
@@ -478,11 +482,20 @@ class _HeadLinear(torch.autograd.Function):
             return _head_backward(hidden, weight, g.contiguous())
 
 
+def _head_on_device(hidden, linear):
+    """The one predicate of the HIP head kernels: float32 CUDA ``hidden`` (row stride a multiple of 4 floats, K % 16 == 0) and a
+    float32 nn.Linear with bias and <= 32 outputs ON THE SAME DEVICE (the kernels take raw pointers)."""
+    w, b = linear.weight, linear.bias
+    return (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.dim() == 2 and hidden.stride(1) == 1 and hidden.shape[1] % 16 == 0
+            and hidden.stride(0) % 4 == 0 and w.shape[0] <= 32 and w.is_contiguous() and b is not None
+            and w.dtype == torch.float32 and b.dtype == torch.float32 and w.device == hidden.device and b.device == hidden.device
+            and b.is_contiguous())
+
+
 def head_linear(hidden, linear):
-    """``linear(hidden)`` for the nn.Linear head of a network whose body ran on the f16x3 engine (float32 CUDA ``hidden`` with
-    K % 16 == 0 and <= 32 outputs: the HIP head kernels, differentiable); anything else goes to the module itself."""
-    if (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.dim() == 2 and hidden.stride(1) == 1 and hidden.shape[1] % 16 == 0
-            and hidden.stride(0) % 4 == 0 and linear.weight.shape[0] <= 32 and linear.weight.is_contiguous() and linear.bias is not None):
+    """``linear(hidden)`` for the nn.Linear head of a network whose body ran on the f16x3 engine (see _head_on_device: the HIP
+    head kernels, differentiable); anything else goes to the module itself."""
+    if _head_on_device(hidden, linear):
         return _HeadLinear.apply(hidden, linear.weight, linear.bias)
     return linear(hidden)
 
@@ -503,11 +516,12 @@ def _head_backward(hidden, weight, g):
     return dh, grad[:N_ * K_].view(N_, K_), grad[N_ * K_:N_ * K_ + N_]
 
 
+FORCE_AUTOGRAD_HEADS = False      # A/B switch (tools/reward_curve.py "+autograd"): heads and losses through PyTorch autograd
+
+
 def heads_fusable(hidden, linear):
     """whether ppo_head_step / value_head_step can run on ``hidden`` (what head_linear needs)"""
-    return (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.dim() == 2 and hidden.stride(1) == 1 and hidden.shape[1] % 16 == 0
-            and hidden.stride(0) % 4 == 0 and linear.weight.shape[0] <= 32 and linear.weight.is_contiguous() and linear.bias is not None
-            and linear.weight.dtype == torch.float32)
+    return (not FORCE_AUTOGRAD_HEADS) and _head_on_device(hidden, linear)
 
 
 def ppo_head_step(hidden, policy, actions, advantages, fixed_log_probs, clip_epsilon, weight=1.0):

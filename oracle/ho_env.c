@@ -209,7 +209,13 @@ void hoo_env_compute_torque(const ho_env* e, const double* ctrl, double* torque)
   for (int i = 3; i < 6; i++) target[i] = ref[i] + 0.3 * ctrl[i];
   for (int i = 6; i < n; i++) target[i] = (e->cfg.pd_rel ? ref[i] : e->base_pose[i]) + e->ctrl_scale[i] * ctrl[i];
   for (int i = 0; i < n; i++) err[i] = d->qpos[i] + d->qvel[i] * dt - target[i];
-  for (int i = 3; i < n; i++) { while (err[i] > M_PI) err[i] -= 2 * M_PI; while (err[i] < -M_PI) err[i] += 2 * M_PI; }
+  /* the reference's while loops (ho_im4.py:476-481) with the trip limit of the HIP kernel (hoic_env.h dev_pd_torque): a
+     runaway test-mode state (|err| > 33 pi) would otherwise spin for ages here and hang the GPU launch there; both sides
+     give the same result for every |err| */
+  for (int i = 3; i < n; i++) {
+    for (int k = 0; k < 16 && err[i] > M_PI; k++) err[i] -= 2 * M_PI;
+    for (int k = 0; k < 16 && err[i] < -M_PI; k++) err[i] += 2 * M_PI;
+  }
   /* compute_desired_accel: chol(M[:26,:26] + Kd dt)^-1 (-C - Kp e - Kd qd), M and C from the LAST forward pass */
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) A[i * NU + j] = d->qM[i * NV + j];

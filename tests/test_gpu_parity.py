@@ -622,6 +622,32 @@ def test_logger_statistics_exclude_end_bonus(box_blob, box_model):
     agent.env.close()
 
 
+def test_rollout_filter_forks_are_ordered_before_the_side_streams(box_blob, setup):
+    """The per-range forks of the observation filter are the first thing a range's chain reads on its side stream: they must be
+    made on the main stream BEFORE the side streams take their wait point on it (round 3 made them after it: a side stream could
+    normalise its first states with an all-zero filter and the garbage increment was merged into the shared filter for good).
+    A main stream that is held back by a long sleep kernel in front of the rollout must change nothing."""
+    _, ex, _ = setup
+    outs = []
+    for delay in (False, True):
+        torch.manual_seed(5)                               # (the networks are initialised from the global generator)
+        agent = _small_agent(ex, 64, 64 * 6, seed=3)
+        agent.n_groups = 2
+        torch.manual_seed(11)
+        agent.sample(64 * 6)                               # a first rollout: the filter now holds statistics worth losing
+        torch.cuda.synchronize()
+        torch.manual_seed(12)
+        if delay:
+            torch.cuda._sleep(400_000_000)                 # ~0.2 s of main-stream work in front of the rollout's set-up
+        batch, _ = agent.sample(64 * 6)
+        torch.cuda.synchronize()
+        outs.append((batch.states.clone(), agent.running_state.n.clone(), agent.running_state.mean.clone(), agent.running_state.S.clone()))
+        agent.env.close()
+    for a, b in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+    assert float(outs[0][1]) == 2 * 64 * 6
+
+
 def test_sample_episodes_mode_is_the_reference_batch(box_blob, setup):
     """sample_mode='episodes' (sample_process, agent_handmimic.py:430-501): every env collects whole episodes until it
     holds floor(min_batch / n_envs) steps; every episode in the batch is complete, nothing is bootstrapped."""
@@ -950,31 +976,6 @@ def test_zfilter_device_path_matches_tensor_path():
     x = torch.randn(300, 617, generator=g).to(dev)
     torch.testing.assert_close(a(x, update=False), b(x, update=False), rtol=0, atol=2e-6)
     assert torch.equal(st, a._st)
-
-
-def test_fused_step_matches_two_launches(box_blob, setup, monkeypatch):
-    """HOIC_FUSED_STEP=1 (post-step work at the end of the substep launch, a second instantiation of the substep kernel):
-    same outputs and states up to float32 rounding (the two instantiations contract multiply-adds differently)."""
-    cfg, ex, thresh = setup
-    N = 128
-    a_sim = _sim(box_blob, N, cfg, ex, thresh)
-    monkeypatch.setenv("HOIC_FUSED_STEP", "1")
-    b_sim = _sim(box_blob, N, cfg, ex, thresh)
-    monkeypatch.delenv("HOIC_FUSED_STEP")
-    g = torch.Generator().manual_seed(12)
-    seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(120, 260, (N,), generator=g, dtype=torch.int32)
-    a_sim.reset(seq, start); b_sim.reset(seq, start)
-    for t in range(3):
-        act = (torch.randn(N, 32, generator=g) * 0.3).cuda()
-        ra = [x.clone() for x in a_sim.step(act)]
-        rb = [x.clone() for x in b_sim.step(act)]
-        torch.testing.assert_close(ra[0], rb[0], rtol=0, atol=5e-4)          # obs
-        torch.testing.assert_close(ra[1], rb[1], rtol=0, atol=1e-4)          # reward
-        torch.testing.assert_close(ra[2], rb[2], rtol=0, atol=1e-4)          # reward terms
-        assert torch.equal(ra[3][:, :3], rb[3][:, :3])                        # fail / end / done
-    qa, va, _ = a_sim.get_state(); qb, vb, _ = b_sim.get_state()
-    torch.testing.assert_close(qa, qb, rtol=0, atol=1e-4); torch.testing.assert_close(va, vb, rtol=0, atol=5e-3)
-    torch.testing.assert_close(a_sim.rfc_score(), b_sim.rfc_score(), rtol=1e-3, atol=1e-4)
 
 
 def test_gae_device_path_is_bit_identical():

@@ -314,11 +314,24 @@ def run_hip_arm(args, arm, seed):
     model = mjcf.load_packaged(args.obj)
     expert = motions.synthetic_expert(model, N_SEQ, SEQ_LEN)
     torch.manual_seed(seed)
+    # "<arm>+<switch>+...": attribution switches on top of an arm
+    #   g1        one env range: ONE observation filter updated by every step's whole batch (no per-range forks, no side streams)
+    #   torchfwd  the rollout's policy forward in PyTorch float32 with its own N(0, 1) draw per step (no tiled f16x3 forward, no
+    #             up-front noise tensor)
+    #   autograd  the update's heads and losses through PyTorch autograd (no hoic_mlp_head / ppo_loss / value_loss kernels)
+    #   racy      round 3's fork order: the per-range filter forks are made AFTER the side streams' wait point
+    base, *switches = arm.split("+")
     mode, n_envs = {"hip_fixed": ("fixed", args.envs), "hip_episodes": ("episodes", args.episode_workers),
                     "hip_episodes_frozen": ("episodes", args.episode_workers),
-                    "hip_fixed_long": ("fixed", max(args.envs // 4, 1)), "hip_fixed_f16x3": ("fixed", args.envs)}[arm]
+                    "hip_fixed_long": ("fixed", max(args.envs // 4, 1)), "hip_fixed_f16x3": ("fixed", args.envs)}[base]
+    if "autograd" in switches:
+        from hoic_amd import mlp as _mlp
+        _mlp.FORCE_AUTOGRAD_HEADS = True
+    if "racy" in switches:
+        os.environ["HOIC_FORK_AFTER_WAIT"] = "1"
     agent = AgentHandMimic(cfg, device=dev, n_envs=n_envs, model=args.obj, expert_seqs=expert, sample_mode=mode,
-                           update_dtype="f16x3" if arm.endswith("f16x3") else "f32", filter_mode="frozen" if arm.endswith("_frozen") else "online")
+                           update_dtype="f16x3" if base.endswith("f16x3") else "f32", filter_mode="frozen" if base.endswith("_frozen") else "online",
+                           n_groups=1 if "g1" in switches else None, rollout_forward="torch" if "torchfwd" in switches else "tiled")
     curve, evals = [], []
     t_start = time.time()
     for it in range(args.iters + 1):
@@ -371,6 +384,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--arms", default="cpu_episodes,hip_fixed,hip_episodes")
     ap.add_argument("--seeds", type=int, default=5)
+    ap.add_argument("--seed0", type=int, default=1, help="first seed (runs use seed0 .. seed0 + seeds - 1)")
     ap.add_argument("--cpu-fixed-seeds", type=int, default=None, help="seeds of the cpu_fixed arm (default: --seeds)")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--eval-every", type=int, default=5)
@@ -397,13 +411,13 @@ def main():
     jobs = []
     for arm in arms:
         ns = args.cpu_fixed_seeds if (arm == "cpu_fixed" and args.cpu_fixed_seeds is not None) else args.seeds
-        jobs += [(arm, 1 + s) for s in range(ns)]
+        jobs += [(arm, args.seed0 + s) for s in range(ns)]
     # every run is its own process (its own HIP context); CPU runs and whole-episode HIP runs are latency-bound and run
     # side by side, the fixed-horizon HIP runs fill the GPU and go one after the other
     common = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--eval-every", str(args.eval_every),
               "--workers", str(args.workers), "--slots", str(args.slots), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
     t0 = time.time()
-    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3")]
+    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0].split("+")[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3")]
     procs = []
     for arm, seed in side:
         f = os.path.join(tmp, f"{arm}_{seed}.json")
