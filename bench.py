@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps 130 --warmup 26
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher around it: starts the N ranks itself as a child process, exits non-zero
+                                         when fewer than N GPUs are visible)
 
 A "step" is one pass of the hot path over the whole batch: running observation filter + policy forward + one fused HIP
 env step (15 physics substeps, reward, observation) for every env of every rank.  The PPO update (GAE + 5 full-batch
@@ -51,32 +53,36 @@ def _latest_profile(pattern, pred=lambda d: True):
     return best
 
 
-def traffic_from_profile(envs, obj):
+def traffic_from_profile(envs, obj, build_id):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/sim_only.py, FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950).  Counters cannot be read inside this process, so the number is only reported when a
-    profile was taken at the same env count and object; otherwise null."""
-    p = _latest_profile("*_hbm_traffic*.json", lambda d: d.get("envs") == envs and d.get("kernel") == "hoic_substep_kernel" and d.get("obj", "box") == obj)
+    profile was taken at the same env count and object ON THE LIBRARY THAT IS LOADED (hoic_build_id); otherwise null."""
+    p = _latest_profile("*_hbm_traffic*.json", lambda d: d.get("envs") == envs and d.get("kernel") == "hoic_substep_kernel" and d.get("obj", "box") == obj
+                        and d.get("build_id") == build_id)
     return None if p is None else p[1]["traffic_bytes_per_launch"]
 
 
-def valu_roofline(kernel_ms, envs_per_launch, rollout_env_steps=None, rollout_s=None):
+def valu_roofline(kernel_ms, envs_per_launch, build_id, rollout_env_steps=None, rollout_s=None):
     """The dominant kernel against the vector-issue peak: VALU instructions per wavefront (= per env-step) from the
     committed SQ counter pass (profiles/*_substep_sq_counters.json) x 64 lanes x envs per launch / the launch time
     measured here.  `achieved` / `frac` price ONE launch against the whole chip although the rollout keeps one launch per
     env range in flight; `achieved_chip` / `frac_chip` sum over all launches of the timed rollouts: lane-operations of
     every env-step stepped / the rollouts' wall time (a lower bound of the chip-wide issue rate while the substep
-    kernels run: the wall time also holds the policy forwards, the filter and the end-of-rollout work)."""
-    p = _latest_profile("*_substep_sq_counters.json")
+    kernels run: the wall time also holds the policy forwards, the filter and the end-of-rollout work).
+    The counters are static properties of the kernel binary: a pass is quoted only when it was taken on the library that
+    is loaded (hoic_build_id recorded in the profile); with another library the object says so instead of quoting stale numbers."""
+    p = _latest_profile("*_substep_sq_counters.json", lambda d: d.get("build_id") == build_id)
     if p is None or kernel_ms <= 0:
-        return None
+        return {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-ops/s", "frac": None,
+                "note": f"no SQ counter pass under profiles/ was taken on this library (hoic_build_id {build_id}): re-run tools/run_measurements.sh part 2"}
     name, d = p
     c = d["per_env_step"]
     lane_ops = float(c["SQ_INSTS_VALU"]) * 64.0
     achieved = lane_ops * envs_per_launch / (kernel_ms * 1e-3)
     wc = float(c.get("SQ_WAVE_CYCLES", 0)) or None
     out = {"bound": "valu-issue", "achieved": achieved, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-ops/s", "frac": achieved / VALU_PEAK_LANE_OPS,
-           "valu_insts_per_env_step": c["SQ_INSTS_VALU"], "source": name,
+           "valu_insts_per_env_step": c["SQ_INSTS_VALU"], "source": name, "build_id": build_id,
            "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)) if ("SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_INSTS_VALU")) else None}
     if out["active_lane_fraction"]:      # lanes that carried work: the issue slots above count idle lanes as used
         out["achieved_active"] = achieved * out["active_lane_fraction"]; out["frac_active"] = out["achieved_active"] / VALU_PEAK_LANE_OPS
@@ -191,6 +197,65 @@ def cpu_baseline(seconds=24.0):
                       f"cannot run here: MuJoCo is not in the image"}
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a torch.distributed launcher around it: this process -- which never touches the GPU (counting
+    devices does not initialise it) -- starts the N ranks as a CHILD process (`python -m torch.distributed.run`), relays rank 0's
+    JSON line and exits with the child's code.  With fewer than N visible devices it exits non-zero instead of quietly running
+    one rank."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible: not running (a 1-rank line must not pass for an {n}-GPU one)\n")
+        sys.exit(3)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n"); sys.stdout.flush()
+    sys.exit(p.returncode if p.returncode != 0 or lines else 4)
+
+
+def quick_config(obj, args, device, iterations=8, warm=4):
+    """BASELINE.json configs 3 and 4 (Bottle, Banana: the convex-mesh contact paths) next to the headline: the same loop, `warm`
+    untimed and `iterations` timed PPO iterations each (the first iterations of a fresh agent carry one-time costs: allocator,
+    stream and engine set-up) -- enough for a driver-timed number, not a substitute for a full run."""
+    import torch
+    from hoic_amd import mjcf, motions
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config
+    cfg = Config(f"{obj}_future5_light_add_geom")
+    model = mjcf.load_packaged(obj)
+    expert = motions.synthetic_expert(model, 17, 600)
+    agent = AgentHandMimic(cfg, device=device, n_envs=args.envs, model=obj, expert_seqs=expert, update_dtype=args.update_dtype,
+                           n_groups=args.groups, rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward),
+                           update_streams=args.update_streams)
+    for it in range(warm):
+        agent.optimize_policy(it, save_model=False)
+    agent.env.sim.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.time(); ts = tu = 0.0; k_ms = []; steps = 0
+    for it in range(iterations):
+        info = agent.optimize_policy(warm + it, save_model=False)
+        ts += info["T_sample"]; tu += info["T_update"]; steps += int(agent.last_rollout_steps)
+        k_ms += agent.env.sim.step_times()[0]
+    agent.learner.finish_update(); torch.cuda.synchronize()
+    el = time.time() - t0
+    n = steps * args.envs
+    diag = agent.env.sim.diagnostics()
+    out = {"workload": f"{obj.capitalize()}, {args.envs} parallel envs, whole loop", "value": n / el, "unit": "env-steps/s", "timed_iterations": iterations,
+           "rollout_only_env_steps_per_s": n / ts, "update_s_per_iteration": tu / iterations, "kernel": "hoic_substep_kernel",
+           "kernel_ms": sum(k_ms) / max(len(k_ms), 1), "envs_per_launch": args.envs // len(agent._groups()),
+           "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"]}
+    agent.env.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,14 +280,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=None, help="Newton iteration cap per substep (default: the model's <option iterations>, 20)")
     ap.add_argument("--groups", type=int, default=None, help="env ranges pipelined on separate streams during the rollout (default: 2 at >= 4096 envs)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="compute units kept free of substep workgroups during the rollout (hoic_set_cu_reserve; multiple of 8)")
     ap.add_argument("--sample-mode", default="fixed", choices=["fixed", "episodes"],
                     help="fixed: fixed-horizon batches of every env (the GPU default, what `value` of the headline is quoted on); episodes: the "
                          "reference's batch (agent_handmimic.py:430-535): every env is one sampler worker collecting WHOLE episodes until it holds "
                          "floor(50000 / envs) steps -- use with --envs 32 for the reference's --num_threads 32 shape")
-    ap.add_argument("--min-iterations", type=int, default=10,
-                    help="the timed region holds at least this many PPO iterations whatever --steps asks for (a 2-iteration region is 0.14 s: not a "
-                         "measurement); steps_requested keeps the flag's value")
+    ap.add_argument("--min-iterations", type=int, default=30,
+                    help="the timed region holds at least this many PPO iterations whatever --steps asks for (30 iterations = 2 s; a 2-iteration "
+                         "region is 0.14 s and a 10-iteration one sits inside the box-to-box spread: not measurements); steps_requested keeps the flag's value")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="1 (one rank, default Box run only): append `other_configs` = Bottle and Banana at the same settings, 8 timed iterations each")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)           # does not return
 
     # Exactly ONE line on stdout: libraries print banners to file descriptor 1 (RCCL's version block at communicator creation),
     # so everything but the JSON line goes to stderr for the whole run.
@@ -255,7 +325,7 @@ def main():
     expert = motions.synthetic_expert(model, 17, 600, grasp="closed" if args.workload == "closed-grasp" else "kinematic")   # 17 sequences x 600 frames
     agent = AgentHandMimic(cfg, device=torch.device("cuda", local_rank), n_envs=args.envs, model=args.obj,
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
-                           solver_iterations=args.solver_iterations, n_groups=args.groups, scaling=args.scaling,
+                           solver_iterations=args.solver_iterations, n_groups=args.groups, reserve_cus=args.reserve_cus, scaling=args.scaling,
                            start_min=100 if args.workload in ("grasp", "closed-grasp") else 0, overlap_value_update=bool(args.overlap),
                            rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams,
                            sample_mode=args.sample_mode)
@@ -314,6 +384,8 @@ def main():
 
     if rank == 0:
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        from hoic_amd import lib as _lib
+        build_id = _lib.build_id()
         n_groups = len(agent._groups())
         envs_per_launch = args.envs // n_groups          # the rollout steps the batch as n_groups env ranges (hoic_step_range)
         achieved = ALGO_BYTES_PER_ENV_STEP * envs_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -355,15 +427,19 @@ def main():
                                "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"],
                                "solver_cap_hit_fraction_of_substeps": diag["solver_cap_hits"] / float(K * args.envs * cfg.sim_step)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(envs_per_launch, args.obj), "kernel": "hoic_substep_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(envs_per_launch, args.obj, build_id), "kernel": "hoic_substep_kernel",
                          "kernel_ms": k_ms, "poststep_kernel_ms": sum(post_ms) / max(len(post_ms), 1),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * envs_per_launch, "envs_per_launch": envs_per_launch,
                          "note": "launch durations are HIP-event times on each range's own stream; with 2 ranges in flight a launch "
                                  "shares the GPU with the other range's kernels" if n_groups > 1 else None},
-            "roofline_valu": valu_roofline(k_ms, envs_per_launch, K * args.envs, t_sample),
+            "roofline_valu": valu_roofline(k_ms, envs_per_launch, build_id, K * args.envs, t_sample),
         }
         if args.update_dtype == "f16x3":
             out["roofline_update_gemm"] = update_gemm_roofline(steps_per_iter * args.envs, torch.device("cuda", local_rank))
+        if (args.other_configs and world == 1 and args.obj == "box" and args.workload == "train" and args.sample_mode == "fixed"
+                and not args.pretrain and args.envs == 4096):
+            agent.env.close()
+            out["other_configs"] = {o: quick_config(o, args, torch.device("cuda", local_rank)) for o in ("bottle", "banana")}
         out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

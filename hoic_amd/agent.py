@@ -375,7 +375,7 @@ class AgentHandMimic:
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
                  start_min=0, overlap_value_update=False, rollout_forward="tiled", async_reward=True, fused_adam=True,
-                 update_streams=2, filter_mode="online"):
+                 update_streams=2, filter_mode="online", reserve_cus=0):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
@@ -385,6 +385,9 @@ class AgentHandMimic:
         # off its critical path (hoic_set_async_reward);  both are on by default and exist as switches for A/B measurements
         assert rollout_forward in ("tiled", "torch")
         self.rollout_forward, self.async_reward = rollout_forward, bool(async_reward)
+        # reserve_cus: compute units kept free of substep workgroups during a pipelined rollout (hoic_set_cu_reserve; a
+        # scheduling knob, 0 = off)
+        self.reserve_cus = int(reserve_cus)
         # observation filter during sampling: "online" = every step's observations update it before they are normalised (the
         # reference's ZFilter updates row by row inside its sampler, zfilter.py:59-73); "frozen" = a rollout is normalised with
         # the statistics of the iterations before it and its valid observations are merged afterwards (what a sampler that
@@ -451,10 +454,13 @@ class AgentHandMimic:
         G = max(1, min(self.n_groups, self.n_envs)) if self.device.type == "cuda" else 1
         if G > 1 and (self._streams is None or len(self._streams) != G):
             self._streams = [torch.cuda.Stream(self.device) for _ in range(G)]
-        c, r = divmod(self.n_envs, G)            # the first r ranges are one env longer
+        # ranges in units of 64 envs when the batch allows it (the tiled policy forward wants multiples of 32 rows), the first
+        # ranges one unit longer; otherwise env by env
+        unit = 64 if (self.n_envs % 64 == 0 and self.n_envs // 64 >= G) else 1
+        c, r = divmod(self.n_envs // unit, G)
         out, first = [], 0
         for g in range(G):
-            n = c + (1 if g < r else 0)
+            n = (c + (1 if g < r else 0)) * unit
             out.append((first, n)); first += n
         return out
 
@@ -572,6 +578,7 @@ class AgentHandMimic:
         async_reward = direct and self.async_reward
         if async_reward:
             self.env.sim.set_async_reward(True)
+            self.env.sim.set_cu_reserve(self.reserve_cus if use_streams else 0)
         gemm_done = None
         t_host0 = time.perf_counter()
         for t in range(T):

@@ -22,6 +22,10 @@ static thread_local std::string g_err;
 static void set_err(const std::string& s) { g_err = s; }
 void hoic_set_error(const std::string& s) { g_err = s; }     // for the other translation units of the library (hoic_mlp.hip)
 extern "C" const char* hoic_last_error(void) { return g_err.c_str(); }
+#ifndef HOIC_BUILD_ID
+#define HOIC_BUILD_ID "unknown"
+#endif
+extern "C" const char* hoic_build_id(void) { return HOIC_BUILD_ID; }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return HOIC_ERR_DEVICE; } } while (0)
 
@@ -626,7 +630,9 @@ struct hoic_sim {
   // split post-step (hoic_set_async_reward): per env range a side stream for the reward part, the record buffer of the next
   // step and the events "reward part of the step that used buffer b has finished"
   struct AsyncRange { int first = 0, count = 0, next_buf = 0; hipStream_t side = nullptr; hipEvent_t sub_done = nullptr, ord_done = nullptr, rew_done[2] = {nullptr, nullptr};
-                      bool pending[2] = {false, false}; bool order_ready = false; };
+                      bool pending[2] = {false, false}; bool order_ready = false;
+                      hipStream_t sub = nullptr; int sub_reserve = 0; hipEvent_t in_ready = nullptr; };   // CU-masked substep stream (hoic_set_cu_reserve)
+  int reserve_cus = 0;
   bool async_reward = false;
   std::vector<AsyncRange> ranges;
   int expert_reserve = 0, expert_cap = 0;   // streaming: room for more frames behind the last sequence
@@ -1004,6 +1010,8 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   for (auto& r : s->ranges) {
     if (r.side) { hipStreamSynchronize(r.side); hipStreamDestroy(r.side); }
+    if (r.sub) { hipStreamSynchronize(r.sub); hipStreamDestroy(r.sub); }
+    if (r.in_ready) hipEventDestroy(r.in_ready);
     if (r.sub_done) hipEventDestroy(r.sub_done);
     if (r.ord_done) hipEventDestroy(r.ord_done);
     for (int b = 0; b < 2; b++) if (r.rew_done[b]) hipEventDestroy(r.rew_done[b]);
@@ -1172,14 +1180,33 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
     // the order kernel behind this step rewrites order[first, first + count): other ranges that overlap it lose theirs
     for (auto& q : s->ranges) if (&q != r && q.first < first + count && first < q.first + q.count) q.order_ready = false;
     const int buf = r->next_buf; r->next_buf ^= 1;
-    if (r->pending[buf]) HIPCHK(hipStreamWaitEvent(st, r->rew_done[buf], 0));      // the reward part of step t - 2 read this record
+    // hoic_set_cu_reserve: the substep kernel goes to the range's CU-masked stream `ks`, behind everything the caller has
+    // enqueued so far; the caller's stream continues behind the kernel (sub_done below)
+    hipStream_t ks = st;
+    if (s->reserve_cus > 0) {
+      if (r->sub && r->sub_reserve != s->reserve_cus) { HIPCHK(hipStreamSynchronize(r->sub)); HIPCHK(hipStreamDestroy(r->sub)); r->sub = nullptr; }
+      if (!r->sub) {
+        int ncu = 0;
+        HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device));
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = s->reserve_cus; i < ncu; i++) mask[i / 32] |= 1u << (i % 32);     // bit i = CU (i / 8) of XCD (i % 8): tools/probe/cu_mask.hip
+        HIPCHK(hipExtStreamCreateWithCUMask(&r->sub, (uint32_t)mask.size(), mask.data()));
+        r->sub_reserve = s->reserve_cus;
+        if (!r->in_ready) HIPCHK(hipEventCreateWithFlags(&r->in_ready, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(r->in_ready, st));
+      HIPCHK(hipStreamWaitEvent(r->sub, r->in_ready, 0));
+      ks = r->sub;
+    }
+    if (r->pending[buf]) HIPCHK(hipStreamWaitEvent(ks, r->rew_done[buf], 0));      // the reward part of step t - 2 read this record
     const int have_order = (use_order && r->order_ready) ? 1 : 0;
-    if (have_order) HIPCHK(hipStreamWaitEvent(st, r->ord_done, 0));                // this range's launch order (made behind its previous step)
-    if (e) hipEventRecord(e[0], st);
-    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, st, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, have_order,
+    if (have_order) HIPCHK(hipStreamWaitEvent(ks, r->ord_done, 0));                // this range's launch order (made behind its previous step)
+    if (e) hipEventRecord(e[0], ks);
+    hipLaunchKernelGGL(hoic_substep_kernel<2>, dim3(count), dim3(NT), 0, ks, s->d_model, s->d_cfg, s->d_ex, s->d_st, d_action, first, have_order,
                        s->use_lag ? 1 : 0, d_obs, d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, s->n_envs, buf);
-    if (e) hipEventRecord(e[1], st);
-    HIPCHK(hipEventRecord(r->sub_done, st));
+    if (e) hipEventRecord(e[1], ks);
+    HIPCHK(hipEventRecord(r->sub_done, ks));
+    if (ks != st) HIPCHK(hipStreamWaitEvent(st, r->sub_done, 0));
     HIPCHK(hipStreamWaitEvent(r->side, r->sub_done, 0));
     if (use_order) {
       hipLaunchKernelGGL(hoic_order_kernel, dim3(1), dim3(ORDER_NT), 0, r->side, s->st.cost, s->st.order, s->n_envs, first, count);
@@ -1223,6 +1250,15 @@ extern "C" int32_t hoic_set_async_reward(hoic_sim* s, int32_t enable, void* stre
   HIPCHK(hipSetDevice(s->device));
   if (!enable) { const int32_t rc = drain_rewards(s, (hipStream_t)stream); if (rc != HOIC_OK) return rc; }
   s->async_reward = enable != 0;
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_set_cu_reserve(hoic_sim* s, int32_t n_cus) {
+  if (!s) { set_err("hoic_set_cu_reserve: null handle"); return HOIC_ERR_ARG; }
+  int ncu = 0;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device));
+  if (n_cus < 0 || n_cus % 8 != 0 || n_cus > ncu - 8) { set_err("hoic_set_cu_reserve: n_cus must be a multiple of 8 in [0, CUs - 8]"); return HOIC_ERR_ARG; }
+  s->reserve_cus = n_cus;
   return HOIC_OK;
 }
 extern "C" int32_t hoic_sync_rewards(hoic_sim* s, void* stream) {

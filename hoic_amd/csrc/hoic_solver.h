@@ -464,8 +464,17 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     jtf = dev_jt_force(m, w, rk, ev);
     const float g = vd ? (Ma - fs - jtf) : 0.f;
     const float g2 = wave_sum(tid < 32 ? g * g : 0.f);
-    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; break; }
+    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; PTC(11); break; }
     PT(20);
+#ifdef HOIC_PHASE_TIMING
+    {   // how often is the Newton Hessian M itself (no curvature on any row)?
+      float cz = ev.curv_f + ev.curv_l;
+#pragma unroll
+      for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; if (r < nrow) cz += w.cr_curv[r]; }
+      if (!(wave_max(cz) > 0.f)) PTC(19);
+      PTC(17);
+    }
+#endif
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
     const float sd = dev_hsolve<true>(m, w, M, ev.curv_f + ev.curv_l, m.nv, -g);
     if (tid < NV) w.sc.vec.x[tid] = vd ? sd : 0.f;      // (a_smooth is in registers by now; T is dead between two solves)
@@ -504,14 +513,14 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     for (int k = 0; k < NCSLOT; k++) ev.jar_c[k] = fmaf(alpha, jv.jar_c[k], ev.jar_c[k]);
     const float crow = dev_rows_cost(m, w, dk, rk, D_c, ev);
     const float st = wave_max((tid < m.nv) ? fabsf(dq) / (1.f + fabsf(qacc)) : 0.f);
-    if (st < 1e-7f) { it++; capped = false; break; }
+    if (st < 1e-7f) { it++; capped = false; PTC(12); break; }
     // MuJoCo's second criterion (engine_solver.c: improvement = scale * (oldcost - cost) < tolerance): once a Newton
     // step no longer lowers the cost, what is left of the gradient is float32 rounding and another Hessian solve
     // would only polish noise
     const float cost = crow + wave_sum((tid < m.nv) ? 0.5f * (Ma - fs) * (qacc - a0) : 0.f);
     const float improvement = scale * (cost_prev - cost);
     cost_prev = cost;
-    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; capped = false; break; }
+    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; capped = false; PTC(14); break; }
   }
   // forces at the final acceleration (the row state already belongs to it)
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);

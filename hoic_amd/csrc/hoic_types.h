@@ -269,10 +269,15 @@ struct PostWork {
   float S[NV][6];
   float gxmat[NG][9];
   float rec_sum[NHG][12]; int rec_cnt[NHG];
+#ifdef HOIC_PHASE_TIMING
+  long long pt[24], pt_last;
+#endif
 };
 
 #ifdef HOIC_PHASE_TIMING
 #define PT(i) do { long long t_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) { w.pt[i] += t_ - w.pt_last; w.pt_last = t_; } } while (0)
+#define PTC(i) do { if (threadIdx.x == 0) w.pt[i] += 1; } while (0)      // event counters in the slots the substep kernel has no phase for
 #else
 #define PT(i) do {} while (0)
+#define PTC(i) do {} while (0)
 #endif

@@ -38,14 +38,14 @@ class RewardParams(C.Structure):
     _fields_ = [("wk", C.c_float * 16), ("end_reward", C.c_float), ("use_end_reward", C.c_int32)]
 
 
-EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error",
+EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error", "hoic_build_id",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame", "hoic_get_diagnostics", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps",
            "hoic_mlp_gemm", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed", "hoic_mlp_set_pipeline", "hoic_mlp_gemm_tn",
            "hoic_mlp_colsum_packed", "hoic_mlp_amax_colsum", "hoic_mlp_colpart_finish", "hoic_mlp_update_exps_rel", "hoic_mlp_pack_tiled", "hoic_mlp_forward_tiled",
-           "hoic_set_async_reward", "hoic_sync_rewards", "hoic_mlp_head", "hoic_mlp_head_backward", "hoic_mlp_ppo_loss",
+           "hoic_set_async_reward", "hoic_sync_rewards", "hoic_set_cu_reserve", "hoic_mlp_head", "hoic_mlp_head_backward", "hoic_mlp_ppo_loss",
            "hoic_mlp_value_loss"]
 
 
@@ -77,6 +77,7 @@ def load():
     L.hoic_destroy.argtypes = [vp]
     L.hoic_destroy.restype = None
     L.hoic_last_error.restype = C.c_char_p
+    L.hoic_build_id.restype = C.c_char_p
     for n in ("hoic_num_envs", "hoic_obs_dim", "hoic_action_dim"):
         getattr(L, n).argtypes = [vp]
         getattr(L, n).restype = i32
@@ -107,11 +108,16 @@ def load():
     L.hoic_get_diagnostics.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(i32), i32]
     L.hoic_last_poststep_ms.restype = f32
     for n in EXPORTS:
-        if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_last_step_ms", "hoic_last_poststep_ms",
+        if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_build_id", "hoic_last_step_ms", "hoic_last_poststep_ms",
                      "hoic_zfilter_scratch_doubles"):
             getattr(L, n).restype = i32
     _lib = L
     return L
+
+
+def build_id() -> str:
+    """hoic_build_id(): which sources the loaded library was built from (profiles/ files carry it)"""
+    return load().hoic_build_id().decode()
 
 
 def _chk(rc, what):
@@ -293,6 +299,13 @@ class BatchedSim:
         self.L.hoic_set_async_reward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         _chk(self.L.hoic_set_async_reward(self.h, int(bool(on)), self._stream()), "hoic_set_async_reward")
         self._async_keep = [] if on else None       # buffers of the outstanding steps stay referenced until the synchronisation
+
+    def set_cu_reserve(self, n_cus):
+        """hoic_set_cu_reserve: keep ``n_cus`` compute units (a multiple of 8) free of substep workgroups in the split form, so
+        that the other ranges' policy chains and the reward parts always find room; 0 = off.  A scheduling knob: no result
+        depends on it."""
+        self.L.hoic_set_cu_reserve.argtypes = [C.c_void_p, C.c_int32]
+        _chk(self.L.hoic_set_cu_reserve(self.h, int(n_cus)), "hoic_set_cu_reserve")
 
     def sync_rewards(self):
         """the current stream waits for every outstanding reward part"""

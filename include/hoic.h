@@ -64,6 +64,9 @@ int32_t hoic_num_envs(const hoic_sim* s);
 int32_t hoic_obs_dim(const hoic_sim* s);     /* observation_space.shape[0] = 617 */
 int32_t hoic_action_dim(const hoic_sim* s);  /* action_space.shape[0] = 32 */
 const char* hoic_last_error(void);
+/* first 16 hex digits of the SHA-256 over the sources this library was built from (csrc/Makefile BUILD_ID; no reference
+ * analogue): measurement files under profiles/ carry it, bench.py quotes a counter pass only for the library it was taken on */
+const char* hoic_build_id(void);
 
 int32_t hoic_set_config(hoic_sim* s, const hoic_env_config* cfg);
 int32_t hoic_set_reward_params(hoic_sim* s, const hoic_reward_params* rp);
@@ -179,6 +182,14 @@ int32_t hoic_probe_qp(hoic_sim* s, int32_t n, const float* d_cols, const int32_t
  * (ho_im4.py:611-662); the sampler only needs obs to continue (agent_handmimic.py:463-482). */
 int32_t hoic_set_async_reward(hoic_sim* s, int32_t enable, void* stream);
 int32_t hoic_sync_rewards(hoic_sim* s, void* stream);
+/* Scheduling knob of the split form (no reference analogue; results never depend on it): keep `n_cus` compute units (a
+ * multiple of 8: the same number on each of the 8 XCDs; 0 = off) free of substep workgroups.  The substep kernel of a range
+ * then runs on a CU-masked stream of the library (hipExtStreamCreateWithCUMask) behind an event of the caller's stream, and
+ * the caller's stream continues behind the kernel's end.  With three 168-register substep wavefronts on every SIMD nothing
+ * else becomes resident on a CU, so the kernels of the OTHER ranges' policy chains (filter, tiled forward, action head) and
+ * the reward parts otherwise wait for substep wavefronts to retire; on the reserved CUs they always find room.  Takes effect
+ * for ranges stepped after the call. */
+int32_t hoic_set_cu_reserve(hoic_sim* s, int32_t n_cus);
 int32_t hoic_get_diagnostics(hoic_sim* s, int64_t* contact_overflow_total, int64_t* solver_cap_hits,
                              int32_t* envs_with_overflow, int32_t reset);
 

@@ -99,7 +99,54 @@ def test_two_rank_f16x3_update_equals_the_single_rank_update():
         d12 = sum(float(((two_rank[k].double() - sd1[k].cpu().double()) ** 2).sum()) for k in sd64)
         print(f"{name}: |2-rank f16x3 - f64| / |p| = {(e2 / nrm) ** 0.5:.3e}  |1-rank f32 - f64| / |p| = {(e32 / nrm) ** 0.5:.3e}  "
               f"|2-rank - 1-rank f16x3| / |p| = {(d12 / nrm) ** 0.5:.3e}")
-        assert e2 ** 0.5 <= 4 * e32 ** 0.5 + 1e-7 * nrm ** 0.5          # as close to the float64 update as the float32 library update is
+        assert e2 ** 0.5 <= 1.5 * e32 ** 0.5 + 1e-7 * nrm ** 0.5          # as close to the float64 update as the float32 library update is
     for i in range(2):          # the ranks' losses are means over their (equally sized) halves
         glob = 0.5 * (la[i] + lb[i])
         assert abs(glob - one.last_losses[i]) < 1e-4 * abs(one.last_losses[i]) + 1e-7, (la, lb, one.last_losses)
+
+
+def _loop_worker(rank, world, port, q, update_dtype):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from hoic_amd import mjcf, motions
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config
+    cfg = Config("box_future5_light_add_geom")
+    cfg.min_batch_size = 2048
+    model = mjcf.load_packaged("box")
+    expert = motions.synthetic_expert(model, 5, 300)
+    agent = AgentHandMimic(cfg, device=torch.device("cuda", 0), n_envs=256, model="box", expert_seqs=expert, distributed=True, n_groups=2,
+                           update_dtype=update_dtype)
+    for it in range(3):
+        info = agent.optimize_policy(it, save_model=False)
+    torch.cuda.synchronize()
+    p = torch.cat([x.detach().flatten() for x in agent.policy_net.parameters()]).double().cpu()
+    v = torch.cat([x.detach().flatten() for x in agent.value_net.parameters()]).double().cpu()
+    z = agent.running_state
+    q.put((rank, float(p.sum()), float(p.abs().sum()), float(v.sum()), float(v.abs().sum()), float(z.n), float(z.mean.sum()), float(z.S.sum()),
+           float(info["log"].avg_c_reward), int(info["log"].num_steps)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("update_dtype", ["f32", "f16x3"])
+def test_two_rank_whole_loop_keeps_the_ranks_identical(update_dtype):
+    """The whole multi-rank loop -- env sharding, two pipelined env ranges per rank with the split post-step, the LDS-free rollout
+    forward (f16x3), asynchronous gradient all-reduces interleaved with the other network's pass, the advantage statistics and
+    the observation-filter merge -- as two processes on ONE GPU (gloo between them: RCCL refuses two ranks on one device).  After
+    three PPO iterations both ranks hold bit-identical policy and value parameters and the same filter; the logger counts the
+    samples of both ranks.  (was tools/dist_smoke.py.)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, update_dtype)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in ps:
+        p.join(60)
+    a, b = res
+    assert a[1:8] == b[1:8], ("ranks disagree on parameters / filter", a, b)
+    assert a[9] == b[9] == 2 * 256 * 8            # both ranks' 256 envs x ceil(2048 / 256) steps
+    assert 0.0 < a[8] <= 1.0 and a[8] == b[8]

@@ -410,12 +410,14 @@ def test_rltest_streaming_loop(box_blob, box_model, setup):
     print("streaming control step: %.2f ms" % (per_step * 1e3))
 
 
-def test_episode_reward_parity(box_blob, oracle_lib, setup):
+@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
+def test_episode_reward_parity(obj, oracle_lib):
     """North-star parity statement: the same (seeded, randomly initialised) deterministic policy driven through the
     float64 oracle and through the HIP simulator gives the same episode length and the same episode reward within
-    float32 tolerance, over whole episodes of several hundred env steps (6000+ substeps with contacts)."""
+    float32 tolerance, over whole episodes of several hundred env steps (6000+ substeps with contacts) -- for the Box and for
+    the two convex-mesh objects (BASELINE.json configs 2-4)."""
     from hoic_amd.rl import PolicyGaussian
-    cfg, ex, thresh = setup
+    box_blob, cfg, ex, thresh = _obj_setup(obj)
     N = 4
     sim = _sim(box_blob, N, cfg, ex, thresh)
     torch.manual_seed(3)
@@ -1127,26 +1129,30 @@ def test_train_script_runs_two_iterations(tmp_path):
 def test_reward_curve_band_after_ten_iterations(box_model):
     """North-star clause "reward-curve parity to the CPU reference at equal step count", as far as it can be asserted in a
     test: 10 PPO iterations from the config's initial weights, deterministic reward per step of all 17 sequences.
-    profiles/r02_reward_curve.json and profiles/r03_reward_curve_filter_*.json (tools/reward_curve.py, 5 seeds x 100 iterations
-    per arm on this hardware) hold the bands.  At iteration 10 the reference-shaped CPU sampler (float64 oracle, whole
-    episodes, 64 sampler threads) gives 0.7502 +- 0.0014; the HIP simulator under the same sampler AND the same handling of
-    the observation filter (statistics shipped once per iteration: filter_mode='frozen') gives 0.7510 +- 0.0007 and stays
-    within 0.001 of the CPU curve to iteration 75 -- the round-2 offset of the default (online) filter, 0.004-0.005 from
-    iteration 30 on, is the filter's handling, not the simulator.
+    profiles/r02_reward_curve.json, profiles/r03_reward_curve_filter_*.json and profiles/r04_reward_curve_*.json
+    (tools/reward_curve.py, 3-5 seeds per arm on this hardware) hold the bands.  At iteration 10 the reference-shaped CPU
+    sampler (float64 oracle, whole episodes, 64 sampler threads) gives 0.7502 +- 0.0014; the HIP simulator under the same
+    sampler AND the same handling of the observation filter (statistics shipped once per iteration: filter_mode='frozen')
+    gives 0.7510 +- 0.0007 and stays within 0.001 of the CPU curve to iteration 75.
       * whole-episode sampler, CPU-arm filter handling: within 0.004 of the CPU value (mean of two seeds: 2 sigma of both arms);
       * whole-episode sampler, online filter (the product default): the same at iteration 10 (the curves part later);
-      * the default fixed-horizon sampler is a different estimator (13-step windows, value bootstrap): it trails over
-        the first ~60 iterations (0.725 +- 0.002 here) and leads after ~75; its known offset is bounded here."""
+      * the HEADLINE configuration -- fixed-horizon sampler, f16x3 update, two pipelined env ranges (what bench.py times) -- is a
+        different estimator (13-step windows, value bootstrap): 0.7255 +- 0.0036 at iteration 10 on the round-4 code
+        (r04_reward_curve_attribution.json, 3 seeds; round 2: 0.7247 +- 0.0015, 5 seeds).  Asserted: the mean of two seeds within
+        2 sigma of that band and the two seeds within 0.02 of each other -- round 3's unordered filter forks (a side stream could read
+        a fork's state before the main stream had written it) showed as 0.705 / 0.757 / 0.762 between seeds whenever other work
+        shared the GPU, and a -0.04 ... +0.005 window passed it."""
     from hoic_amd.agent import AgentHandMimic
     from hoic_amd.config import Config
     ex = motions.synthetic_expert(box_model, 17, 600)
-    res = {}
-    for name, mode, n_envs, fm in (("episodes_frozen", "episodes", 64, "frozen"), ("episodes", "episodes", 64, "online"), ("fixed", "fixed", 4096, "online")):
+    res, per_seed = {}, {}
+    for name, mode, n_envs, fm, ud in (("episodes_frozen", "episodes", 64, "frozen", "f32"), ("episodes", "episodes", 64, "online", "f32"),
+                                       ("fixed_f16x3", "fixed", 4096, "online", "f16x3")):
         vals = []
         for seed in (1, 2):
             cfg = Config("box_future5_light_add_geom"); cfg.seed = seed
             torch.manual_seed(seed)
-            agent = AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode, filter_mode=fm)
+            agent = AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode, filter_mode=fm, update_dtype=ud)
             for it in range(10):
                 agent.optimize_policy(it, save_model=False)
             cfg.update_adaptive_params(9)
@@ -1154,8 +1160,9 @@ def test_reward_curve_band_after_ten_iterations(box_model):
             vals.append(ev["reward_per_step"])
             assert ev["mean_percent"] > 0.9
             agent.env.close(); agent._eval_env.close()
-        res[name] = float(np.mean(vals))
-    print("deterministic reward per step after 10 iterations:", res)
+        res[name] = float(np.mean(vals)); per_seed[name] = vals
+    print("deterministic reward per step after 10 iterations:", res, per_seed)
     assert abs(res["episodes_frozen"] - 0.7502) < 0.004, res
     assert abs(res["episodes"] - 0.7502) < 0.005, res
-    assert -0.04 < res["fixed"] - res["episodes"] < 0.005, res
+    assert abs(res["fixed_f16x3"] - 0.7255) < 0.008, res
+    assert abs(per_seed["fixed_f16x3"][0] - per_seed["fixed_f16x3"][1]) < 0.02, per_seed

@@ -1,6 +1,7 @@
 """Host-side logic (CPU): config, motions, RL building blocks against the reference-generated goldens, the
 model blob round trip, and that the C-ABI library exports every symbol include/hoic.h declares."""
 import ctypes
+import sys
 import os
 import re
 import types
@@ -375,3 +376,15 @@ def test_filter_forks_merge_to_the_shared_filter():
     assert float(shared.n) == float(one.n) == 64 + 240
     torch.testing.assert_close(shared.mean, one.mean, rtol=1e-13, atol=1e-13)
     torch.testing.assert_close(shared.S, one.S, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_gpus_flag_refuses_instead_of_running_one_rank():
+    """`bench.py --gpus N` without a launcher starts the N ranks itself -- and with fewer than N visible GPUs it must exit
+    non-zero WITHOUT a JSON line (round 3 parsed the flag and ignored it: `--gpus 8` printed an n_gpus = 1 line).  This container
+    has no GPU, so any N > 1 must be refused; the parent never touches the GPU."""
+    import subprocess
+    env = dict(os.environ); env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert p.returncode == 3, (p.returncode, p.stderr.decode()[-400:])
+        assert b"{" not in p.stdout and b"only" in p.stderr

@@ -279,7 +279,7 @@ def test_ppo_update_f16x3_is_as_accurate_as_float32():
             e32 += float(((sd32[k].double() - sd64[k]) ** 2).sum()); ea += float(((sda[k].double() - sd64[k]) ** 2).sum())
             nrm += float((sd64[k] ** 2).sum())
         print(f"{net}: |f32 - f64| / |p| = {(e32 / nrm) ** 0.5:.3e}   |f16x3 - f64| / |p| = {(ea / nrm) ** 0.5:.3e}")
-        assert ea ** 0.5 <= 4 * e32 ** 0.5 + 1e-7 * nrm ** 0.5
+        assert ea ** 0.5 <= 1.5 * e32 ** 0.5 + 1e-7 * nrm ** 0.5       # measured 1.2e-7 against 1.6e-7 (f16x3 is the closer one)
     for i in range(2):
         assert abs(ref64.last_losses[i] - a.last_losses[i]) < 1e-5 * abs(ref64.last_losses[i]) + 1e-7
 

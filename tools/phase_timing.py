@@ -32,8 +32,14 @@ for t in range(8):
     sim.L.hoicdbg_phase_cycles(C.c_void_p(sim.h), buf, C.byref(ov))
     if t >= 2: tot += np.array(buf[:])
 tot /= 6
+cnt_slots = (11, 12, 14, 17, 19)
+counters = tot.copy()
+for i in cnt_slots: tot[i] = 0
 print('kernel ms', np.round(ms, 2), 'iters mean', float(out[3][:, 3].float().mean()), 'overflow', ov.value)
 s = tot.sum()
 for n, v in zip(names, tot):
     print(f'{n:16s} {v:12.0f} cycles  {100 * v / s:5.1f}%')
 print('total cycles per env-step', s, ' (@2.4GHz = %.3f ms)' % (s / 2.4e6))
+# event counters of the Newton loop (per env-step = 15 substeps), kept in the phase slots the substep kernel does not use
+c = {k: counters[i] for k, i in (('stop: gradient', 11), ('stop: step', 12), ('stop: improvement', 14), ('Hessian solves', 17), ('Hessian == M', 19))}
+print('Newton events per env-step:', {k: round(float(v), 2) for k, v in c.items()})

@@ -54,10 +54,11 @@ def main():
     a = sub.add_parser("counters")
     a.add_argument("--dir", required=True, nargs="+"); a.add_argument("--kernel", required=True); a.add_argument("--envs", type=int, required=True)
     a.add_argument("--skip", type=int, default=2); a.add_argument("--out", required=True); a.add_argument("--command", default=""); a.add_argument("--obj", default="box")
+    a.add_argument("--build-id", default=None, help="hoic_build_id() of the library the pass ran on (python3 -c 'from hoic_amd import lib; print(lib.build_id())')")
     b = sub.add_parser("traffic")
     b.add_argument("--fetch-dir", required=True); b.add_argument("--write-dir", required=True); b.add_argument("--kernel", required=True)
     b.add_argument("--envs", type=int, required=True); b.add_argument("--obj", default="box"); b.add_argument("--skip", type=int, default=2)
-    b.add_argument("--out", required=True); b.add_argument("--command", default="")
+    b.add_argument("--out", required=True); b.add_argument("--command", default=""); b.add_argument("--build-id", default=None)
     c = sub.add_parser("stats")
     c.add_argument("--dir", required=True); c.add_argument("--out", required=True)
     args = ap.parse_args()
@@ -85,6 +86,7 @@ def main():
         shutil.copy(sorted(files)[-1], args.out)
         print("copied", sorted(files)[-1], "->", args.out)
         return
+    out["build_id"] = args.build_id
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out)[:600])
