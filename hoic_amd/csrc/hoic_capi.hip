@@ -38,7 +38,7 @@ __device__ __forceinline__ void load_state(const DevModel& m, const DevState& st
     w.qacc[tid] = as_global(st.warm)[(size_t)env * NV + tid];       // the warm start of the first solve
     w.applied[tid] = 0.f;
   }
-  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.fail = 0; w.capped = 0; }
+  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.cbod = 0u; w.capped = 0; }
   wsync();
 }
 // lag_too: the state is also the state before the last integration (after a reset)
@@ -134,7 +134,8 @@ __device__ __forceinline__ void dev_poststep(const DevModel& m, const DevConfig&
   if constexpr (PART != POST_A) {
     if (ok) {
       dev_classify_contact(m, w);                                                                // :562
-      if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8));   // :631
+      if (cfg.c.residual_force) rfc_score = dev_solve_rfc(m, cfg, w, vf, vt, (double*)(as_global(st.qp_lam) + (size_t)env * 8),
+                                                          as_global(st.qpcol) + (size_t)env * QP_COL_FLOATS);   // :631
       if (!isfinite(rfc_score)) { if (PART == POST_ALL) ok = false; rfc_score = 0.f; }
     }
     asm volatile("" ::: "memory");   // keep the expert-frame loads of the reward / observation below the QP (register peak)
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // ---- kernel 2 of a step: contact averaging, the residual-force QP (float64), termination, reward, the optional
 // in-launch reset and the 617-float observation (HandObjMimic4.step after do_simulation, ho_im4.py:631-662)
 template <int PART>      // POST_ALL: everything after the substeps; POST_B: the reward part of the split form (record-only inputs)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                            DevExpert ex, DevState st, const float* __restrict__ action,
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
@@ -549,7 +550,7 @@ __global__ void hoic_clamp_episode_kernel(DevExpert ex, DevState st, int n) {
 struct ProbeArgs {
   const float *qpos, *qvel, *ctrl, *applied, *warm;
   int do_step;
-  float *xpos, *xquat, *gxpos, *gxmat, *qM, *bias, *contacts, *asmooth, *qacc, *qpos_out, *qvel_out;
+  float *xpos, *xquat, *gxpos, *gxmat, *qM, *bias, *contacts, *asmooth, *qacc, *qpos_out, *qvel_out, *cforce;
   int *ncon, *iters;
 };
 __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp, ProbeArgs a) {
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
     w.applied[tid] = f;                                                              // applied + actuator forces, as dev_applied leaves them
     w.qacc[tid] = (a.warm && tid < m.nv) ? a.warm[(size_t)env * m.nv + tid] : 0.f;      // warm start
   }
-  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.capped = 0; }
+  if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.cbod = 0u; w.capped = 0; }
   wsync();
   dev_load_constants(m, w);
   MReg M;
@@ -600,6 +601,18 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
         for (int i = 0; i < 9; i++) r[4 + i] = w.c_frame[c][i];
         r[13] = (float)m.pair_geom1[p]; r[14] = (float)m.pair_geom2[p]; r[15] = (float)m.pair_condim[p];
       } else for (int i = 0; i < 16; i++) r[i] = 0.f;
+    }
+  }
+  if (a.cforce) {     // mj_contactForce: decode the pyramid's edge forces (the solver's row forces are intact: nothing ran since)
+    for (int c = tid; c < HOIC_PROBE_MAXCON; c += NT) {
+      float* r = a.cforce + ((size_t)env * HOIC_PROBE_MAXCON + c) * 6;
+      float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (ok && c < w.ncon) {
+        const int nr = w.c_nrow[c], r0 = w.c_row0[c];
+        for (int e = 0; e < nr; e++) f[0] += w.cr_force[r0 + e];
+        for (int k = 0; 2 * k + 1 < nr; k++) f[1 + k] = w.c_mu[c][k] * (w.cr_force[r0 + 2 * k] - w.cr_force[r0 + 2 * k + 1]);
+      }
+      for (int i = 0; i < 6; i++) r[i] = f[i];
     }
   }
   if (a.do_step && ok) dev_euler(m, w, M, (GPTR(float))nullptr, (GPTR(float))nullptr);
@@ -972,7 +985,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
        hipMalloc(&s->st.start, n * 4) == hipSuccess && hipMalloc(&s->st.seq, n * 4) == hipSuccess &&
        hipMalloc(&s->st.rfc_score, n * 4) == hipSuccess && hipMalloc(&s->st.diag, n * 8) == hipSuccess &&
        hipMalloc(&s->st.phase, n * 24 * 8) == hipSuccess && hipMalloc(&s->st.post, 2 * n * PB_SIZE * 4) == hipSuccess &&
-       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess &&
+       hipMalloc(&s->st.oldg, n * OG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.qp_lam, n * 8 * 8) == hipSuccess && hipMalloc(&s->st.qpcol, n * (size_t)QP_COL_FLOATS * 4) == hipSuccess &&
        hipMalloc(&s->st.cost, 2 * n * 4) == hipSuccess && hipMalloc(&s->st.order, 2 * n * 4) == hipSuccess &&
        hipMalloc(&s->st.lagrec, n * LG_SIZE * 4) == hipSuccess && hipMalloc(&s->st.lag_valid, n * 4) == hipSuccess;
   if (!ok) { set_err("hoic_create: hipMalloc failed"); hoic_destroy(s); return nullptr; }
@@ -1005,7 +1018,7 @@ extern "C" void hoic_destroy(hoic_sim* s) {
   hipSetDevice(s->device);
   for (void* p : s->ex_allocs) hipFree(p);
   void* ptrs[] = {s->d_model, s->d_cfg, s->st.qpos, s->st.qlag, s->st.qvel, s->st.vlag, s->st.warm, s->st.cur_t,
-                  s->st.start, s->st.seq, s->st.rfc_score, s->st.diag, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
+                  s->st.start, s->st.seq, s->st.rfc_score, s->st.diag, s->st.phase, s->st.post, s->st.oldg, s->st.qp_lam, s->st.qpcol, s->st.cost, s->st.order, s->st.lagrec, s->st.lag_valid, s->d_iota_seq, s->d_iota_start, s->d_ex, s->d_st};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < hoic_sim::NEV; i++) for (int k = 0; k < 3; k++) if (s->ev[i][k]) hipEventDestroy(s->ev[i][k]);
   for (auto& r : s->ranges) {
@@ -1298,10 +1311,10 @@ extern "C" int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpo
                                       const float* d_applied, const float* d_warm, int32_t do_step, float* d_xpos,
                                       float* d_xquat, float* d_geom_xpos, float* d_geom_xmat, float* d_qM, float* d_bias,
                                       int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
-                                      float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream) {
+                                      float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, float* d_contact_force, void* stream) {
   if (!s || n <= 0 || !d_qpos || !d_qvel) { set_err("hoic_probe_forward: bad arguments"); return HOIC_ERR_ARG; }
   ProbeArgs a{d_qpos, d_qvel, d_ctrl, d_applied, d_warm, do_step, d_xpos, d_xquat, d_geom_xpos, d_geom_xmat, d_qM, d_bias,
-              d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_ncon, d_solver_iter};
+              d_contacts, d_qacc_smooth, d_qacc, d_qpos_out, d_qvel_out, d_contact_force, d_ncon, d_solver_iter};
   HIPCHK(hipSetDevice(s->device));
   hipLaunchKernelGGL(hoic_probe_kernel, dim3(n), dim3(NT), 0, (hipStream_t)stream, s->d_model, s->d_cfg, a);
   HIPCHK(hipGetLastError());
@@ -1313,8 +1326,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                                                                 const double* __restrict__ rhs, int max_col,
                                                                                                 double* __restrict__ lam_out, int* __restrict__ stat_out) {
   __shared__ PostWork w;
+  __shared__ float qcols[QP_COL_FLOATS];
   const int k = blockIdx.x, tid = threadIdx.x, ncol = ncols[k];
-  float* qc = w.qp_col;
+  float* qc = qcols;
   const float* src = cols + (size_t)k * max_col * 7;
   for (int c = tid; c < ncol; c += NT)
     for (int i = 0; i < 7; i++) qc[i * QP_MAXCOL + c] = src[(size_t)c * 7 + i];
@@ -1322,7 +1336,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double b[6], lam[6];
   for (int i = 0; i < 6; i++) b[i] = rhs[(size_t)k * 6 + i];
   int stat[2];
-  dev_nnqp(w, qc, ncol, b, lam, stat);
+  dev_nnqp(w, (const float*)qc, ncol, b, lam, stat);
   if (tid < 6) lam_out[(size_t)k * 6 + tid] = lam[tid];
   if (tid < 2) stat_out[(size_t)k * 2 + tid] = stat[tid];
 }

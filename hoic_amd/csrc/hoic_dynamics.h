@@ -27,23 +27,28 @@ __device__ __forceinline__ void dev_load_constants(const DevModel& m, Work& w) {
 // sum_{d on the packed path} S[d] * x[d]  (+ optional extra[d]) as straight-line code: all LDS reads are issued
 // before the first FMA needs them (one latency instead of one per dof); `below` keeps only dofs < below
 template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[3], const float* x, const float (*extra)[6],
-                                          int below, float* V, float* A) {
+                                          int below, float* V, float* A, bool second = true) {
   // (the packed path is loop-invariant over the substeps: hidden from the optimiser, or the 12 unpacked indices and
   // their scaled copies are hoisted out of the substep loop and spilled)
+  // second (wave-uniform): also entries 6..11 -- a caller that knows no lane's path is longer than six dofs (the free object,
+  // the palm) skips that batch
   const unsigned pk[3] = {path[0], path[1], path[2]};
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
-    if (i == 6) __builtin_amdgcn_sched_barrier(0);   // two batches of six gathers in flight, not twelve (register peak)
-    const unsigned e = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-    const bool on = e < (unsigned)below;
-    const int d = on ? (int)e : 0;
-    const float msk = on ? 1.f : 0.f;
-    const float xd = x[d] * msk;               // unconditional loads (index 0 when off): no exec-masked branches
+  for (int h = 0; h < 2; h++) {
+    if (h == 1) { __builtin_amdgcn_sched_barrier(0); if (!second) break; }   // two batches of six gathers in flight, not twelve (register peak)
 #pragma unroll
-    for (int k = 0; k < 6; k++) V[k] = fmaf(w.S[d][k], xd, V[k]);
-    if (EXTRA) {
+    for (int i = 6 * h; i < 6 * h + 6; i++) {
+      const unsigned e = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      const bool on = e < (unsigned)below;
+      const int d = on ? (int)e : 0;
+      const float msk = on ? 1.f : 0.f;
+      const float xd = x[d] * msk;               // unconditional loads (index 0 when off): no exec-masked branches
 #pragma unroll
-      for (int k = 0; k < 6; k++) A[k] = fmaf(extra[d][k], msk, A[k]);
+      for (int k = 0; k < 6; k++) V[k] = fmaf(w.S[d][k], xd, V[k]);
+      if (EXTRA) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) A[k] = fmaf(extra[d][k], msk, A[k]);
+      }
     }
   }
 }

@@ -234,7 +234,7 @@ HD void chol6_solve(double* H, double* x) {  // H: 21 lower-packed row-major (ov
 // ---- the residual-force QP proper: columns a_k (6) and offsets c_k (k < ncol) in LDS at qc[i * QP_MAXCOL + k],
 // right-hand side b; returns the dual optimum lambda = 2 (A x - b).  stat (optional, lane-uniform): column entries,
 // small solves are not counted; [0] = active-set iterations, [1] = dual-Newton iterations of the fallback.
-__device__ __forceinline__ void dev_nnqp(PostWork& w, const float* qc, int ncol, const double (&b)[6], double (&lam)[6], int* stat) {
+template <class QC> __device__ __forceinline__ void dev_nnqp(PostWork& w, QC qc, int ncol, const double (&b)[6], double (&lam)[6], int* stat) {
   const int tid = threadIdx.x;
   const double eps = 1e-7;
   const int nslot = (ncol + NT - 1) / NT;         // columns per lane actually present (typically 1-2 of at most 6)
@@ -449,7 +449,10 @@ __device__ __forceinline__ void dev_nnqp(PostWork& w, const float* qc, int ncol,
   if (stat) stat[1] = n_dual;
 }
 
-__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, PostWork& w, const float* vf, const float* vt, double* warm_lam) {
+// qc: the env's QP_COL_FLOATS floats of DevState::qpcol (global memory, L2-resident while in use: the columns exist for the 8 % of
+// the envs that have a hand-object contact, and keeping 10.6 KB of LDS for them in every workgroup cost the post-step kernel its
+// place beside the substep workgroups)
+__device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, PostWork& w, const float* vf, const float* vt, double* warm_lam, GPTR(float) qc) {
   const int tid = threadIdx.x;
   const double w_t = 1e4, swt = 100.0, mu = 0.75, dx = 0.0025;
   if (!cfg.c.explain_force)
@@ -488,7 +491,6 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, PostWork
   // columns a_i (6) and offsets c_i live in LDS as float32 (their inputs are float32 quantities; all arithmetic on
   // them is float64): the QP then needs ~130 registers instead of ~460, and its loops run over the columns that
   // exist instead of six unrolled slots per lane
-  float* qc = w.qp_col;
   const double obj_p[3] = {w.qpos[nq - 7], w.qpos[nq - 6], w.qpos[nq - 5]};
   const double obj_v[3] = {w.sc.post.gvel[lastg][0], w.sc.post.gvel[lastg][1], w.sc.post.gvel[lastg][2]};
   for (int jj = 0; jj < nslot; jj++) {
@@ -530,15 +532,16 @@ __device__ float dev_solve_rfc(const DevModel& m, const DevConfig& cfg, PostWork
     qc[5 * QP_MAXCOL + col] = (float)(swt * (cro[0] * xv[1] - cro[1] * xv[0]));
     qc[6 * QP_MAXCOL + col] = (float)(((vn * nn <= 0.0) ? nvn : 0.0) + (e == am ? 0.0 : nvt));
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the columns travel between lanes through global memory
   wsync();
   const double b[6] = {F[0], F[1], F[2], swt * tau[0], swt * tau[1], swt * tau[2]};
   double lam[6];
 #ifdef HOIC_TRACE_DISPATCH
   int qstat[2];
-  dev_nnqp(w, qc, ncol, b, lam, qstat);
+  dev_nnqp(w, (GPTR(const float))qc, ncol, b, lam, qstat);
   if (tid == 0) { g_trace_qp[blockIdx.x * 4] = qstat[0]; g_trace_qp[blockIdx.x * 4 + 1] = qstat[1]; g_trace_qp[blockIdx.x * 4 + 2] = ncol; g_trace_qp[blockIdx.x * 4 + 3] = qstat[1] > 0; }
 #else
-  dev_nnqp(w, qc, ncol, b, lam, nullptr);
+  dev_nnqp(w, (GPTR(const float))qc, ncol, b, lam, nullptr);
 #endif
   if (tid < 6) warm_lam[tid] = lam[tid];
   if (tid == 6) warm_lam[6] = 1.0;

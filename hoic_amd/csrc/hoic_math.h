@@ -127,6 +127,14 @@ HD float wave_max(float v) {
   return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
 }
 HD float wave_min(float v) { return -wave_max(-v); }
+HD unsigned wave_or(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);
+  return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16)) |
+         (unsigned)(__builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+}
 HD float sel3(float v0, float v1, float v2, int i) { return i == 0 ? v0 : (i == 1 ? v1 : v2); }
 HD void sel3v(const float (*A)[3], int i, float* o) { for (int k = 0; k < 3; k++) o[k] = sel3(A[0][k], A[1][k], A[2][k], i); }
 // float64 wave sum on the DPP crossbar (two 32-bit moves per step) instead of six ds_bpermute round trips

@@ -231,10 +231,14 @@ struct RowEval { float jar_f, force_f, curv_f, jar_l, force_l, curv_l, jar_c[NCS
 __device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const float* x) {
   const int tid = opaque(threadIdx.x);
   if (w.ncon == 0) return;
-  if (tid < m.nbody) {
+  // only the bodies that take part in a contact (typically the object on the table: ONE body with a path of six dofs; the
+  // gather over all 28 bodies' 12-dof paths was 15 % of the kernel), and the second half of the paths only when one of them
+  // is a finger body (dev_make_constraint leaves both facts in w.cbod)
+  const unsigned cb = w.cbod;
+  if (tid < m.nbody && ((cb >> tid) & 1u)) {
     float V[6] = {0, 0, 0, 0, 0, 0};
     const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
-    path_gather<false>(w, bp, x, nullptr, 0xFF, V, nullptr);
+    path_gather<false>(w, bp, x, nullptr, 0xFF, V, nullptr, (cb >> 31) != 0u);
 #pragma unroll
     for (int i = 0; i < 6; i++) w.bV[tid][i] = V[i];
   }
@@ -319,6 +323,14 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
       const int b1 = m.pair_b1[p], b2 = m.pair_b2[p];
       w.c_b1[c] = (unsigned char)b1; w.c_b2[c] = (unsigned char)b2;
       w.c_mpos[c] = m.pair_mpos[p]; w.c_mneg[c] = m.pair_mneg[p];
+    }
+    {   // which bodies the Jacobian products have to visit (dev_basis_dot)
+      unsigned bits = 0u;
+      if (c < w.ncon) { const int p = w.c_pair[c]; bits = (1u << m.pair_b1[p]) | (1u << m.pair_b2[p]); }
+      const unsigned cb = wave_or(bits) & 0x7FFFFFFFu;
+      const bool lng = tid < m.nbody && ((cb >> tid) & 1u) && ((w.k_bpath[tid][1] >> 16) & 0xFFu) != 0xFFu;
+      const unsigned cbl = cb | (__ballot(lng) != 0ull ? 0x80000000u : 0u);
+      if (tid == 0) w.cbod = cbl;
     }
     const int incl_sum = wave_incl_scan(nrow);
     const int row0 = incl_sum - nrow;
@@ -456,6 +468,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   float qacc = vd ? (usewarm ? wm : a0) : 0.f, Ma = vd ? (usewarm ? Mw : fs) : 0.f;   // M asmooth = fsmooth
   if (usewarm) ev = evw;
   else dev_rows_cost(m, w, dk, rk, D_c, ev);      // forces / curvatures back to the asmooth state
+  PT(23);
   int it = 0;
   bool capped = true;     // the loop ran out of iterations (no stop criterion met)
   bool fresh = false;     // jtf holds J'f of the current qacc
@@ -464,17 +477,8 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     jtf = dev_jt_force(m, w, rk, ev);
     const float g = vd ? (Ma - fs - jtf) : 0.f;
     const float g2 = wave_sum(tid < 32 ? g * g : 0.f);
-    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; PTC(11); break; }
-    PT(20);
-#ifdef HOIC_PHASE_TIMING
-    {   // how often is the Newton Hessian M itself (no curvature on any row)?
-      float cz = ev.curv_f + ev.curv_l;
-#pragma unroll
-      for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; if (r < nrow) cz += w.cr_curv[r]; }
-      if (!(wave_max(cz) > 0.f)) PTC(19);
-      PTC(17);
-    }
-#endif
+    PT(11);
+    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; break; }
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
     const float sd = dev_hsolve<true>(m, w, M, ev.curv_f + ev.curv_l, m.nv, -g);
     if (tid < NV) w.sc.vec.x[tid] = vd ? sd : 0.f;      // (a_smooth is in registers by now; T is dead between two solves)
@@ -484,8 +488,10 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     float gq = 0.f, hh = 0.f, g0 = 0.f;
     if (tid < m.nv) { gq = (Ma - fs) * sd; hh = sd * Ms; g0 = g * sd; }
     gq = wave_sum(gq); hh = wave_sum(hh); g0 = wave_sum(g0);
+    PT(12);
     RowEval jv;
     dev_rows_jar(m, w, rk, aref_c, w.sc.vec.x, false, jv);
+    PT(14);
     float a = 0.f, lo = 0.f, hi = -1.f, alpha = 0.f;
     for (int ls = 0; ls < 10; ls++) {
       float dphi = 0.f, ddphi = 0.f, f, cv;
@@ -506,6 +512,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
       if (hi >= 0.f && hi - lo < 1e-6f * (1.f + hi)) break;
       a = an;
     }
+    PT(17);
     const float dq = alpha * sd;
     qacc += vd ? dq : 0.f; Ma = fmaf(alpha, Ms, Ma);
     ev.jar_f = fmaf(alpha, jv.jar_f, ev.jar_f); ev.jar_l = fmaf(alpha, jv.jar_l, ev.jar_l);
@@ -513,14 +520,15 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     for (int k = 0; k < NCSLOT; k++) ev.jar_c[k] = fmaf(alpha, jv.jar_c[k], ev.jar_c[k]);
     const float crow = dev_rows_cost(m, w, dk, rk, D_c, ev);
     const float st = wave_max((tid < m.nv) ? fabsf(dq) / (1.f + fabsf(qacc)) : 0.f);
-    if (st < 1e-7f) { it++; capped = false; PTC(12); break; }
+    if (st < 1e-7f) { it++; capped = false; break; }
     // MuJoCo's second criterion (engine_solver.c: improvement = scale * (oldcost - cost) < tolerance): once a Newton
     // step no longer lowers the cost, what is left of the gradient is float32 rounding and another Hessian solve
     // would only polish noise
     const float cost = crow + wave_sum((tid < m.nv) ? 0.5f * (Ma - fs) * (qacc - a0) : 0.f);
     const float improvement = scale * (cost_prev - cost);
     cost_prev = cost;
-    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; capped = false; PTC(14); break; }
+    PT(19);
+    if (improvement < HOIC_IMPROVEMENT_TOL) { it++; capped = false; break; }
   }
   // forces at the final acceleration (the row state already belongs to it)
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);

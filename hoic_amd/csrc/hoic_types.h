@@ -155,6 +155,7 @@ struct DevState {
   float* oldg;   // [n, OG_SIZE]
   float* lagrec; // [n, LG_SIZE]
   int* lag_valid; // [n] 0: the record does not belong to (qlag, vlag) (after a reset / set_state / failed step)
+  float* qpcol;   // [n, QP_COL_FLOATS] columns of the residual-force QP (post-step kernel scratch)
   double* qp_lam; // [n, 8] multipliers of the last residual-force QP: lambda[6], valid flag, pad (diagnostic; the active-set solve starts cold)
   long long* phase;  // [n, 24] per-phase cycle counters (HOIC_PHASE_TIMING builds only)
   unsigned* cost;    // [2, n] shader-clock duration (>> 6) of the env's last substep / post-step pass
@@ -225,7 +226,8 @@ struct Work {
     struct { float col_lc[COLSLOT * 7 * NT]; float col_pool[COLPOOL][2 * 7]; float col_poly[32]; float gxmat[NG][9]; };
   };
   // contacts of the current forward pass
-  int ncon, nrow, solver_iter, fail, capped;
+  int ncon, nrow, solver_iter, capped;
+  unsigned cbod;                       // bodies that take part in a contact (bit b), bit 31: one of them has a path of more than six dofs
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
   unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
   unsigned k_bpath[NB][3];             // packed dof paths of the bodies (model constant, loaded once per launch)
@@ -241,9 +243,9 @@ static_assert(sizeof(Work) <= 12800, "Work must stay within 10 LDS granules of 1
 static_assert(offsetof(Work, gxmat) >= offsetof(Work, c_mu), "gxmat must not overlay the dynamics scratch (written while it is live)");
 static_assert(offsetof(Work, col_poly) + sizeof(((Work*)0)->col_poly) <= offsetof(Work, gxmat), "collision staging layout");
 
-// ---- workspace of the post-step kernel, the reset kernel and the QP probe (float64 QP, kinematics of a reset): the
-// residual-force QP keeps its columns in qp_col (up to 19 contacts x 5 points x 4 edges, 7 floats each, column c of component
-// k at qp_col[k * QP_MAXCOL + c])
+// ---- workspace of the post-step kernel, the reset kernel and the QP probe (float64 QP, kinematics of a reset): 8 KB.  The
+// residual-force QP's columns (up to 19 contacts x 5 points x 4 edges, 7 floats each, column c of component k at
+// [k * QP_MAXCOL + c]) live in global memory (DevState::qpcol), not here
 #define QP_MAXCOL (NHG * 5 * 4)
 #define QP_COL_FLOATS (7 * QP_MAXCOL)
 struct PostWork {
@@ -265,7 +267,6 @@ struct PostWork {
       float gvel[NG][3], gangvel[NG][3], obj_avg_acc[6];
     } post;
   } sc;
-  float qp_col[QP_COL_FLOATS];
   float S[NV][6];
   float gxmat[NG][9];
   float rec_sum[NHG][12]; int rec_cnt[NHG];

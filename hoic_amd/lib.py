@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhoic_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("HOIC_LIB", "libhoic_hip.so"))      # HOIC_LIB: development builds of the same library (A/B runs)
 OBS_DIM, ACT_DIM, NQ, NV, NU, NHB, NINFO = 617, 32, 33, 32, 26, 21, 9
 PROBE_MAXCON = 32
 
@@ -90,7 +90,7 @@ def load():
     L.hoic_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.hoic_set_state.argtypes = [vp, vp, vp, vp]
     L.hoic_get_rfc_score.argtypes = [vp, vp, vp]
-    L.hoic_probe_forward.argtypes = [vp, i32] + [vp] * 5 + [i32] + [vp] * 14       # 13 outputs + stream
+    L.hoic_probe_forward.argtypes = [vp, i32] + [vp] * 5 + [i32] + [vp] * 15       # 14 outputs + stream
     L.hoic_enable_timing.argtypes = [vp, i32]
     L.hoic_last_step_ms.argtypes = [vp]
     L.hoic_last_step_ms.restype = f32
@@ -366,12 +366,13 @@ class BatchedSim:
                  geom_xmat=t.zeros(n, ng, 9, **f), qM=t.zeros(n, NV, NV, **f), bias=t.zeros(n, NV, **f),
                  ncon=t.zeros(n, device=self.device, dtype=t.int32), contacts=t.zeros(n, PROBE_MAXCON, 16, **f),
                  qacc_smooth=t.zeros(n, NV, **f), qacc=t.zeros(n, NV, **f), qpos_out=t.zeros(n, NQ, **f),
-                 qvel_out=t.zeros(n, NV, **f), iters=t.zeros(n, device=self.device, dtype=t.int32))
+                 qvel_out=t.zeros(n, NV, **f), iters=t.zeros(n, device=self.device, dtype=t.int32),
+                 contact_force=t.zeros(n, PROBE_MAXCON, 6, **f))
         _chk(self.L.hoic_probe_forward(self.h, n, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(applied), _ptr(warm), int(do_step),
                                        _ptr(o["xpos"]), _ptr(o["xquat"]), _ptr(o["geom_xpos"]), _ptr(o["geom_xmat"]), _ptr(o["qM"]),
                                        _ptr(o["bias"]), _ptr(o["ncon"]), _ptr(o["contacts"]), _ptr(o["qacc_smooth"]),
                                        _ptr(o["qacc"]), _ptr(o["qpos_out"]), _ptr(o["qvel_out"]), _ptr(o["iters"]),
-                                       self._stream()), "hoic_probe_forward")
+                                       _ptr(o["contact_force"]), self._stream()), "hoic_probe_forward")
         t.cuda.synchronize(self.device)
         if kinematics_only:
             o = {k: o[k] for k in ("xpos", "xquat", "geom_xpos", "geom_xmat", "ncon", "contacts")}

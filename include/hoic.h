@@ -127,13 +127,16 @@ int32_t hoic_get_rfc_score(hoic_sim* s, float* d_score, void* stream);
  * (sim.forward()/sim.step() + data.qM, qfrc_bias, body_xpos, body_xquat, geom_xpos, contact[], qacc;
  * call sites ho_im4.py:383,398-401,545,810-829,884).  Used by the parity tests.  All device pointers, any
  * output may be NULL.  d_ctrl [n,26], d_applied [n,32], d_warm [n,32] may be NULL (zeros).
- * d_contacts [n,HOIC_PROBE_MAXCON,16] rows: dist,pos[3],frame[9],geom1,geom2,dim. */
+ * d_contacts [n,HOIC_PROBE_MAXCON,16] rows: dist,pos[3],frame[9],geom1,geom2,dim.
+ * d_contact_force [n,HOIC_PROBE_MAXCON,6]: mj_contactForce of every contact (ho_im4.py:866-881 get_contact, test mode): the
+ * contact-frame 6-vector decoded from the pyramid's edge forces of the constraint solve -- [0] normal force (sum of the edges),
+ * [1], [2] tangential forces mu_i (f_2i - f_2i+1), [3] the torsional moment of a condim-4 contact, [4], [5] zero. */
 #define HOIC_PROBE_MAXCON 32
 int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const float* d_qvel, const float* d_ctrl,
                            const float* d_applied, const float* d_warm, int32_t do_step, float* d_xpos,
                            float* d_xquat, float* d_geom_xpos, float* d_geom_xmat, float* d_qM, float* d_bias,
                            int32_t* d_ncon, float* d_contacts, float* d_qacc_smooth, float* d_qacc,
-                           float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, void* stream);
+                           float* d_qpos_out, float* d_qvel_out, int32_t* d_solver_iter, float* d_contact_force, void* stream);
 
 /* Generalized advantage estimation (khrylib core/common.py:12-19, called from agent_pg.py:46) over a time-major
  * rollout, no handle needed: d_rewards, d_masks (0 at episode ends), d_values [T, N] float32, d_next_values [N] (value

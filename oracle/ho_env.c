@@ -578,6 +578,19 @@ int hoo_get_contacts(const ho_env* e, double* out, int maxcon) {
   }
   return n;
 }
+/* mj_contactForce (mujoco_py functions.mj_contactForce, call site uhc/envs/ho_im4.py:875): the 6-vector of contact c in the
+   contact frame decoded from the pyramid's edge forces [MJ-doc: mju_decodePyramid]: force[0] = sum of the edge forces (normal),
+   force[1 + i] = mu_i (f_2i - f_2i+1) -- two tangential components, for condim 4 the torsional moment; frictionless: the one row */
+int hoo_contact_force(const ho_env* e, int c, double* out6) {
+  if (c < 0 || c >= e->d.ncon) return -1;
+  const ho_contact* k = &e->d.contact[c];
+  const double* f = e->d.efc_force + k->efc_address;
+  for (int i = 0; i < 6; i++) out6[i] = 0;
+  if (k->dim == 1) { out6[0] = f[0]; return 0; }
+  for (int i = 0; i < 2 * (k->dim - 1); i++) out6[0] += f[i];
+  for (int i = 0; i < k->dim - 1; i++) out6[1 + i] = k->friction[i] * (f[2 * i] - f[2 * i + 1]);
+  return 0;
+}
 void hoo_forward(ho_env* e) { ho_forward(&e->m, &e->d); }
 int hoo_solve_dual_pgs(ho_env* e, int max_sweeps, double tol, double* qacc_out, double* force_out) {
   return ho_solve_dual_pgs(&e->m, &e->d, max_sweeps, tol, qacc_out, force_out);

@@ -42,6 +42,7 @@ def lib():
         L.hoo_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.hoo_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.hoo_get_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hoo_contact_force.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hoo_env_set_cfg.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p]
         L.hoo_env_set_expert.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
         L.hoo_env_set_pd_ref_offset.argtypes = [C.c_void_p, C.c_int]
@@ -115,6 +116,14 @@ class OracleEnv:
         buf = np.zeros((128, 16))
         n = self.L.hoo_get_contacts(self.h, _p(buf), 128)
         return buf[:n].copy()
+
+    def contact_forces(self):
+        """mj_contactForce of every contact of the last forward pass ([ncon, 6], contact frame; ho_im4.py:866-881)"""
+        n = int(self.get("ncon")[0])
+        out = np.zeros((n, 6))
+        for c in range(n):
+            assert self.L.hoo_contact_force(self.h, c, _p(out[c])) == 0
+        return out
 
     # ---- configuration
     def set_cfg(self, jkp, jkd, torque_lim, thresh=(0.1, 1.0, 0.1, 0.1, 1.0), rf_scale=2.5, rt_scale=0.125,

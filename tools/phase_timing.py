@@ -21,7 +21,7 @@ seq = torch.randint(0, 16, (N,), generator=g, dtype=torch.int32); start = torch.
 sim.reset(seq, start)
 sim.enable_timing(True)
 names = ['other', 'pd_torque', 'applied+record', 'kinematics', 'mass_matrix', 'bias', 'collision', 'constraint', 'M^-1 solve',
-         'newton', 'euler', 'avg+classify', 'rfc_qp', 'diff+reward', 'obs+store', 'hs:assemble', 'hs:factor', 'hs:forward', 'hs:transpose+back', 'hs:store', 'pre-hsolve (newton pre-work etc.)', 'kin:levels', 'kin:inertia']
+         'newton: after the loop', 'euler', 'nw: J^T f + gradient', 'nw: M s + sums', 'diff+reward', 'nw: J s (rows_jar)', 'hs:assemble', 'hs:factor', 'nw: line search', 'hs:transpose+back', 'nw: rows cost + criteria', 'pre-hsolve (PD / M^-1 / Euler set-up)', 'kin:levels', 'kin:inertia', 'nw: warm-start evaluation']
 tot = np.zeros(24); ms = []
 for t in range(8):
     a = torch.randn(N, 32, generator=g) * 0.1
@@ -32,14 +32,8 @@ for t in range(8):
     sim.L.hoicdbg_phase_cycles(C.c_void_p(sim.h), buf, C.byref(ov))
     if t >= 2: tot += np.array(buf[:])
 tot /= 6
-cnt_slots = (11, 12, 14, 17, 19)
-counters = tot.copy()
-for i in cnt_slots: tot[i] = 0
 print('kernel ms', np.round(ms, 2), 'iters mean', float(out[3][:, 3].float().mean()), 'overflow', ov.value)
 s = tot.sum()
 for n, v in zip(names, tot):
     print(f'{n:16s} {v:12.0f} cycles  {100 * v / s:5.1f}%')
 print('total cycles per env-step', s, ' (@2.4GHz = %.3f ms)' % (s / 2.4e6))
-# event counters of the Newton loop (per env-step = 15 substeps), kept in the phase slots the substep kernel does not use
-c = {k: counters[i] for k, i in (('stop: gradient', 11), ('stop: step', 12), ('stop: improvement', 14), ('Hessian solves', 17), ('Hessian == M', 19))}
-print('Newton events per env-step:', {k: round(float(v), 2) for k, v in c.items()})
