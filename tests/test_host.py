@@ -388,3 +388,17 @@ def test_bench_gpus_flag_refuses_instead_of_running_one_rank():
     if torch.cuda.device_count() < 2:
         assert p.returncode == 3, (p.returncode, p.stderr.decode()[-400:])
         assert b"{" not in p.stdout and b"only" in p.stderr
+
+
+def test_library_reports_the_sources_it_was_built_from():
+    """hoic_build_id() = first 16 hex digits of the SHA-256 over the library's sources in the Makefile's order: the counter passes
+    under profiles/ carry it and bench.py quotes them only for the library they were taken on -- a stale or hand-compiled object
+    (id "unknown") must not pass for the current sources."""
+    import hashlib
+    csrc = os.path.join(ROOT, "hoic_amd", "csrc")
+    hdr = ["hoic_zfilter.h", "hoic_types.h", "hoic_math.h", "hoic_dynamics.h", "hoic_collide.h", "hoic_solver.h", "hoic_env.h",
+           "../../include/hoic.h", "../../include/hoic_model.h"]
+    h = hashlib.sha256()
+    for f in hdr + ["hoic_capi.hip", "hoic_mlp.hip"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    assert lib.build_id() == h.hexdigest()[:16]
