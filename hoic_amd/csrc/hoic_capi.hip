@@ -223,11 +223,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   GPTR(const float) act = as_global(action) + (size_t)io * HOIC_ACT_DIM;       // clipped where it is read (ho_im4.py:613)
   const int seq = as_global(st.seq)[env];
   ExpertView ev{&ex, as_global(ex.seq_off)[seq], as_global(ex.seq_len)[seq], as_global(st.start)[env], as_global(st.cur_t)[env]};
-  float vf[3], vt[3];
-  for (int i = 0; i < 3; i++) {
-    vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * fminf(fmaxf(act[m.nu + i], -1.f), 1.f) : 0.f;     // :622-623
-    vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * fminf(fmaxf(act[m.nu + 3 + i], -1.f), 1.f) : 0.f;
-  }
   int* ovf = (int*)&as_global(st.diag)[2 * env];
   int ncapped = 0;
   GPTR(float) post = as_global(st.post) + ((size_t)post_buf * n_envs + env) * PB_SIZE;
@@ -280,11 +275,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (mode == 1) {
       dev_record_contact(ml, w, post); PT(2);          // :543 (contacts of the previous forward pass)
       dev_pd_torque(ml, cl, w, M, ev, act); PT(1);     // :518-523
-      dev_applied(ml, cl, w, vf, vt);                  // :526-540
+      dev_applied(ml, cl, w, act);                     // :526-540
     }
     if (mode == 0) {   // the lagged pass runs on (qlag, vlag): into the workspace's state for the pass, the state proper comes back below
-      if (tid < NQP) w.qpos[tid] = gqlag[tid];
-      if (tid < NV) w.qvel[tid] = gvlag[tid];
+      const int tl = opaque(tid);      // (the lane's global addresses are formed here, not kept in registers across the loop)
+      if (tl < NQP) w.qpos[tl] = gqlag[tl];
+      if (tl < NV) w.qvel[tl] = gvlag[tl];
       wsync();
     }
     dev_forward_kin(ml, cl, w, M, w.qpos, w.qvel, tid == 0 ? ovf : nullptr);
@@ -293,8 +289,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
         for (int i = 0; i < 9; i++) oldg[g * 12 + 3 + i] = w.gxmat[g][i];
       }
-      if (tid < NQP) w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
-      if (tid < NV) w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid];
+      const int tl = opaque(tid);
+      if (tl < NQP) w.qpos[tl] = as_global(st.qpos)[(size_t)env * NQP + tl];
+      if (tl < NV) w.qvel[tl] = as_global(st.qvel)[(size_t)env * NV + tl];
       wsync();
       old_objvel = (tid < 6) ? w.qvel[ml.nv - 6 + tid] : 0.f;
       mode = 1;
@@ -310,8 +307,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (done_sub >= nsub - 1) trace_last = w.solver_iter * 100 + w.ncon;
 #endif
     if (!ok) {  // the reference converts the MuJoCo exception into fail=True (:635-637); keep the last finite state
-      if (tid < NQP) w.qpos[tid] = gqlag[tid];
-      if (tid < NV) { w.qvel[tid] = gvlag[tid]; w.qacc[tid] = 0.f; }
+      const int tl = opaque(tid);
+      if (tl < NQP) w.qpos[tl] = gqlag[tl];
+      if (tl < NV) { w.qvel[tl] = gvlag[tl]; w.qacc[tl] = 0.f; }
       wsync();
       mode = 2;
       continue;
@@ -376,7 +374,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   if (tid == 0) as_global(st.cost)[env] = (unsigned)((clk1 - clk0) >> 6);
   if (MODE != 0) {
     wsync();
-    dev_poststep<POST_A>(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, vf, vt, obs, reward, reward_info, flags, percent,
+    dev_poststep<POST_A>(m, cfg, w, ex, st, ev, env, io, ok, w.solver_iter, nullptr, nullptr, obs, reward, reward_info, flags, percent,
                          next_seq, next_start, post);
   }
 #ifdef HOIC_TRACE_DISPATCH   // development aid: when and where (XCC / SE / CU / SIMD) each env ran, constant 100 MHz clock

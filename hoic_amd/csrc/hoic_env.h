@@ -72,8 +72,15 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
 
 // ---- generalized applied forces: gravity compensation + residual object wrench (lagged Jacobians) + the PD torques of
 // dev_pd_torque (sc.vec.ctrl)
-__device__ __forceinline__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, const float* vf, const float* vt) {
+// act: the env's action row (global memory): the residual wrench is formed from it here, every substep, instead of living in six
+// registers for the whole launch (ho_im4.py:622-623)
+__device__ __forceinline__ void dev_applied(const DevModel& m, const DevConfig& cfg, Work& w, GPTR(const float) act) {
   const int tid = opaque(threadIdx.x);
+  float vf[3], vt[3];
+  for (int i = 0; i < 3; i++) {
+    vf[i] = cfg.c.residual_force ? cfg.c.residual_force_scale * fminf(fmaxf(act[m.nu + i], -1.f), 1.f) : 0.f;
+    vt[i] = cfg.c.residual_force ? cfg.c.residual_torque_scale * fminf(fmaxf(act[m.nu + 3 + i], -1.f), 1.f) : 0.f;
+  }
   if (tid < NV) {
     float s = 0.f;
     if (tid < m.nv) {
