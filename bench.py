@@ -445,8 +445,12 @@ def main():
         if (args.other_configs and world == 1 and args.obj == "box" and args.workload == "train" and args.sample_mode == "fixed"
                 and not args.pretrain and args.envs == 4096):
             agent.env.close()
-            out["other_configs"] = {o: quick_config(o, args, torch.device("cuda", local_rank), agent._streams, agent.learner._value_stream)
-                                    for o in ("bottle", "banana")}
+            out["other_configs"] = {}
+            for o in ("bottle", "banana"):
+                try:
+                    out["other_configs"][o] = quick_config(o, args, torch.device("cuda", local_rank), agent._streams, agent.learner._value_stream)
+                except Exception as e:          # the headline line must not die with a secondary measurement
+                    out["other_configs"][o] = {"error": f"{type(e).__name__}: {e}"}
         out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

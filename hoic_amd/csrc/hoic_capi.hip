@@ -43,7 +43,7 @@ __device__ __forceinline__ void load_state(const DevModel& m, const DevState& st
 }
 // lag_too: the state is also the state before the last integration (after a reset)
 template <class W> __device__ __forceinline__ void store_state(const DevState& st, const W& w, int env, bool lag_too) {
-  const int tid = threadIdx.x;
+  const int tid = opaque(threadIdx.x);
   if (tid < NQP) { as_global(st.qpos)[(size_t)env * NQP + tid] = w.qpos[tid]; if (lag_too) as_global(st.qlag)[(size_t)env * NQP + tid] = w.qpos[tid]; }
   if (tid < NV) {
     as_global(st.qvel)[(size_t)env * NV + tid] = w.qvel[tid]; if (lag_too) as_global(st.vlag)[(size_t)env * NV + tid] = w.qvel[tid];
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       if (tl < NV) w.qvel[tl] = gvlag[tl];
       wsync();
     }
-    dev_forward_kin(ml, cl, w, M, w.qpos, w.qvel, tid == 0 ? ovf : nullptr);
+    dev_forward_kin(ml, cl, w, M, w.qpos, w.qvel, ovf);      // (ovf: wave-uniform; only lane 0 writes through it)
     if (mode == 0) {
       for (int g = tid; g < ml.ngeom; g += NT) {
         for (int i = 0; i < 3; i++) oldg[g * 12 + i] = w.gxpos[g][i];
@@ -318,11 +318,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (++done_sub >= nsub) break;
   }
   PT(0);
+  const int te = opaque(tid);       // (lane id of the epilogue: its global addresses are formed here, not carried through the loop)
   {   // 15-substep finite differences (:554-559) -> the hand-over record; the geom poses of the last forward pass -> oldg
     const float dt = (float)nsub * m.timestep, idt = ok ? 1.f / dt : 0.f;
     const bool hand_over = ok && nsub > 0;
-    if (tid < 6) post[PB_OBJACC + tid] = ok ? (w.qvel[m.nv - 6 + tid] - old_objvel) * idt : 0.f;                   // :554
-    for (int g = tid; g < m.ngeom; g += NT) {
+    if (te < 6) post[PB_OBJACC + te] = ok ? (w.qvel[m.nv - 6 + te] - old_objvel) * idt : 0.f;                   // :554
+    for (int g = te; g < m.ngeom; g += NT) {
       float gv[3] = {0.f, 0.f, 0.f}, ga[3] = {0.f, 0.f, 0.f};
       if (ok) {
         // the geom's rotation matrix from its body's pose (the LDS copy of the forward pass lived only until the collision
@@ -351,22 +352,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       for (int i = 0; i < 3; i++) { post[PB_GVEL + g * 3 + i] = gv[i]; post[PB_GANGVEL + g * 3 + i] = ga[i]; }
     }
   }
-  if (tid == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
-  for (int k = tid; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
-  for (int k = tid; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
-  for (int k = tid; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
+  if (te == 0) { post[PB_OK] = ok ? 1.f : 0.f; post[PB_ITER] = (float)w.solver_iter; }
+  for (int k = te; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
+  for (int k = te; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
+  for (int k = te; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
   store_state(st, w, env, false);
   if (ok && nsub > 0) {       // hand the last forward pass over to the next launch (it ran on the state that is now qlag, vlag)
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) lag[LG_M + reg * NT + tid] = M.r[reg];
-    if (tid < NV) lag[LG_BIAS + tid] = w.bias[tid];
-    for (int k = tid; k < NV * 6; k += NT) lag[LG_S + k] = w.S[k / 6][k % 6];
+    for (int reg = 0; reg < 16; reg++) lag[LG_M + reg * NT + te] = M.r[reg];
+    if (te < NV) lag[LG_BIAS + te] = w.bias[te];
+    for (int k = te; k < NV * 6; k += NT) lag[LG_S + k] = w.S[k / 6][k % 6];
     const int nc = w.ncon;
-    if (tid == 0) lag[LG_NCON] = (float)nc;
-    if (tid < nc) {
-      for (int i = 0; i < 3; i++) lag[LG_CPOS + tid * 3 + i] = w.c_pos[tid][i];
-      for (int i = 0; i < 9; i++) lag[LG_CFRAME + tid * 9 + i] = w.c_frame[tid][i];
-      lag[LG_CGEOM + tid] = (float)((int)w.c_g1[tid] | ((int)w.c_g2[tid] << 8));
+    if (te == 0) lag[LG_NCON] = (float)nc;
+    if (te < nc) {
+      for (int i = 0; i < 3; i++) lag[LG_CPOS + te * 3 + i] = w.c_pos[te][i];
+      for (int i = 0; i < 9; i++) lag[LG_CFRAME + te * 9 + i] = w.c_frame[te][i];
+      lag[LG_CGEOM + te] = (float)((int)w.c_g1[te] | ((int)w.c_g2[te] << 8));
     }
   }
   if (tid == 0) { as_global(st.lag_valid)[env] = (ok && nsub > 0) ? 1 : 0; if (ncapped) as_global(st.diag)[2 * env + 1] += ncapped; }

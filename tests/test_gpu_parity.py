@@ -1076,6 +1076,41 @@ def test_diagnostics_guard_the_compiled_caps(box_blob, setup):
     sim.close()
 
 
+def test_contact_and_row_caps_cut_the_list_and_are_counted():
+    """The two compiled capacities of the contact stage on states that exceed them: the hand pushed INTO the banana, which lies on
+    the table (three mesh parts x up to four condim-4 table contacts of six rows each, then two contacts per finger capsule and
+    mesh part).  More than 32 contacts are found, the list is cut after the first 32 in pair order, and -- because its twelve
+    table contacts take six rows each -- cut again where the 128 constraint rows run out (hoic_collide.h, last scan).  Both cuts
+    are counted (hoic_get_diagnostics), the step stays finite, and nothing of it shows in a normal rollout (the other tests
+    assert a zero counter)."""
+    blob, cfg, ex, thresh = _obj_setup("banana")
+    N = 8
+    sim = _sim(blob, N, cfg, ex, thresh)
+    sim.reset(np.zeros(N, dtype=np.int64), np.full(N, 200))
+    q, v, _ = sim.get_state()
+    q = q.cpu().numpy().copy(); v = np.zeros_like(v.cpu().numpy())
+    rng = np.random.default_rng(2)
+    probe0 = sim.probe_forward(q[:1, :33], v[:1], kinematics_only=True)
+    for i in range(N):
+        q[i, 26:29] = [0.0, 0.0, 0.012 + 0.002 * i]              # the object low over the table: its hull parts touch it
+        q[i, 29:33] = [1.0, 0.0, 0.0, 0.0]
+        q[i, 0:3] = q[i, 26:29] - probe0["xpos"][0, sim.model.scalar("hand_body0")] + q[i, 0:3] + rng.normal(size=3) * 0.004   # the palm into the object
+    sim.set_state(torch.as_tensor(q), torch.as_tensor(v))
+    out = sim.probe_forward(q[:, :33], v, kinematics_only=True)
+    ncon = out["ncon"]
+    cc = out["contacts"]
+    rows = np.array([sum(1 if d == 1 else 2 * (int(d) - 1) for d in cc[i, :ncon[i], 15]) for i in range(N)])
+    print("contacts", ncon.tolist(), "rows", rows.tolist(), "condim-4 contacts", [(cc[i, :ncon[i], 15] == 4).sum() for i in range(N)])
+    assert ncon.max() <= 32 and rows.max() <= 128
+    assert (ncon >= 20).any(), "the test needs states that fill the contact list"
+    a = torch.zeros(N, 32)
+    o = sim.step(a)
+    assert torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all()
+    d = sim.diagnostics()
+    assert d["contact_overflow"] > 0 and d["envs_with_overflow"] > 0, d            # the cuts were taken and counted
+    sim.close()
+
+
 def test_single_env_adapter_has_the_reference_signature(box_blob, oracle_lib, setup):
     """hoic_amd.env.HandObjMimic4 — NumPy in / out, step(a[32]) -> (obs[617], 1.0, done, {fail, end, percent}) as
     uhc/envs/ho_im4.py:611-662 — stepped against the oracle on the same action tape."""
