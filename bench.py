@@ -234,7 +234,7 @@ def quick_config(obj, args, device, streams=None, value_stream=None, iterations=
     expert = motions.synthetic_expert(model, 17, 600)
     agent = AgentHandMimic(cfg, device=device, n_envs=args.envs, model=obj, expert_seqs=expert, update_dtype=args.update_dtype,
                            n_groups=args.groups, rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward),
-                           update_streams=args.update_streams)
+                           update_streams=args.update_streams, run_ahead=bool(args.run_ahead))
     # the headline agent's streams: fresh ones would be mapped onto the process's few hardware queues again, and two env ranges
     # that land on ONE queue run one after the other (measured: Bottle rollout 0.79 M instead of 1.4 M env-steps/s)
     if streams is not None:
@@ -245,13 +245,13 @@ def quick_config(obj, args, device, streams=None, value_stream=None, iterations=
         agent.optimize_policy(it, save_model=False)
     agent.env.sim.enable_timing(True)
     torch.cuda.synchronize()
-    t0 = time.time(); ts = tu = 0.0; k_ms = []; steps = 0
+    t0 = time.time(); k_ms = []; steps = 0; infos = []
     for it in range(iterations):
-        info = agent.optimize_policy(warm + it, save_model=False)
-        ts += info["T_sample"]; tu += info["T_update"]; steps += int(agent.last_rollout_steps)
+        infos.append(agent.optimize_policy(warm + it, save_model=False)); steps += int(agent.last_rollout_steps)
         k_ms += agent.env.sim.step_times()[0]
     agent.learner.finish_update(); torch.cuda.synchronize()
     el = time.time() - t0
+    ts, tu = sum(i["T_sample"] for i in infos), sum(i["T_update"] for i in infos)     # (GPU-timeline durations, read after the region)
     n = steps * args.envs
     diag = agent.env.sim.diagnostics()
     out = {"workload": f"{obj.capitalize()}, {args.envs} parallel envs, whole loop", "value": n / el, "unit": "env-steps/s", "timed_iterations": iterations,
@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=None, help="Newton iteration cap per substep (default: the model's <option iterations>, 20)")
     ap.add_argument("--groups", type=int, default=None, help="env ranges pipelined on separate streams during the rollout (default: 2 at >= 4096 envs)")
+    ap.add_argument("--run-ahead", type=int, default=1, help="1 = the agent enqueues rollout and update back to back and waits for the rollout's "
+                    "statistics only (default); 0 = every phase is drained before the next is enqueued (A/B)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="compute units kept free of substep workgroups during the rollout (hoic_set_cu_reserve; multiple of 8)")
     ap.add_argument("--sample-mode", default="fixed", choices=["fixed", "episodes"],
                     help="fixed: fixed-horizon batches of every env (the GPU default, what `value` of the headline is quoted on); episodes: the "
@@ -331,7 +333,7 @@ def main():
     expert = motions.synthetic_expert(model, 17, 600, grasp="closed" if args.workload == "closed-grasp" else "kinematic")   # 17 sequences x 600 frames
     agent = AgentHandMimic(cfg, device=torch.device("cuda", local_rank), n_envs=args.envs, model=args.obj,
                            expert_seqs=expert, distributed=distributed, update_dtype=args.update_dtype,
-                           solver_iterations=args.solver_iterations, n_groups=args.groups, reserve_cus=args.reserve_cus, scaling=args.scaling,
+                           solver_iterations=args.solver_iterations, n_groups=args.groups, reserve_cus=args.reserve_cus, run_ahead=bool(args.run_ahead), scaling=args.scaling,
                            start_min=100 if args.workload in ("grasp", "closed-grasp") else 0, overlap_value_update=bool(args.overlap),
                            rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams,
                            sample_mode=args.sample_mode)
@@ -360,21 +362,26 @@ def main():
     post_ms = []
     barrier()
     t0 = time.time()
-    t_sample = t_update = 0.0
+    infos = []
+    host_phases = [0.0, 0.0, 0.0]
     last_log = None
     launches = 0
     host_enqueue = 0.0
     collected = 0          # samples that entered the batches (episodes mode: valid rows; fixed horizon: steps x envs)
     for _ in range(n_it):
         info = agent.optimize_policy(epoch, save_model=False); epoch += 1
-        t_sample += info["T_sample"]; t_update += info["T_update"]; last_log = info["log"]
+        infos.append(info); last_log = info["log"]
         collected += int(info["log"].num_steps); launches += int(agent.last_rollout_steps)
         host_enqueue += float(getattr(agent, "last_host_enqueue_s", 0.0))
+        host_phases = [a_ + b_ for a_, b_ in zip(host_phases, getattr(agent, "last_host_phases", (0.0, 0.0, 0.0)))]
         a, b = agent.env.sim.step_times()       # HIP events on the launch stream, read after the iteration's own sync
         kernel_ms += a; post_ms += b
     agent.learner.finish_update()            # an asynchronous value phase belongs to the timed region
     barrier()
     elapsed = time.time() - t0
+    # rollout / update split: the agent's host runs ahead of the GPU, so the two durations are taken between HIP events on the
+    # main stream (agent.IterationInfo) and read here, after the timed region; they add up to the region's GPU timeline
+    t_sample, t_update = sum(i["T_sample"] for i in infos), sum(i["T_update"] for i in infos)
     tmax = torch.tensor([elapsed, t_sample, t_update], device="cuda", dtype=torch.float64)
     if distributed:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -421,6 +428,7 @@ def main():
                        "samples_per_iteration": total_env_steps // n_it, "parallelism": f"env-dp{world}", "sample_mode": args.sample_mode,
                        "rollout_env_ranges": n_groups, "update_gemms": args.update_dtype,
                        "value_update_overlaps_next_rollout": bool(agent.learner.overlap_value_update),
+                       "host_runs_ahead": bool(agent.run_ahead),
                        "rollout_policy_forward": "hoic_fwd_tiled_kernel (LDS-free f16x3)" if (args.rollout_forward == "tiled" and args.update_dtype == "f16x3") else "PyTorch float32",
                        "async_reward": bool(args.async_reward), "update_streams": args.update_streams,
                        "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
@@ -428,6 +436,8 @@ def main():
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,
             "update_s_per_iteration": t_update / n_it, "rollout_s_per_iteration": t_sample / n_it,
             "rollout_host_enqueue_s_per_iteration": host_enqueue / n_it,
+            "host_s_per_iteration": ({"enqueue_rollout": host_phases[0] / n_it, "enqueue_update": host_phases[1] / n_it,
+                                      "wait_rollout_statistics": host_phases[2] / n_it} if agent.run_ahead else None),
             "avg_episode_len": float(last_log.avg_episode_len), "avg_c_reward": float(last_log.avg_c_reward),
             "workload_stats": {"hand_object_contact_env_fraction": float(ho.any(1).mean()), "mean_contacts_per_env": float((cc[:, :, 15] > 0).sum(1).mean()),
                                "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"],

@@ -79,6 +79,43 @@ class LoggerRL:
             setattr(self, k, v)
 
 
+class PendingLog:
+    """A rollout's LoggerRL whose statistics are still on their way to the host: the device reductions and their copy into
+    pinned memory are enqueued, ``result()`` (or any attribute access) waits for the copy's event -- the end of the ROLLOUT
+    on the GPU's timeline, not of whatever was enqueued behind it -- and builds the LoggerRL."""
+
+    def __init__(self, event, build):
+        self.__dict__["_event"], self.__dict__["_build"], self.__dict__["_log"] = event, build, None
+
+    def result(self):
+        if self._log is None:
+            self._event.synchronize()
+            self.__dict__["_log"] = self._build()
+        return self._log
+
+    def __getattr__(self, k):
+        return getattr(self.result(), k)
+
+
+class IterationInfo(dict):
+    """optimize_policy's result when the host runs ahead of the GPU: T_sample / T_update / T_total are durations on the GPU's
+    timeline between HIP events of the main stream (iteration start, rollout end, update end); reading one of them waits for
+    the iteration's last event, so a loop that wants to stay ahead reads them later (bench.py: after the timed region)."""
+
+    def __init__(self, log, events):
+        super().__init__(log=log)
+        self._events = events
+
+    def __missing__(self, k):
+        if k not in ("T_sample", "T_update", "T_total"):
+            raise KeyError(k)
+        e0, e1, e2 = self._events
+        e2.synchronize()
+        self["T_sample"], self["T_update"] = e0.elapsed_time(e1) * 1e-3, e1.elapsed_time(e2) * 1e-3
+        self["T_total"] = self["T_sample"] + self["T_update"]
+        return dict.__getitem__(self, k)
+
+
 class PPOLearner:
     """Policy/value replicas, optimizers and the PPO update (AgentPG.update_params + AgentPPO.update_policy).
     Device-agnostic so the multi-rank path can be exercised with gloo on CPU."""
@@ -112,6 +149,9 @@ class PPOLearner:
         self._value_stream = self._value_event = self._value_keep = None
         assert update_dtype in ("f32", "bf16", "f16x3")
         self._engines = None             # f16x3: SplitMLP of (value net, policy net)
+        # the f16-range check of an update in two halves (mlp._post_overflow): with defer_checks the host does not wait for
+        # the update it has just enqueued -- the counters are read before the NEXT update is enqueued (or by finish_update)
+        self.defer_checks = False
 
     # ------------------------------------------------------------------ update (agent_pg.py:39-55, agent_ppo.py:16-64)
     def _allreduce_start(self, params):
@@ -295,7 +335,15 @@ class PPOLearner:
             self._losses = (value_loss, policy_phase())
         # BOTH engines: each SplitMLP owns its exponent table and its saturation counter (a policy hidden activation or
         # gradient beyond the float16 range under its delayed exponent must be as loud as a value-network one)
-        veng.check_overflow(); peng.check_overflow()
+        veng.post_overflow(); peng.post_overflow()
+        if not self.defer_checks:
+            self.resolve_checks()
+
+    def resolve_checks(self):
+        """the host half of the last update's f16-range check (no-op when nothing is outstanding)"""
+        if self._engines is not None:
+            for eng in self._engines:
+                eng.wait_overflow()
 
     def wait_value_update(self):
         """Everything that reads the value network (or needs the update finished) calls this first: makes the current stream
@@ -309,6 +357,7 @@ class PPOLearner:
     def finish_update(self):
         """wait_value_update + host synchronisation + the f16-range check of the asynchronous phase"""
         self.wait_value_update()
+        self.resolve_checks()
         if getattr(self, "_overflow_check_due", False):
             self._overflow_check_due = False
             torch.cuda.current_stream(self.device).synchronize()
@@ -375,7 +424,7 @@ class AgentHandMimic:
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
                  start_min=0, overlap_value_update=False, rollout_forward="tiled", async_reward=True, fused_adam=True,
-                 update_streams=2, filter_mode="online", reserve_cus=0):
+                 update_streams=2, filter_mode="online", reserve_cus=0, run_ahead=True):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
@@ -434,6 +483,11 @@ class AgentHandMimic:
                                   strict_reference, fused_adam=fused_adam, update_streams=update_streams)
         # the value network's five steps on a side stream, under the next iteration's rollout (f16x3 update on the GPU only)
         self.learner.overlap_value_update = bool(overlap_value_update) and update_dtype == "f16x3" and self.device.type == "cuda"
+        # run_ahead: optimize_policy enqueues rollout and update back to back and waits for the rollout's statistics only (the
+        # fixed-horizon sampler on the GPU; see optimize_policy).  Off = every phase is drained before the next is enqueued.
+        self.run_ahead = (bool(run_ahead) and self.device.type == "cuda" and sample_mode == "fixed"
+                          and not self.learner.overlap_value_update and not os.environ.get("HOIC_NO_RUN_AHEAD"))
+        self.learner.defer_checks = self.run_ahead
         self.policy_net, self.value_net = self.learner.policy_net, self.learner.value_net
         self.optimizer_policy, self.optimizer_value = self.learner.optimizer_policy, self.learner.optimizer_value
         self.running_state = BatchZFilter(self.state_dim, clip=5.0, device=self.device)
@@ -476,7 +530,7 @@ class AgentHandMimic:
             start = (u * self._max_start[seq].to(u.dtype)).to(torch.int32)
         return seq.to(torch.int32), start
 
-    def _make_log(self, steps, rewards, end_flags, done_flags, rinfo, valid, t0):
+    def _make_log(self, steps, rewards, end_flags, done_flags, rinfo, valid, t0, defer=False):
         """LoggerRL of a rollout held as [T, N] tensors.  ``rewards`` carry the end bonus the kernel added on 'end'
         steps (hoic_capi.hip dev_poststep); the c_reward statistics are taken without it, as LoggerRL.step sees them
         (agent_handmimic.py:476-482) — they feed env.end_reward of the next iteration (:318-319)."""
@@ -495,14 +549,28 @@ class AgentHandMimic:
         stats = torch.stack([csum, cmin, cmax, n_done])
         if self.distributed:
             import torch.distributed as dist
-            tot = torch.cat([stats[[0, 3]], c_info, torch.tensor([float(steps)], device=stats.device, dtype=torch.float64)])
+            tot = torch.cat([stats[[0, 3]], c_info, torch.full((1,), float(steps), device=stats.device, dtype=torch.float64)])
             dist.all_reduce(tot)
             mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
             mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:-1]; steps = int(tot[-1].item())
-        s = stats.cpu().numpy(); ci = c_info.cpu().numpy()
-        return LoggerRL(num_steps=steps, num_episodes=int(s[3]), total_c_reward=s[0], min_c_reward=s[1], max_c_reward=s[2],
-                        total_c_info=ci, sample_time=time.time() - t0, end_bonus=bonus)
+            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:-1]
+            # (fixed horizon: every rank holds the same T x N, no need to read the reduced count back)
+            steps = int(tot[-1].item()) if valid is not None else steps * self.world
+        sample_time = time.time() - t0
+
+        def build(s, ci):
+            return LoggerRL(num_steps=steps, num_episodes=int(s[3]), total_c_reward=s[0], min_c_reward=s[1], max_c_reward=s[2],
+                            total_c_info=ci, sample_time=sample_time, end_bonus=bonus)
+        if not (defer and stats.is_cuda):
+            return build(stats.cpu().numpy(), c_info.cpu().numpy())
+        # the host runs ahead: copy into pinned memory behind the reductions, wait for that copy only (PendingLog)
+        both = torch.cat([stats, c_info])
+        if getattr(self, "_log_host", None) is None or self._log_host.shape != both.shape:
+            self._log_host = torch.empty(both.shape, dtype=both.dtype).pin_memory()
+        host = self._log_host
+        host.copy_(both, non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
+        return PendingLog(ev, lambda: build(host[:4].numpy().copy(), host[4:].numpy().copy()))
 
     # ------------------------------------------------------------------ rollout (sample / sample_process, :430-535)
     def _rollout_forward(self, groups):
@@ -620,8 +688,10 @@ class AgentHandMimic:
         obs = self.env.get_obs()
         self._obs = obs
         if fwd is not None:
-            for e in fwd:
-                e.check_overflow()          # hidden activations beyond the float16 range under their delayed exponents: loud, not silent
+            for e in fwd:           # hidden activations beyond the float16 range under their delayed exponents: loud, not silent
+                e.post_overflow()
+                if not self.run_ahead:
+                    e.wait_overflow()
         if self.distributed:
             self.running_state.sync()          # one observation filter for all ranks from here on
         next_state = self.running_state(obs, update=False)
@@ -629,9 +699,13 @@ class AgentHandMimic:
         next_values = self.value_net(next_state).squeeze(1)
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
                                 exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values, valid=None)
-        log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0)
+        log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0, defer=self.run_ahead)
         self.last_rollout_steps = T
         return batch, log
+
+    def _resolve_rollout_checks(self):
+        for e in (getattr(self, "_fwd_engines", None) or []):
+            e.wait_overflow()
 
     @torch.no_grad()
     def _sample_episodes(self, min_batch_size, sync_every=8):
@@ -706,18 +780,50 @@ class AgentHandMimic:
 
     def optimize_policy(self, epoch, save_model=True):
         self.epoch = epoch
-        t0 = time.time()
-        self.per_epoch_update(epoch)
         share = self.world if (self.scaling == "strong" and self.distributed) else 1
-        batch, log = self.sample(int(math.ceil(self.cfg.min_batch_size / share)))
-        if self.cfg.end_reward:
-            self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
-        t1 = time.time()
-        self.update_params(batch)
-        if self.device.type == "cuda" and not self.learner.overlap_value_update:
-            torch.cuda.synchronize(self.device)      # (with the overlap the value phase keeps running under the next rollout)
-        t2 = time.time()
-        info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
+        if self.run_ahead and self.sample_mode == "fixed":
+            # The host runs one phase ahead of the GPU.  Nothing the update needs of the rollout is read on the host (batch,
+            # bootstrap values and advantages stay on the device), so rollout and update are enqueued back to back; the one
+            # host read of the iteration -- the logger's c_reward mean, which sets the NEXT rollout's end bonus (:318-319)
+            # -- waits for the rollout's end only, while the update is already queued behind it; the next call then
+            # enqueues its rollout behind the running update.  The GPU never drains at a phase boundary (measured before:
+            # 1.4 ms + 1.9 ms of an iteration idle or on launch-latency-bound tiny kernels there).  The reward-parameter
+            # refresh is stream-ordered (hoic_set_reward_params_async), the f16-range checks are read one phase late.
+            cur = torch.cuda.current_stream(self.device)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            h0 = time.perf_counter()
+            self.per_epoch_update(epoch)
+            ev[0].record(cur)
+            batch, log = self.sample(int(math.ceil(self.cfg.min_batch_size / share)))
+            ev[1].record(cur)
+            h1 = time.perf_counter()
+            self.update_params(batch)
+            ev[2].record(cur)
+            del batch
+            h2 = time.perf_counter()
+            log = log.result() if isinstance(log, PendingLog) else log
+            self._resolve_rollout_checks()
+            # host seconds: enqueueing the rollout, enqueueing the update (includes the wait for the previous update's range
+            # check), waiting for this rollout's statistics
+            self.last_host_phases = (h1 - h0, h2 - h1, time.perf_counter() - h2)
+            if self.cfg.end_reward:
+                self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
+            info = IterationInfo(log, ev)
+        else:
+            t0 = time.time()
+            self.per_epoch_update(epoch)
+            batch, log = self.sample(int(math.ceil(self.cfg.min_batch_size / share)))
+            log = log.result() if isinstance(log, PendingLog) else log
+            self._resolve_rollout_checks()
+            if self.cfg.end_reward:
+                self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
+            t1 = time.time()
+            self.update_params(batch)
+            if self.device.type == "cuda" and not self.learner.overlap_value_update:
+                self.learner.resolve_checks()
+                torch.cuda.synchronize(self.device)      # (with the overlap the value phase keeps running under the next rollout)
+            t2 = time.time()
+            info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
         if save_model and (epoch + 1) % self.cfg.save_n_epochs == 0 and self.rank == 0:
             self.save_checkpoint(epoch)
             info["log_eval"] = self.eval_policy(epoch)

@@ -949,6 +949,7 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
       }
     }
     m.mesh_prune = getenv("HOIC_MESH_STREAM") == nullptr ? 1 : 0;
+    m.obb_reject = getenv("HOIC_NO_OBB_REJECT") == nullptr ? 1 : 0;
   } else { set_err("model blob: mesh tables missing"); return false; }
   return true;
 }
@@ -1056,6 +1057,22 @@ extern "C" int32_t hoic_set_reward_params(hoic_sim* s, const hoic_reward_params*
   if (!s || !rp) { set_err("hoic_set_reward_params: null"); return HOIC_ERR_ARG; }
   s->hcfg.rp = *rp;
   return write_config(s);
+}
+// the stream-ordered form: the new parameters take effect for every launch enqueued on (or ordered behind) `stream` after
+// this call and nothing waits on the host -- the caller's training loop runs one phase ahead of the GPU
+__global__ void hoic_set_reward_params_kernel(DevConfig* cfg, hoic_reward_params rp) {
+  if (threadIdx.x == 0) cfg->rp = rp;
+}
+extern "C" int32_t hoic_set_reward_params_async(hoic_sim* s, const hoic_reward_params* rp, void* stream) {
+  if (!s || !rp) { set_err("hoic_set_reward_params_async: null"); return HOIC_ERR_ARG; }
+  HIPCHK(hipSetDevice(s->device));
+  // reward parts still running on the ranges' side streams read the old parameters: order them before the write
+  const int32_t rc = drain_rewards(s, (hipStream_t)stream);
+  if (rc != HOIC_OK) return rc;
+  s->hcfg.rp = *rp;
+  hipLaunchKernelGGL(hoic_set_reward_params_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s->d_cfg, *rp);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
 }
 extern "C" int32_t hoic_set_mode(hoic_sim* s, int32_t train) {
   if (!s) return HOIC_ERR_ARG;

@@ -648,6 +648,41 @@ HD void make_frame(float* f) {
   cross3(x, y, z);
 }
 
+// Separating-axis test of two oriented boxes, all 15 axes: true = along one of them the boxes are more than `gap` apart, so
+// nothing inside one is within `gap` of anything inside the other.  Box A: centre pa + Ra ca, axes = columns of Ra, half
+// sizes a; box B: centre pb, axes = columns of Rb, half sizes b.  Conservative in rounding (a pair is only dropped with
+// room to spare) and for nearly parallel edges (the usual epsilon on |R|).
+HD bool obb_separated(const float* pa, const float* Ra, const float* ca, const float* a, const float* pb, const float* Rb, const float* b, float gap) {
+  float R[3][3], Q[3][3], t[3];
+  const float d[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t[i] = d[0] * Ra[i] + d[1] * Ra[3 + i] + d[2] * Ra[6 + i] - ca[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { R[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]; Q[i][j] = fabsf(R[i][j]) + 1e-6f; }
+  }
+  const float g = gap + 1e-6f;
+  bool sep = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float lhs = fabsf(t[i]);
+    sep = sep || lhs > (a[i] + b[0] * Q[i][0] + b[1] * Q[i][1] + b[2] * Q[i][2] + g) * 1.00001f;
+    const float lb = fabsf(t[0] * R[0][i] + t[1] * R[1][i] + t[2] * R[2][i]);
+    sep = sep || lb > (b[i] + a[0] * Q[0][i] + a[1] * Q[1][i] + a[2] * Q[2][i] + g) * 1.00001f;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float lhs = fabsf(t[i2] * R[i1][j] - t[i1] * R[i2][j]);
+      sep = sep || lhs > (a[i1] * Q[i2][j] + a[i2] * Q[i1][j] + b[j1] * Q[i][j2] + b[j2] * Q[i][j1] + g) * 1.00001f;
+    }
+  }
+  return sep;
+}
+
 // ---- collision driver: lane = pair (two passes when npair > 64); contacts compacted into the workspace
 __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* overflow, int mesh_single) {
   const int tid = opaque(threadIdx.x);
@@ -671,6 +706,28 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         test = dot3(dv, dv) <= bound * bound;
       } else {        // bounding sphere of geom2 against the plane (exact reject: no point of geom2 can be within the margin)
         test = (p2[0] - p1[0]) * R1[2] + (p2[1] - p1[1]) * R1[5] + (p2[2] - p1[2]) * R1[8] <= bound;
+      }
+      if (test && m.obb_reject && (t1 == HOIC_GEOM_CAPSULE || t1 == HOIC_GEOM_BOX) && (t2 == HOIC_GEOM_CAPSULE || t2 == HOIC_GEOM_BOX || t2 == HOIC_GEOM_MESH)) {
+        // Second reject, one code path for every capsule / box / hull pair (no divergence between the pair types): both
+        // geoms as oriented boxes -- a capsule is inside r x r x (l + r) along its axis, a hull inside its bounding box in
+        // the mesh frame (the principal axes: tight for long objects) -- and the 15-axis separating-axis test with the
+        // pair's margin (the oracle's driver makes the same test with the same constants, ho_sim.c ho_collision).  A pair it
+        // drops is farther apart than the margin: the exact routines (capsule / box) return nothing for it anyway, and the
+        // hull routines could only report what their max-over-face-planes distance under-estimates next to a sharp hull
+        // vertex -- a shallow contact of two separated geoms that a geometric collider does not give (HOIC_NO_OBB_REJECT=1
+        // switches the test off: tests/test_gpu_parity.py test_obb_reject_only_drops_contacts_of_separated_pairs).  What
+        // it saves is the pair's turn in the sequential box-box / hull routines (four of five hull turns found nothing) and,
+        // when no lane is left, the capsule-box routine.
+        const float* z1 = m.pair_size1[p]; const float* z2 = m.pair_size2[p];
+        const bool cap1 = t1 == HOIC_GEOM_CAPSULE, cap2 = t2 == HOIC_GEOM_CAPSULE, hull2 = t2 == HOIC_GEOM_MESH;
+        const float h1[3] = {z1[0], cap1 ? z1[0] : z1[1], cap1 ? z1[1] + z1[0] : z1[2]};
+        float h2[3] = {z2[0], cap2 ? z2[0] : z2[1], cap2 ? z2[1] + z2[0] : z2[2]}, c2[3] = {0.f, 0.f, 0.f};
+        if (hull2) {
+          const int me = m.pair_mesh[p];
+#pragma unroll
+          for (int i = 0; i < 3; i++) { c2[i] = 0.5f * (m.mesh_aabb[me][i] + m.mesh_aabb[me][4 + i]); h2[i] = 0.5f * (m.mesh_aabb[me][4 + i] - m.mesh_aabb[me][i]); }
+        }
+        if (obb_separated(p2, R2, c2, h2, p1, R1, h1, m.pair_margin[p])) test = false;
       }
       isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
       ismesh = test && t2 == HOIC_GEOM_MESH;
@@ -699,22 +756,6 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
             cdist += (c - q[i]) * nl[i]; ext += hh * fabsf(nl[i]);
           }
           if (cdist - ext > mg + 1e-6f * (1.f + fabsf(cdist))) ismesh = false;      // the whole box is farther than the margin above the plane
-        }
-      }
-      if (isbb) {
-        // per-lane pre-test on the six face axes: a pair separated by more than the margin along a face normal has no
-        // contact and does not take a turn in the (sequential) wave-cooperative routine below
-        const float mg = m.pair_margin[p] + 1e-6f;
-        float tw[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, Rab[3][3];
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) Rab[i][j] = fabsf(R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j]) + 1e-6f;
-        const float* ha = m.pair_size1[p]; const float* hb = m.pair_size2[p];
-        for (int i = 0; i < 3; i++) {
-          const float ta = tw[0] * R1[i] + tw[1] * R1[3 + i] + tw[2] * R1[6 + i];
-          const float tb = tw[0] * R2[i] + tw[1] * R2[3 + i] + tw[2] * R2[6 + i];
-          const float pa_ = ha[i] + hb[0] * Rab[i][0] + hb[1] * Rab[i][1] + hb[2] * Rab[i][2] - fabsf(ta);
-          const float pb_ = hb[i] + ha[0] * Rab[0][i] + ha[1] * Rab[1][i] + ha[2] * Rab[2][i] - fabsf(tb);
-          if (pa_ < -mg || pb_ < -mg) isbb = false;
         }
       }
       if (test && !isbb && !ismesh) {

@@ -86,6 +86,7 @@ struct DevModel {
   __attribute__((aligned(16))) float mesh_plane[MAXMESHP][4];   // hull faces n.x <= d in the geom frame
   // ---- run bounds of the hull tables (build_model; exact pruning of the narrow phase's hull queries, hoic_collide.h)
   int mesh_prune;                                  // 0: stream every table entry (HOIC_MESH_STREAM=1, A/B and the identity test)
+  int obb_reject;                                  // 0: no oriented-box reject in the collision driver (HOIC_NO_OBB_REJECT=1, A/B and its test)
   int mesh_vrunadr[HOIC_MAX_MESH], mesh_vrunnum[HOIC_MAX_MESH], mesh_frunadr[HOIC_MAX_MESH], mesh_frunnum[HOIC_MAX_MESH];
   __attribute__((aligned(16))) float mesh_aabb[HOIC_MAX_MESH][8];      // lo xyz _, hi xyz _ of the hull vertices (mesh frame)
   __attribute__((aligned(16))) float mesh_vrun[MAXVRUN][4];            // bounding sphere of a run of HOIC_HULL_RUN_VERTS vertices: centre, radius

@@ -39,7 +39,7 @@ class RewardParams(C.Structure):
 
 
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error", "hoic_build_id",
-           "hoic_set_config", "hoic_set_reward_params", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
+           "hoic_set_config", "hoic_set_reward_params", "hoic_set_reward_params_async", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
            "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame", "hoic_get_diagnostics", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps",
@@ -83,6 +83,7 @@ def load():
         getattr(L, n).restype = i32
     L.hoic_set_config.argtypes = [vp, C.POINTER(EnvConfig)]
     L.hoic_set_reward_params.argtypes = [vp, C.POINTER(RewardParams)]
+    L.hoic_set_reward_params_async.argtypes = [vp, C.POINTER(RewardParams), vp]
     L.hoic_set_mode.argtypes = [vp, i32]
     L.hoic_set_expert.argtypes = [vp, i32] + [vp] * 8
     L.hoic_reset.argtypes = [vp, vp, i32, vp, vp, vp, vp]
@@ -193,12 +194,15 @@ class BatchedSim:
         for i in range(16):
             r.wk[i] = float(wk[i])
         r.end_reward, r.use_end_reward = float(end_reward), int(use_end_reward)
-        self.torch.cuda.synchronize(self.device)
-        _chk(self.L.hoic_set_reward_params(self.h, C.byref(r)), "hoic_set_reward_params")
+        # ordered on the current stream, no host wait: the caller may be enqueueing the next rollout behind a running update
+        _chk(self.L.hoic_set_reward_params_async(self.h, C.byref(r), self._stream()), "hoic_set_reward_params_async")
 
     def set_mode(self, train: bool):
+        if getattr(self, "_mode_train", None) == bool(train):
+            return              # (hoic_set_mode synchronises the device: only on a change)
         self.torch.cuda.synchronize(self.device)
         _chk(self.L.hoic_set_mode(self.h, int(train)), "hoic_set_mode")
+        self._mode_train = bool(train)
 
     def set_expert(self, seqs):
         """seqs: list of dicts with the DatasetSingleDepth.preprocess_seq keys."""

@@ -295,6 +295,29 @@ def pick_splits16(tiles, nkt, slots=512, max_splits=64):
     return best[1]
 
 
+def _post_overflow(eng):
+    """The saturation check in two halves, so that a caller that runs ahead of the GPU does not have to stop for it: this half
+    enqueues the copy of the engine's counter into pinned host memory on the current stream (behind the launches that may
+    have raised it) and an event; ``_wait_overflow`` waits for that event only and raises.  ``check_overflow`` = both."""
+    if getattr(eng, "_ovf_host", None) is None:
+        eng._ovf_host = torch.zeros_like(eng.table.overflow, device="cpu").pin_memory()
+    eng._ovf_host.copy_(eng.table.overflow, non_blocking=True)
+    eng._ovf_event = torch.cuda.Event()
+    eng._ovf_event.record(torch.cuda.current_stream(eng.table.overflow.device))
+
+
+def _wait_overflow(eng):
+    ev = getattr(eng, "_ovf_event", None)
+    if ev is None:
+        return
+    ev.synchronize()
+    eng._ovf_event = None
+    n = int(eng._ovf_host.sum())
+    if n:
+        eng.table.overflow.zero_()
+        raise lib.HoicError(eng._OVERFLOW_MSG.format(n=n))
+
+
 class SplitMLP:
     SLOT_X, SLOT_W0, SLOT_H0, SLOT_DZ0 = 0, 1, 4, 8        # W: 1..3, H (hidden activations): 4..6, dZ: 8..10
 
@@ -435,12 +458,17 @@ class SplitMLP:
                 Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
                        "hoic_mlp_rowsum_packed")
 
+    _OVERFLOW_MSG = ("f16x3 GEMM path: {n} tensor(s) exceeded the float16 range under their delayed scale exponent; "
+                     "the update is not valid (use update_dtype='f32')")
+
+    def post_overflow(self):
+        return _post_overflow(self)
+
+    def wait_overflow(self):
+        return _wait_overflow(self)
+
     def check_overflow(self):
-        n = int(self.table.overflow.item())
-        if n:
-            self.table.overflow.zero_()
-            raise lib.HoicError(f"f16x3 GEMM path: {n} tensor(s) exceeded the float16 range under their delayed scale exponent; "
-                                "the update is not valid (use update_dtype='f32')")
+        self.post_overflow(); self.wait_overflow()
 
 
 def action_head(hidden, weight, bias, std=None, eps=None, out=None):
@@ -664,8 +692,13 @@ class TiledForward:
                 A, sa = self.HT[i], self.SLOT_H0 + i
         return self.out
 
+    _OVERFLOW_MSG = "tiled forward: {n} hidden activation tensor(s) exceeded the float16 range under their delayed exponent"
+
+    def post_overflow(self):
+        return _post_overflow(self)
+
+    def wait_overflow(self):
+        return _wait_overflow(self)
+
     def check_overflow(self):
-        n = int(self.table.overflow.item())
-        if n:
-            self.table.overflow.zero_()
-            raise lib.HoicError(f"tiled forward: {n} hidden activation tensor(s) exceeded the float16 range under their delayed exponent")
+        self.post_overflow(); self.wait_overflow()

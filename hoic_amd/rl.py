@@ -124,7 +124,7 @@ def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, di
             prev_v = values[t]
         returns = values + adv
     if valid is None:
-        a, cnt = adv, torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)
+        a, cnt = adv, torch.full((), float(adv.numel()), device=adv.device, dtype=adv.dtype)       # (a fill, not a host-to-device copy)
     else:
         a, cnt = torch.where(valid, adv, torch.zeros_like(adv)), valid.sum().to(adv.dtype)
     s = torch.stack([a.sum(), (a * a).sum(), cnt])

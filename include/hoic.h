@@ -70,6 +70,11 @@ const char* hoic_build_id(void);
 
 int32_t hoic_set_config(hoic_sim* s, const hoic_env_config* cfg);
 int32_t hoic_set_reward_params(hoic_sim* s, const hoic_reward_params* rp);
+/* The same refresh ordered on a HIP stream instead of behind a device synchronisation: launches enqueued on (or ordered
+ * behind) `stream` after the call see the new parameters, earlier ones the old; the host does not wait.  For a training
+ * loop that enqueues iteration k+1's rollout while the GPU still runs iteration k's update (agent_handmimic.py:311-336
+ * makes the same refresh once per epoch, between the two). */
+int32_t hoic_set_reward_params_async(hoic_sim* s, const hoic_reward_params* rp, void* stream);
 int32_t hoic_set_mode(hoic_sim* s, int32_t train); /* set_mode('train'|'test'), ho_im4.py:132 */
 
 /* ---- expert motions: set_expert for every sequence at once (ho_im4.py:135; arrays are the output of

@@ -115,6 +115,7 @@ static void free_expert(ho_expert* x) {
 }
 void hoo_env_set_pd_ref_offset(ho_env* e, int off) { e->cfg.pd_ref_offset = off; }
 void hoo_env_set_mesh_single_contact(ho_env* e, int on) { e->m.mesh_single_contact = on ? 1 : 0; }
+void hoo_env_set_obb_reject(ho_env* e, int on) { e->m.no_obb_reject = on ? 0 : 1; }     /* default on (ho_sim.c ho_collision) */
 void hoo_env_destroy(ho_env* e) { if (e) { free_expert(&e->e); free(e); } }
 
 void hoo_env_set_cfg(ho_env* e, const double* jkp, const double* jkd, const double* torque_lim,

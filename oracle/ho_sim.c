@@ -153,6 +153,14 @@ int ho_model_load(ho_model* m, const void* blob, size_t nbytes) {
   LF("pair_margin", m->pair_margin); LF("pair_gap", m->pair_gap);
   LI("mesh_vertadr", m->mesh_vertadr); LI("mesh_vertnum", m->mesh_vertnum); LF("mesh_vert", m->mesh_vert);
   LI("mesh_planeadr", m->mesh_planeadr); LI("mesh_planenum", m->mesh_planenum); LF("mesh_plane", m->mesh_plane);
+  for (int i = 0; i < m->nmesh && i < HOIC_MAX_MESH; i++) {
+    for (int k = 0; k < 3; k++) { m->mesh_aabb[i][k] = 1e300; m->mesh_aabb[i][3 + k] = -1e300; }
+    for (int v = m->mesh_vertadr[i]; v < m->mesh_vertadr[i] + m->mesh_vertnum[i]; v++)
+      for (int k = 0; k < 3; k++) {
+        if (m->mesh_vert[v][k] < m->mesh_aabb[i][k]) m->mesh_aabb[i][k] = m->mesh_vert[v][k];
+        if (m->mesh_vert[v][k] > m->mesh_aabb[i][3 + k]) m->mesh_aabb[i][3 + k] = m->mesh_vert[v][k];
+      }
+  }
   LI1("hand_body0", m->hand_body0); LI1("hand_nbody", m->hand_nbody); LI1("obj_body", m->obj_body);
   LI1("hand_geom0", m->hand_geom0); LI1("hand_geom1", m->hand_geom1);
   LI1("obj_geom0", m->obj_geom0); LI1("obj_geom1", m->obj_geom1);
@@ -372,6 +380,34 @@ void ho_apply_ft(const ho_model* m, const ho_data* d, const double f[3], const d
     for (int k = 0; k < 3; k++) qfrc[i] += jp[k * nv + i] * f[k] + jr[k * nv + i] * t[k];
 }
 
+/* Separating-axis test of two oriented boxes, all 15 axes: 1 = along one of them the boxes are more than `gap` apart.
+ * Box A: centre pa + Ra ca, axes = columns of Ra, half sizes a; box B: centre pb, axes = columns of Rb, half sizes b. */
+static int obb_separated(const double pa[3], const double Ra[9], const double ca[3], const double a[3],
+                         const double pb[3], const double Rb[9], const double b[3], double gap) {
+  double R[3][3], Q[3][3], t[3], d[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  for (int i = 0; i < 3; i++) {
+    t[i] = d[0] * Ra[i] + d[1] * Ra[3 + i] + d[2] * Ra[6 + i] - ca[i];
+    for (int j = 0; j < 3; j++) { R[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]; Q[i][j] = fabs(R[i][j]) + 1e-6; }
+  }
+  const double g = gap + 1e-6;
+  for (int i = 0; i < 3; i++) {
+    if (fabs(t[i]) > (a[i] + b[0] * Q[i][0] + b[1] * Q[i][1] + b[2] * Q[i][2] + g) * 1.00001) return 1;
+    if (fabs(t[0] * R[0][i] + t[1] * R[1][i] + t[2] * R[2][i]) > (b[i] + a[0] * Q[0][i] + a[1] * Q[1][i] + a[2] * Q[2][i] + g) * 1.00001) return 1;
+  }
+  for (int i = 0; i < 3; i++) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    for (int j = 0; j < 3; j++) {
+      int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      if (fabs(t[i2] * R[i1][j] - t[i1] * R[i2][j]) > (a[i1] * Q[i2][j] + a[i2] * Q[i1][j] + b[j1] * Q[i][j2] + b[j2] * Q[i][j1] + g) * 1.00001) return 1;
+    }
+  }
+  return 0;
+}
+
+/* test hook (tests/test_oracle_physics.py checks the test against sampled box-box distances) */
+int hoo_obb_separated(const double* pa, const double* Ra, const double* ca, const double* a, const double* pb, const double* Rb,
+                      const double* b, double gap) { return obb_separated(pa, Ra, ca, a, pb, Rb, b, gap); }
+
 /* ------------------------------------------------------------------ collision driver */
 void ho_collision(const ho_model* m, ho_data* d) {
   d->ncon = 0;
@@ -384,6 +420,25 @@ void ho_collision(const ho_model* m, ho_data* d) {
       for (int i = 0; i < 3; i++) dv[i] = d->geom_xpos[g1][i] - d->geom_xpos[g2][i];
       double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
       if (ho_dot3(dv, dv) > bound * bound) continue;
+      /* bounding-box rejection: both geoms as oriented boxes (a capsule inside r x r x (l + r) along its axis, a hull
+       * inside its bounding box in the mesh frame), 15-axis separating-axis test with the pair's margin.  A pair it drops
+       * is farther apart than the margin, so the exact routines (box, capsule) return nothing for it anyway; the hull
+       * routines' max-over-face-planes distance under-estimates next to sharp hull vertices (ho_collide.c) and can report
+       * a shallow contact for such a pair -- with this test it does not, which is what a geometric collider (the
+       * reference's libccd) gives.  Same test, same constants, in the kernel (hoic_collide.h obb_separated). */
+      int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+      if (!m->no_obb_reject && (t1 == HOIC_GEOM_CAPSULE || t1 == HOIC_GEOM_BOX) &&
+          (t2 == HOIC_GEOM_CAPSULE || t2 == HOIC_GEOM_BOX || t2 == HOIC_GEOM_MESH)) {
+        const double *z1 = m->geom_size[g1], *z2 = m->geom_size[g2];
+        double h1[3] = {z1[0], t1 == HOIC_GEOM_CAPSULE ? z1[0] : z1[1], t1 == HOIC_GEOM_CAPSULE ? z1[1] + z1[0] : z1[2]};
+        double h2[3] = {z2[0], t2 == HOIC_GEOM_CAPSULE ? z2[0] : z2[1], t2 == HOIC_GEOM_CAPSULE ? z2[1] + z2[0] : z2[2]};
+        double c2[3] = {0, 0, 0};
+        if (t2 == HOIC_GEOM_MESH) {
+          const double* bb = m->mesh_aabb[m->geom_meshid[g2]];
+          for (int i = 0; i < 3; i++) { c2[i] = 0.5 * (bb[i] + bb[3 + i]); h2[i] = 0.5 * (bb[3 + i] - bb[i]); }
+        }
+        if (obb_separated(d->geom_xpos[g2], d->geom_xmat[g2], c2, h2, d->geom_xpos[g1], d->geom_xmat[g1], h1, margin)) continue;
+      }
     }
     ho_contact tmp[8];
     int n = ho_collide_pair(m, d, p, tmp, 8);

@@ -47,6 +47,7 @@ def lib():
         L.hoo_env_set_expert.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
         L.hoo_env_set_pd_ref_offset.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_set_mesh_single_contact.argtypes = [C.c_void_p, C.c_int]
+        L.hoo_env_set_obb_reject.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hoo_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hoo_env_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -139,6 +140,10 @@ class OracleEnv:
     def set_mesh_single_contact(self, on: bool):
         """keep only the deepest contact of a convex-mesh pair (MuJoCo's contact count for mesh pairs)"""
         self.L.hoo_env_set_mesh_single_contact(self.h, int(bool(on)))
+
+    def set_obb_reject(self, on: bool):
+        """the collision driver's bounding-box rejection (ho_sim.c ho_collision; default on)"""
+        self.L.hoo_env_set_obb_reject(self.h, int(bool(on)))
 
     def set_expert(self, ex: dict):
         T = ex["hand_dof_seq"].shape[0]

@@ -861,6 +861,45 @@ def test_async_reward_matches_the_default_step(box_blob, setup):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
+def test_obb_reject_only_drops_contacts_of_separated_pairs(obj, monkeypatch):
+    """The collision driver's oriented-box rejection (hoic_collide.h obb_separated; the oracle's driver has the same test,
+    tests/test_oracle_physics.py): against a simulator built without it (HOIC_NO_OBB_REJECT=1) the contact list of a forward
+    pass is the same list minus, rarely, shallow hull contacts of pairs whose bounding boxes are apart (banana tip) -- never
+    a contact more, never a capsule / box contact less; Box and Bottle lists are identical."""
+    blob, cfg, ex, thresh = _obj_setup(obj)
+    N = 1536
+    a_sim = _sim(blob, N, cfg, ex, thresh)
+    monkeypatch.setenv("HOIC_NO_OBB_REJECT", "1")
+    b_sim = _sim(blob, N, cfg, ex, thresh)
+    monkeypatch.delenv("HOIC_NO_OBB_REJECT")
+    rng = np.random.default_rng(1)
+    qs = []
+    for i in range(N):
+        e = ex[i % 4]; f = int(rng.integers(0, 400))
+        q = np.concatenate([e["hand_dof_seq"][f], e["obj_pose_seq"][f]]); q[:26] += rng.normal(size=26) * 0.05
+        if i % 2:       # arbitrary object orientation next to the palm
+            qq = rng.normal(size=4); q[29:33] = qq / np.linalg.norm(qq); q[26:29] = q[:3] + rng.normal(size=3) * 0.04 + [0, 0.04, -0.05]
+        qs.append(q)
+    qs = np.array(qs); vs = np.zeros((N, 32))
+    oa = a_sim.probe_forward(qs, vs); ob = b_sim.probe_forward(qs, vs)
+    og0 = a_sim.model.scalar("obj_geom0")
+    gt = a_sim.model.arrays["geom_type"]
+    tot = dropped = 0
+    for i in range(N):
+        ca = {tuple(r) for r in oa["contacts"][i][:oa["ncon"][i]]}; cb = {tuple(r) for r in ob["contacts"][i][:ob["ncon"][i]]}
+        assert ca <= cb, i
+        tot += len(cb)
+        for r in cb - ca:
+            dropped += 1
+            assert gt[int(r[14])] == 7 and int(r[14]) >= og0 and -0.004 < r[0] < 0, r
+    print(f"{obj}: {tot} contacts, {dropped} dropped by the rejection")
+    assert tot > 3000 and dropped <= 0.002 * tot
+    if obj != "banana":
+        assert dropped == 0
+    a_sim.close(); b_sim.close()
+
+
 @pytest.mark.parametrize("obj", ["bottle", "banana"])
 def test_mesh_pruning_changes_no_contact(obj, monkeypatch):
     """The convex-mesh narrow phase skips the runs of hull vertices / faces that a query cannot touch (bounding spheres,
@@ -891,7 +930,7 @@ def test_mesh_pruning_changes_no_contact(obj, monkeypatch):
     cc = oa["contacts"]
     mesh_c = (cc[:, :, 14] >= og0) & (cc[:, :, 14] <= og1) & (cc[:, :, 15] > 0)
     hand_mesh = mesh_c & (cc[:, :, 13] >= a_sim.model.scalar("hand_geom0"))
-    print(f"{obj}: {int(mesh_c.sum())} mesh contacts in {int(mesh_c.any(1).sum())} of {N} states, {int(hand_mesh.sum())} of them hand-mesh")
+    print(f"{obj}: {int(mesh_c.sum())} object contacts in {int(mesh_c.any(1).sum())} of {N} states, {int(hand_mesh.sum())} of them hand-object")
     assert mesh_c.any(1).sum() > N // 3 and hand_mesh.sum() > 20
     g = torch.Generator().manual_seed(4)
     seq = torch.randint(0, len(ex), (N,), generator=g, dtype=torch.int32); start = torch.randint(0, 300, (N,), generator=g, dtype=torch.int32)
