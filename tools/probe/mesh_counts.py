@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import torch
 from hoic_amd import lib, mjcf, motions
 from hoic_amd.config import Config
-lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), os.environ.get("HOIC_LIB", "libhoic_colprof.so"))
+lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), os.environ.get("HOIC_LIB", "libhoic_colcnt.so"))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 OBJ = sys.argv[2] if len(sys.argv) > 2 else 'bottle'
 blob = open(mjcf.packaged_model_path(OBJ), 'rb').read()
@@ -20,7 +20,7 @@ g = torch.Generator().manual_seed(0)
 seq = torch.randint(0, 16, (N,), generator=g, dtype=torch.int32); start = torch.randint(0, 400, (N,), generator=g, dtype=torch.int32)
 sim.reset(seq, start)
 def cnt():
-    b = (C.c_ulonglong * 8)(); sim.L.hoicdbg_cnt(b); return np.array(b[:], dtype=np.float64)
+    b = (C.c_ulonglong * 16)(); sim.L.hoicdbg_cnt(b); return np.array(b[:], dtype=np.float64)
 steps = 8
 c0 = None
 for t in range(steps):
@@ -29,5 +29,5 @@ for t in range(steps):
     ns = torch.randint(0, 16, (N,), generator=g, dtype=torch.int32); nst = torch.randint(0, 400, (N,), generator=g, dtype=torch.int32)
     sim.step(a, ns, nst)
 d = (cnt() - c0) / ((steps - 2) * N * 15)
-for n, v in zip(['mesh pair turns', 'hull_max calls', '  streaming form', '  pruned: candidate passes', 'capsule-mesh', 'box-mesh', 'plane-mesh', 'turns with a contact'], d):
+for n, v in zip(['mesh pair turns', 'hull_max calls', '  streaming form', '  pruned: candidate passes', 'capsule-mesh', 'box-mesh', 'plane-mesh', 'turns with a contact', 'capsule-box routine runs', 'capsule-capsule routine runs', 'plane-box routine runs', 'plane-capsule routine runs', 'capsule-box lanes', 'capsule-capsule lanes', '-', '-'], d):
     print(f'{n:28s} {v:8.3f} per env and substep')
