@@ -97,15 +97,26 @@ def main(argv=None):
     n_envs = args.num_threads if args.sample_mode == "episodes" else args.n_envs
     agent = AgentHandMimic(cfg, torch.float32, device, training=True, checkpoint_epoch=args.epoch, n_envs=n_envs, model=model,
                            expert_seqs=expert, distributed=world > 1, update_dtype=args.update_dtype, sample_mode=args.sample_mode)
+    def log_line(i_iter, info, t_total):                 # the reference's log line (agent_handmimic.py:286-293)
+        log = info["log"]
+        print(f"{i_iter}\tT_sample {info['T_sample']:.2f}\tT_update {info['T_update']:.2f}\tT_total {t_total:.2f}\t"
+              f"eps_len {log.avg_episode_len:.2f}\tavg_rwd {log.avg_c_reward:.4f}\tsteps {log.num_steps}"
+              + (f"\teval {info['log_eval']}" if "log_eval" in info else ""), flush=True)
+
+    # The agent's host runs one phase ahead of the GPU (optimize_policy returns while the update it enqueued is still running), and
+    # an iteration's T_sample / T_update are GPU-timeline durations that exist when that update has finished: the line of
+    # iteration i is printed after iteration i + 1 has been enqueued, so that printing never makes the GPU wait for the host.
+    pending = None
     for i_iter in range(args.epoch, cfg.num_epoch):
         t0 = time.time()
         info = agent.optimize_policy(i_iter)
-        if rank == 0:                                    # the reference's log line (agent_handmimic.py:286-293)
-            log = info["log"]
-            print(f"{i_iter}\tT_sample {info['T_sample']:.2f}\tT_update {info['T_update']:.2f}\tT_total {time.time() - t0:.2f}\t"
-                  f"eps_len {log.avg_episode_len:.2f}\tavg_rwd {log.avg_c_reward:.4f}\tsteps {log.num_steps}"
-                  + (f"\teval {info['log_eval']}" if "log_eval" in info else ""), flush=True)
+        if rank == 0 and pending is not None:
+            log_line(*pending)
+        pending = (i_iter, info, time.time() - t0)
+    agent.learner.finish_update()                        # the last update's f16-range check
     if rank == 0:
+        if pending is not None:
+            log_line(*pending)
         print("training done!")
     if world > 1:
         torch.distributed.destroy_process_group()
