@@ -565,9 +565,7 @@ class AgentHandMimic:
             return build(stats.cpu().numpy(), c_info.cpu().numpy())
         # the host runs ahead: copy into pinned memory behind the reductions, wait for that copy only (PendingLog)
         both = torch.cat([stats, c_info])
-        if getattr(self, "_log_host", None) is None or self._log_host.shape != both.shape:
-            self._log_host = torch.empty(both.shape, dtype=both.dtype).pin_memory()
-        host = self._log_host
+        host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)      # (its own buffer: a log may be read after the next rollout was enqueued)
         host.copy_(both, non_blocking=True)
         ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
         return PendingLog(ev, lambda: build(host[:4].numpy().copy(), host[4:].numpy().copy()))

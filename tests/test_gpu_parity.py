@@ -694,6 +694,37 @@ def test_rollout_filter_forks_are_ordered_before_the_side_streams(box_blob, setu
     assert float(outs[0][1]) == 2 * 64 * 6
 
 
+def test_host_run_ahead_changes_no_number(box_blob, setup):
+    """optimize_policy with the host one phase ahead of the GPU (rollout and update enqueued back to back, the reward-parameter
+    refresh as a stream-ordered kernel, one wait per iteration for the rollout's statistics, range checks read one phase late)
+    makes the launches of the drained loop in the same order on the same streams: parameters, filter, logger statistics and the
+    end bonus the next rollout uses are bit-identical after four iterations; the run-ahead timings are GPU-timeline durations."""
+    _, ex, _ = setup
+    outs = []
+    for ahead in (False, True):
+        torch.manual_seed(5)
+        agent = _small_agent(ex, 128, 128 * 6, seed=3)
+        agent.n_groups = 2
+        agent.run_ahead = ahead; agent.learner.defer_checks = ahead
+        torch.manual_seed(11)
+        logs = []
+        for it in range(4):
+            info = agent.optimize_policy(it, save_model=False)
+            logs.append((info["log"].avg_c_reward, info["log"].num_episodes, float(agent.env.end_reward)))
+        assert info["T_sample"] > 0 and info["T_update"] > 0
+        if ahead:
+            assert abs(info["T_total"] - info["T_sample"] - info["T_update"]) < 1e-9
+        agent.learner.finish_update(); torch.cuda.synchronize()
+        pars = [p.detach().clone() for p in list(agent.policy_net.parameters()) + list(agent.value_net.parameters())]
+        outs.append((logs, pars, agent.running_state.mean.clone(), agent.running_state.S.clone(), float(agent.env.pushed_end_reward)))
+        agent.env.close()
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3]) and outs[0][4] == outs[1][4]
+    assert outs[0][4] > 0           # the end bonus of the last rollout came from the statistics of the one before it
+
+
 def test_sample_episodes_mode_is_the_reference_batch(box_blob, setup):
     """sample_mode='episodes' (sample_process, agent_handmimic.py:430-501): every env collects whole episodes until it
     holds floor(min_batch / n_envs) steps; every episode in the batch is complete, nothing is bootstrapped."""
