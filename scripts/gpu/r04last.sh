@@ -1,0 +1,2 @@
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
