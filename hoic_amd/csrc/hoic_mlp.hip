@@ -631,10 +631,10 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
 
 // ---------------------------------------------------------------------------------------------- rollout forward
 // The policy's forward pass DURING the rollout runs next to the simulator's substep kernel, whose workgroups hold every
-// CU's LDS (8 x 19.98 KB) and 384 of a SIMD's 512 registers: a GEMM whose workgroups need LDS queues behind them (the
-// hipBLASLt float32 GEMMs of the 2048-row batches took 6 ms of a 36 ms rollout that way).  This kernel needs NO LDS and
-// <= 128 registers, so its wavefronts start at once as a third wavefront per SIMD: operands go from L2 straight into MFMA
-// registers, which asks for a layout in which a wavefront's operand load is one contiguous kilobyte --
+// CU's LDS (12 x 12.5 KB) and, with two of its wavefronts on a SIMD, 336 of the 512 registers: a GEMM whose workgroups need LDS
+// queues behind them (the hipBLASLt float32 GEMMs of the 2048-row batches took 6 ms of a 36 ms rollout that way).  This kernel
+// needs NO LDS and 152 registers (the room beside two substep wavefronts is 176), so its wavefronts start at once as a third
+// wavefront per SIMD: operands go from L2 straight into MFMA registers, which asks for a layout in which a wavefront's operand load is one contiguous kilobyte --
 // "tiled" format T of a matrix [R x K]: tile (a, s) = rows 32 a .. + 31, k = 16 s .. + 15, 2 KB at ((a K/16 + s) * 2048):
 //   hi plane [64 lanes x 16 B], then lo plane; lane = 32 hf + l31 holds row 32 a + l31, k = 16 s + 8 hf .. + 7.
 // One wavefront per workgroup computes 32 rows (m) x 64 columns (n): D = W X^T per tile, i.e. lane = row m, registers =
@@ -669,7 +669,7 @@ struct FwdArgs {
   float* outF;                       // float32 row-major [M x N] (last layer)
 };
 template <bool LAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void hoic_fwd_tiled_kernel(FwdArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(168))) void hoic_fwd_tiled_kernel(FwdArgs a) {
   const int lane = threadIdx.x, l31 = lane & 31, hf = lane >> 5;
   const int ksteps = a.K >> 4, nt2 = a.N >> 6;
   const int mt = blockIdx.x / nt2, n2 = blockIdx.x % nt2;          // 32-row tile, pair of 32-column tiles
@@ -694,15 +694,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void hoic
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.xh, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.xh, acc1, 0, 0, 0);
   };
-  Fr f0, f1;
-  ld(0, f0);
+  // three register sets: the loads of step t + 2 are issued before the MFMAs of step t, so an operand has two steps' MFMAs
+  // (~400 cycles) to arrive from L2 (with two sets a step waited for most of its loads' latency: the kernel ran at a fifth of
+  // its MFMA bound); a step past the end re-reads the last stage
+  Fr f0, f1, f2;
+  const int last = ksteps - 1;
+  ld(0, f0); ld(min(1, last), f1);
   int st = 0;
-  for (; st + 2 <= ksteps - 1; st += 2) {       // two register sets: the next step's six loads fly under this step's MFMAs
-    ld(st + 1, f1); mm(f0);
-    ld(st + 2, f0); mm(f1);
+  for (; st + 3 <= ksteps; st += 3) {
+    ld(min(st + 2, last), f2); mm(f0);
+    ld(min(st + 3, last), f0); mm(f1);
+    ld(min(st + 4, last), f1); mm(f2);
   }
-  if (st + 1 < ksteps) { ld(st + 1, f1); mm(f0); mm(f1); }
-  else mm(f0);
+  if (st < ksteps) mm(f0);
+  if (st + 1 < ksteps) mm(f1);
   // ---- epilogue
   const int ex = a.exps ? a.exps[a.ex] : 0, ew = a.exps ? a.exps[a.ew] : 0;
   const float alpha = ldexpf(1.f, -(ex + ew));
