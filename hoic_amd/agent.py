@@ -440,8 +440,9 @@ class AgentHandMimic:
         # observation filter during sampling: "online" = every step's observations update it before they are normalised (the
         # reference's ZFilter updates row by row inside its sampler, zfilter.py:59-73); "frozen" = a rollout is normalised with
         # the statistics of the iterations before it and its valid observations are merged afterwards (what a sampler that
-        # ships the statistics to its workers once per iteration does: tools/reward_curve.py's CPU arms) -- whole-episode mode
-        # only, a switch for attributing reward-curve differences, not a product mode
+        # ships the statistics to its workers once per iteration does: tools/reward_curve.py's CPU arms) -- in both sampling
+        # modes a switch for attributing reward-curve differences, not a product mode (it reads the filter's count on the
+        # host once per rollout and keeps the rollout's raw observations)
         assert filter_mode in ("online", "frozen")
         self.filter_mode = filter_mode
         self.start_min = int(start_min)      # episodes start at frame >= start_min (benchmark workloads; the reference draws from 0)
@@ -486,7 +487,7 @@ class AgentHandMimic:
         # run_ahead: optimize_policy enqueues rollout and update back to back and waits for the rollout's statistics only (the
         # fixed-horizon sampler on the GPU; see optimize_policy).  Off = every phase is drained before the next is enqueued.
         self.run_ahead = (bool(run_ahead) and self.device.type == "cuda" and sample_mode == "fixed"
-                          and not self.learner.overlap_value_update and not os.environ.get("HOIC_NO_RUN_AHEAD"))
+                          and not self.learner.overlap_value_update)
         self.learner.defer_checks = self.run_ahead
         self.policy_net, self.value_net = self.learner.policy_net, self.learner.value_net
         self.optimizer_policy, self.optimizer_value = self.learner.optimizer_policy, self.learner.optimizer_value
@@ -631,14 +632,17 @@ class AgentHandMimic:
         # chains (with a shared filter every range's update waited for the previous range's: a convoy).
         # The forks are made on the main stream BEFORE the side streams take their wait point on it: a fork's state is
         # the first thing a range's chain reads.
-        racy = bool(os.environ.get("HOIC_FORK_AFTER_WAIT"))      # attribution switch only (tools/reward_curve.py "+racy"): round 3's order
-        forks = [self.running_state.fork() for _ in groups] if (use_streams and not racy) else None
+        # filter_mode="frozen" (attribution arm): the rollout is normalised with the statistics of the iterations before it
+        # -- identity (mean 0, std 1) while nothing was seen -- and its raw observations are pushed afterwards, exactly what
+        # tools/reward_curve.py's cpu_fixed arm does; no forks: nothing updates the filter inside the rollout
+        frozen = self.filter_mode == "frozen"
+        identity = frozen and float(self.running_state.n) == 0
+        raw_all = torch.empty(T, N, self.state_dim, device=dev, dtype=torch.float32) if frozen else None
+        forks = [self.running_state.fork() for _ in groups] if (use_streams and not frozen) else None
         if use_streams:
             main = torch.cuda.current_stream(dev)
             for st_ in self._streams:
                 st_.wait_stream(main)
-        if use_streams and racy:
-            forks = [self.running_state.fork() for _ in groups]
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
         async_reward = direct and self.async_reward
@@ -652,7 +656,12 @@ class AgentHandMimic:
                 sl = slice(first, first + count)
                 ctx = torch.cuda.stream(self._streams[gi]) if use_streams else contextlib.nullcontext()
                 with ctx:
-                    state = (forks[gi] if use_streams else self.running_state)(obs[sl], out=states[t, sl] if direct else None)
+                    if frozen:
+                        raw_all[t, sl] = obs[sl]
+                        state = (torch.clamp(obs[sl], -5.0, 5.0).to(dt) if identity else
+                                 self.running_state(obs[sl], update=False, out=states[t, sl] if direct else None))
+                    else:
+                        state = (forks[gi] if use_streams else self.running_state)(obs[sl], out=states[t, sl] if direct else None)
                     if state.data_ptr() != states[t, sl].data_ptr():
                         states[t, sl] = state
                     if direct:
@@ -678,7 +687,11 @@ class AgentHandMimic:
         if use_streams:
             for st_ in self._streams:
                 main.wait_stream(st_)
-            self.running_state.absorb(forks)
+            if not frozen:
+                self.running_state.absorb(forks)
+        if frozen:
+            self.running_state.push(raw_all.view(T * N, self.state_dim))       # the batch's own observations, after the rollout
+            del raw_all
         if async_reward:
             self.env.sim.set_async_reward(False)        # the main stream waits for every outstanding reward part
         done_all = flags_all[:, :, 2] != 0

@@ -30,6 +30,42 @@ def timeit(fn, reps, warm=2):
     return ts[len(ts) // 2]
 
 
+def calibrate(args):
+    """hipBLASLt (torch.mm on float16, float32 accumulation) at the f16x3 kernels' MFMA flop counts.  An f16x3 GEMM of
+    M x N x K issues 3 f16 MFMA products per multiply-add = the MFMA work of a plain f16 GEMM of M x N x 3K."""
+    import torch
+    dev = torch.device("cuda")
+    Mr = args.rows
+    res = {"rows": Mr, "what": "torch.mm(float16, float16) -> hipBLASLt, f32 accumulate; f16 dense peak 2500 TFLOP/s", "gemms": []}
+    g = torch.Generator(device=dev).manual_seed(0)
+    for (N, K, like) in ((1024, 6144, "2048->1024 f16x3 forward"), (2048, 1920, "640->2048 f16x3 forward"), (512, 3072, "1024->512 f16x3 forward"),
+                         (8192, 8192, "square reference")):
+        for zero in (False, True):
+            a = (torch.zeros(Mr, K, device=dev) if zero else torch.randn(Mr, K, device=dev, generator=g)).half()
+            b = (torch.zeros(K, N, device=dev) if zero else torch.randn(K, N, device=dev, generator=g) * 0.03).half()
+            bt = b.t().contiguous()                     # "NT": both operands K-contiguous, the layout the f16x3 kernels read
+            c = torch.empty(Mr, N, device=dev, dtype=torch.float16)
+            for name, f in (("nn", lambda: torch.mm(a, b, out=c)), ("nt", lambda: torch.mm(a, bt.t(), out=c))):
+                ms = timeit(f, args.reps, warm=3)
+                # sustained rate: 20 launches back to back (the clock settles under load)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    f()
+                e1.record(); e1.synchronize()
+                ms20 = e0.elapsed_time(e1) / 20
+                fl = 2.0 * Mr * N * K
+                row = {"like": like, "M": Mr, "N": N, "K": K, "layout": name, "operands": "zero" if zero else "random", "ms": ms, "ms_sustained": ms20,
+                       "tflops": fl / ms / 1e9, "tflops_sustained": fl / ms20 / 1e9, "frac_of_2500": fl / ms20 / 1e9 / 2500.0}
+                res["gemms"].append(row)
+                print(json.dumps(row), flush=True)
+            del a, b, bt, c
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=53248)
@@ -42,8 +78,13 @@ def main():
     ap.add_argument("--ops", default=None, help="comma list of the ops to time (default all)")
     ap.add_argument("--dims", default="640x2048,2048x1024,1024x512", help="KxN of the layers to time (multiples of 256)")
     ap.add_argument("--pipeline", type=int, default=3, help="3: the shipped form (D[m][n] epilogues, row-major weight gradients); 2: transposed-copy form")
+    ap.add_argument("--calibrate", action="store_true", help="what this chip sustains on the same f16 MFMA flop counts with the vendor "
+                    "library: hipBLASLt f16 GEMMs (f32 accumulate) of 53248 x 1024 x 6144 and 53248 x 2048 x 1920 -- the MFMA work of "
+                    "the 2048->1024 and 640->2048 f16x3 forwards -- on random and on all-zero operands (VERDICT r4 #2a)")
     args = ap.parse_args()
     import torch
+    if args.calibrate:
+        return calibrate(args)
     from hoic_amd import mlp as M
     dev = torch.device("cuda")
     M.set_pipeline(args.pipeline)

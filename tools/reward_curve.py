@@ -16,6 +16,7 @@ Arms
   hip_episodes_frozen hip_episodes with the observation filter handled as the CPU arms handle it: a rollout is normalised with
                  the statistics of the iterations before it (iteration 0: none, i.e. raw observations clipped at +-5) and its
                  observations are merged afterwards -- separates "filter order" from "simulator" in the cpu/hip gap
+  hip_fixed_f16x3_frozen hip_fixed_f16x3 with the CPU arms' filter handling (the matched control of cpu_fixed on the headline sampler)
   hip_fixed_long fixed horizon with 4x longer windows (envs / 4 environments): a diagnostic for the truncation length
 
 Every `--eval-every` iterations each run evaluates its current policy + observation filter with deterministic
@@ -319,18 +320,16 @@ def run_hip_arm(args, arm, seed):
     #   torchfwd  the rollout's policy forward in PyTorch float32 with its own N(0, 1) draw per step (no tiled f16x3 forward, no
     #             up-front noise tensor)
     #   autograd  the update's heads and losses through PyTorch autograd (no hoic_mlp_head / ppo_loss / value_loss kernels)
-    #   racy      round 3's fork order: the per-range filter forks are made AFTER the side streams' wait point
     base, *switches = arm.split("+")
     mode, n_envs = {"hip_fixed": ("fixed", args.envs), "hip_episodes": ("episodes", args.episode_workers),
                     "hip_episodes_frozen": ("episodes", args.episode_workers),
-                    "hip_fixed_long": ("fixed", max(args.envs // 4, 1)), "hip_fixed_f16x3": ("fixed", args.envs)}[base]
+                    "hip_fixed_long": ("fixed", max(args.envs // 4, 1)), "hip_fixed_f16x3": ("fixed", args.envs),
+                    "hip_fixed_f16x3_frozen": ("fixed", args.envs)}[base]
     if "autograd" in switches:
         from hoic_amd import mlp as _mlp
         _mlp.FORCE_AUTOGRAD_HEADS = True
-    if "racy" in switches:
-        os.environ["HOIC_FORK_AFTER_WAIT"] = "1"
     agent = AgentHandMimic(cfg, device=dev, n_envs=n_envs, model=args.obj, expert_seqs=expert, sample_mode=mode,
-                           update_dtype="f16x3" if base.endswith("f16x3") else "f32", filter_mode="frozen" if base.endswith("_frozen") else "online",
+                           update_dtype="f16x3" if "f16x3" in base else "f32", filter_mode="frozen" if base.endswith("_frozen") else "online",
                            n_groups=1 if "g1" in switches else None, rollout_forward="torch" if "torchfwd" in switches else "tiled")
     curve, evals = [], []
     t_start = time.time()
@@ -417,7 +416,7 @@ def main():
     common = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--eval-every", str(args.eval_every),
               "--workers", str(args.workers), "--slots", str(args.slots), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
     t0 = time.time()
-    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0].split("+")[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3")]
+    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0].split("+")[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3", "hip_fixed_f16x3_frozen")]
     procs = []
     for arm, seed in side:
         f = os.path.join(tmp, f"{arm}_{seed}.json")
@@ -448,7 +447,8 @@ def main():
                     "hip_episodes": "HIP simulator, whole-episode batches (sample_mode='episodes')",
                     "hip_episodes_frozen": "hip_episodes with the CPU arms' filter handling: statistics frozen during a rollout, merged after it",
                     "hip_fixed_long": "HIP simulator, fixed horizon, 4x fewer envs and 4x longer windows",
-                    "hip_fixed_f16x3": "hip_fixed with the PPO update's GEMMs on the f16x3 matrix-core path (what bench.py times)"},
+                    "hip_fixed_f16x3": "hip_fixed with the PPO update's GEMMs on the f16x3 matrix-core path (what bench.py times)",
+                    "hip_fixed_f16x3_frozen": "hip_fixed_f16x3 with the CPU arms' filter handling: statistics frozen during a rollout, merged after it"},
            "obj": args.obj, "iters": args.iters, "eval_every": args.eval_every, "workers": args.workers, "envs": args.envs,
            "episode_workers": args.episode_workers, "host_cores": os.cpu_count(), "wall_s": time.time() - t0,
            "bands": bands(runs), "runs": runs}
