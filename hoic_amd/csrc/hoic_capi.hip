@@ -64,9 +64,8 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   if (tid < NV) w.sc.vec.x[tid] = a0;           // a_smooth as an LDS vector for the first row evaluation (dead once Newton starts)
   wsync();
   RowK rk;
-  float aref_c[NCSLOT];
-  dev_make_constraint(m, w, rk, aref_c, w.qpos, w.qvel); PT(7);
-  dev_solve(m, w, M, rk, aref_c, fs, a0, cfg.c.solver_iterations); PT(9);
+  dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
+  dev_solve(m, w, M, rk, w.qvel, fs, a0, cfg.c.solver_iterations); PT(9);
   // mj_checkPos / mj_checkVel / mj_checkAcc [MJ-doc]: a non-finite or huge (> 1e10) entry of qpos, qvel or qacc is MuJoCo's
   // "Nan, Inf or huge value" warning, which mujoco_py raises and the env turns into fail = True (ho_im4.py:635-637)
   float bad = 0.f;
@@ -751,6 +750,9 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
   std::vector<double> impr;
   double impratio = 1.0;
   if (b.f64("impratio", impr) && !impr.empty()) impratio = impr[0];
+  m.jnt_poszero = 1;
+  for (int j = 0; j < m.njnt; j++)
+    if (m.jnt_type[j] != HOIC_JNT_FREE && (m.jnt_pos[j][0] != 0.f || m.jnt_pos[j][1] != 0.f || m.jnt_pos[j][2] != 0.f)) m.jnt_poszero = 0;
   // tree bookkeeping
   m.nlevel = 0;
   for (int i = 0; i < m.nbody; i++) m.nlevel = std::max(m.nlevel, m.body_depth[i]);

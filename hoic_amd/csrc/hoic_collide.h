@@ -61,16 +61,16 @@ HD void seg_seg_closest(const float* p1, const float* d1, const float* p2, const
   float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
   float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), s, t;
   if (a <= 1e-12f && e <= 1e-12f) { s_out = t_out = 0.f; return; }
-  if (a <= 1e-12f) { s = 0.f; t = fminf(fmaxf(f / e, 0.f), 1.f); }
+  if (a <= 1e-12f) { s = 0.f; t = fminf(fmaxf(fdiv(f, e), 0.f), 1.f); }
   else {
     float c = dot3(d1, r);
-    if (e <= 1e-12f) { t = 0.f; s = fminf(fmaxf(-c / a, 0.f), 1.f); }
+    if (e <= 1e-12f) { t = 0.f; s = fminf(fmaxf(fdiv(-c, a), 0.f), 1.f); }
     else {
       float b = dot3(d1, d2), den = a * e - b * b;
-      s = den > 1e-6f * a * e ? fminf(fmaxf((b * f - c * e) / den, 0.f), 1.f) : 0.5f;
-      t = (b * s + f) / e;
-      if (t < 0.f) { t = 0.f; s = fminf(fmaxf(-c / a, 0.f), 1.f); }
-      else if (t > 1.f) { t = 1.f; s = fminf(fmaxf((b - c) / a, 0.f), 1.f); }
+      s = den > 1e-6f * a * e ? fminf(fmaxf(fdiv(b * f - c * e, den), 0.f), 1.f) : 0.5f;
+      t = fdiv(b * s + f, e);
+      if (t < 0.f) { t = 0.f; s = fminf(fmaxf(fdiv(-c, a), 0.f), 1.f); }
+      else if (t > 1.f) { t = 1.f; s = fminf(fmaxf(fdiv(b - c, a), 0.f), 1.f); }
     }
   }
   s_out = s; t_out = t;
@@ -86,9 +86,9 @@ HD void col_capsule_capsule(const float* p1, const float* R1, const float* s1, c
   seg_seg_closest(q1, d1, q2, d2, s, t);
   for (int i = 0; i < 3; i++) { c1[i] = q1[i] + s * d1[i]; c2[i] = q2[i] + t * d2[i]; }
   float d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
-  float len = sqrtf(dot3(d, d)), dist = len - s1[0] - s2[0];
+  float len = fsqrt(dot3(d, d)), dist = len - s1[0] - s2[0];
   if (dist >= 0.f) return;
-  if (len < 1e-12f) { d[0] = 1.f; d[1] = d[2] = 0.f; } else { float inv = 1.f / len; d[0] *= inv; d[1] *= inv; d[2] *= inv; }
+  if (len < 1e-12f) { d[0] = 1.f; d[1] = d[2] = 0.f; } else { float inv = frcp(len); d[0] *= inv; d[1] *= inv; d[2] *= inv; }
   float pos[3];
   for (int i = 0; i < 3; i++) pos[i] = c1[i] + d[i] * (s1[0] + 0.5f * dist);
   lc_push(o, dist, pos, d);
@@ -104,10 +104,10 @@ HD bool sphere_box_local(const float* c, float r, const float* h, float& dist, f
     if (d[i] != 0.f) inside = false;
   }
   if (!inside) {
-    float len = sqrtf(dot3(d, d));
+    float len = fsqrt(dot3(d, d));
     dist = len - r;
     if (dist >= 0.f) return false;
-    float inv = 1.f / len;
+    float inv = frcp(len);
     for (int i = 0; i < 3; i++) { n[i] = -d[i] * inv; pos[i] = q[i] + d[i] * inv * 0.5f * dist; }
     return true;
   }
@@ -130,7 +130,7 @@ HD float seg_box_t(const float* a, const float* b, const float* h) {
       if (ex != 0.f) { g += 2.f * ex * v; hh += 2.f * v * v; }
     }
     if (g > 0.f) hi = t; else if (g < 0.f) lo = t; else break;
-    float tn = hh > 0.f ? t - g / hh : 0.5f * (lo + hi);
+    float tn = hh > 0.f ? t - fdiv(g, hh) : 0.5f * (lo + hi);
     if (tn <= lo || tn >= hi) tn = 0.5f * (lo + hi);
     if (fabsf(tn - t) < 1e-7f) { t = tn; break; }
     t = tn;
@@ -213,9 +213,9 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
     float Ai[3], Bj[3], L[3];
     sel3v(A, i, Ai); sel3v(B, j, Bj);
     cross3(Ai, Bj, L);
-    const float len = sqrtf(dot3(L, L));
+    const float len = fsqrt(dot3(L, L));
     if (len >= 1e-4f) {
-      const float inv = 1.f / len;
+      const float inv = frcp(len);
       for (int k = 0; k < 3; k++) L[k] *= inv;
       float ra = 0.f, rb = 0.f;
       for (int k = 0; k < 3; k++) { ra += ha[k] * fabsf(dot3(A[k], L)); rb += hb[k] * fabsf(dot3(B[k], L)); }
@@ -247,7 +247,7 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
     sel3v(A, i, Ai); sel3v(B, j, Bj);
     const float r[3] = {ea[0] - eb[0], ea[1] - eb[1], ea[2] - eb[2]};
     const float bdot = dot3(Ai, Bj), c1 = dot3(Ai, r), f1 = dot3(Bj, r), den = 1.f - bdot * bdot;
-    float u = den > 1e-6f ? (bdot * f1 - c1) / den : 0.f, v = f1 + bdot * u;
+    float u = den > 1e-6f ? fdiv(bdot * f1 - c1, den) : 0.f, v = f1 + bdot * u;
     const float hai = sel3(ha[0], ha[1], ha[2], i), hbj = sel3(hb[0], hb[1], hb[2], j);
     u = fminf(fmaxf(u, -hai), hai); v = fminf(fmaxf(v, -hbj), hbj);
     if (lane == 0) {
@@ -293,7 +293,7 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
   float gx = 0.f, gy = 0.f;
   if (fabsf(det) > 1e-12f) {
     const float dz1 = rl(vz, 1) - z_0, dz3 = rl(vz, 3) - z_0;
-    gx = (dz1 * m11 - dz3 * m01) / det; gy = (dz3 * m00 - dz1 * m10) / det;
+    const float idet = frcp(det); gx = (dz1 * m11 - dz3 * m01) * idet; gy = (dz3 * m00 - dz1 * m10) * idet;
   }
   const float z0 = z_0 - gx * p0x - gy * p0y;
   int n = 4;
@@ -312,7 +312,7 @@ __device__ __forceinline__ int col_box_box_wave(const float* pa, const float* Ra
     if (n == 0) return 0;
     if (e1) { polybuf[2 * pos] = px; polybuf[2 * pos + 1] = py; }
     if (e2) {
-      const float tt = da / (da - db);
+      const float tt = fdiv(da, da - db);
       polybuf[2 * (pos + (e1 ? 1 : 0))] = px + tt * (bx - px); polybuf[2 * (pos + (e1 ? 1 : 0)) + 1] = py + tt * (by - py);
     }
     wsync();
@@ -536,7 +536,7 @@ __device__ __forceinline__ int col_capsule_mesh_wave(const HullRef& h, const flo
     for (int i = 0; i < 4; i++) { pl_[i] = p0[i]; pr_[i] = p1[i]; }
     ts = 0.f; vs = v0;
     for (int it = 0; it < 8; it++) {
-      float t = ((vr - sr * tr) - (vl - sl * tl)) / (sl - sr);
+      float t = fdiv((vr - sr * tr) - (vl - sl * tl), sl - sr);
       t = fminf(fmaxf(t, tl), tr);
       const float v = hull_max_wave(h, a[0] + t * d[0], a[1] + t * d[1], a[2] + t * d[2], pm);
       const float lineval = vl + sl * (t - tl);
@@ -546,7 +546,7 @@ __device__ __forceinline__ int col_capsule_mesh_wave(const HullRef& h, const flo
       if (sm < 0.f) { tl = t; vl = v; sl = sm; for (int i = 0; i < 4; i++) pl_[i] = pm[i]; }
       else { tr = t; vr = v; sr = sm; for (int i = 0; i < 4; i++) pr_[i] = pm[i]; }
     }
-    const float lam = sr / (sr - sl);   // zero sub-gradient combination of the two tied faces
+    const float lam = fdiv(sr, sr - sl);   // zero sub-gradient combination of the two tied faces
     for (int i = 0; i < 3; i++) nmin[i] = lam * pl_[i] + (1.f - lam) * pr_[i];
     normalize3(nmin);
   }

@@ -53,6 +53,33 @@ template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[
   }
 }
 
+// the same gather for NX vectors at once (the Jacobian products of the solve's set-up: qvel, a_smooth and the warm start go
+// through the contact Jacobian together): one unpacking of the path and one read of S[d] serve all of them; per vector the
+// multiply-adds run in the order of path_gather, so every product is bit-identical to a separate pass
+template <int NX> HD void path_gather_multi(const Work& w, const unsigned (&path)[3], const float* const (&x)[NX], float (&V)[NX][6], bool second) {
+  const unsigned pk[3] = {path[0], path[1], path[2]};
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (h == 1) { __builtin_amdgcn_sched_barrier(0); if (!second) break; }
+#pragma unroll
+    for (int i = 6 * h; i < 6 * h + 6; i++) {
+      const unsigned e = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      const bool on = e != 0xFFu;
+      const int d = on ? (int)e : 0;
+      const float msk = on ? 1.f : 0.f;
+      float Sd[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) Sd[k] = w.S[d][k];
+#pragma unroll
+      for (int v = 0; v < NX; v++) {
+        const float xd = x[v][d] * msk;
+#pragma unroll
+        for (int k = 0; k < 6; k++) V[v][k] = fmaf(Sd[k], xd, V[v][k]);
+      }
+    }
+  }
+}
+
 // ---- kinematics: body frames, geoms, motion axes S, body inertias about the origin
 template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel& m, W& w, const float* q) {
   const int tid = opaque(threadIdx.x);
@@ -75,6 +102,7 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
   // 1. transform of each body relative to its parent, with the joint axes / anchors in the parent frame
   if (isb) {
     const int b = tid, ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+    const bool jz = m.jnt_poszero != 0;       // wave-uniform
     for (int i = 0; i < 3; i++) P[i] = m.body_pos[b][i];
     for (int i = 0; i < 4; i++) Q[i] = m.body_quat[b][i];
     for (int j = ja; j < ja + jn; j++) {
@@ -85,6 +113,21 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
         for (int i = 0; i < 3; i++) P[i] = q[qa + i];
         for (int i = 0; i < 4; i++) Q[i] = q[qa + 3 + i];
         normquat(Q);
+      } else if (jz) {
+        // joint at the body's origin (every joint of the HOIC hand): its anchor is the body position, which a rotation about it
+        // does not move -- the two rotations of the anchor offset drop out (they would rotate the zero vector: same results)
+        const float jax[3] = {r[0], r[1], r[2]};
+        float ax[3];
+        qrot(Q, jax, ax);
+        for (int i = 0; i < 3; i++) { w.sc.dyn.u.j.jax[j][i] = ax[i]; w.sc.dyn.u.j.janc[j][i] = P[i]; }
+        if (ty == HOIC_JNT_SLIDE) {
+          for (int i = 0; i < 3; i++) P[i] += ax[i] * r[6];
+        } else {
+          const float ql[4] = {r[6], r[7], r[8], r[9]};
+          float qn[4];
+          mulquat(Q, ql, qn);
+          for (int i = 0; i < 4; i++) Q[i] = qn[i];
+        }
       } else {
         const float jax[3] = {r[0], r[1], r[2]}, jps[3] = {r[3], r[4], r[5]};
         float ax[3], t[3], an[3];

@@ -57,7 +57,11 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
     rhs = -w.bias[d] - kp * err - kd * qv;
   }
   PT(20);
-  const float acc = dev_hsolve<false>(m, w, M, kd * dt, n, rhs);
+  // The solve runs on the whole 32 x 32 matrix, not on the leading hand block with an identity below it: the free object's
+  // dofs couple to no hand dof in M (different subtrees: those entries are exact zeros, build_model checks the structure), its
+  // own block is positive definite, and its right-hand side and diagonal shift are zero here -- the hand part of the solution
+  // is the same, entry by entry, and the 16 masked copies of the accumulator drop out.
+  const float acc = dev_hsolve<false>(m, w, M, kd * dt, (m.nv == NV && n == NV - 6) ? NV : n, rhs);
   if (tid < NV) {
     float tq = 0.f;
     if (tid < n) {

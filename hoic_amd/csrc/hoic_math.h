@@ -27,12 +27,20 @@ HD void cross3(const float* a, const float* b, float* o) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   o[0] = x; o[1] = y; o[2] = z;
 }
+// 1-ulp hardware reciprocal / square root / reciprocal square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32) where the simulator's
+// float32 arithmetic does not need the correctly rounded forms: an IEEE division is ~10 instructions (v_div_scale x2, v_rcp,
+// four fmas, v_div_fmas, v_div_fixup), an IEEE sqrtf ~14; the parity bounds against the float64 oracle are 1e-4 .. 1e-6.
+// (The hardware forms flush denormal arguments: the guards below test against 1e-36, not 1e-40.)
+HD float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+HD float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+HD float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+HD float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 HD float normalize3(float* a) {
-  float n = sqrtf(dot3(a, a));
-  if (n < 1e-20f) { a[0] = 1.f; a[1] = 0.f; a[2] = 0.f; return 0.f; }
-  float inv = 1.f / n;
+  const float n2 = dot3(a, a);
+  if (n2 < 1e-36f) { a[0] = 1.f; a[1] = 0.f; a[2] = 0.f; return 0.f; }
+  const float inv = frsq(n2);
   a[0] *= inv; a[1] *= inv; a[2] *= inv;
-  return n;
+  return n2 * inv;
 }
 HD void quat2mat(const float* q, float* R) {
   float w = q[0], x = q[1], y = q[2], z = q[3];
@@ -48,9 +56,9 @@ HD void mulquat(const float* a, const float* b, float* o) {
   o[0] = w; o[1] = x; o[2] = y; o[3] = z;
 }
 HD void normquat(float* q) {
-  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < 1e-20f) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; return; }
-  float inv = 1.f / n;
+  const float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (n2 < 1e-36f) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; return; }
+  const float inv = frsq(n2);
   q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 // rotate v by the unit quaternion q:  v + 2 w (u x v) + 2 u x (u x v)

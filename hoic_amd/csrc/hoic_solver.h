@@ -206,7 +206,7 @@ HD float dev_impedance(const float* s_in, float pos, float margin) {
   float s0 = fminf(fmaxf(s_in[0], 0.0001f), 0.9999f), s1 = fminf(fmaxf(s_in[1], 0.0001f), 0.9999f);
   float wdt = fmaxf(s_in[2], 0.f), mid = fminf(fmaxf(s_in[3], 0.0001f), 0.9999f), pw = fmaxf(s_in[4], 1.f);
   if (s0 == s1 || wdt <= MINVALF) return 0.5f * (s0 + s1);
-  float x = fabsf((pos - margin) / wdt);
+  float x = fabsf(fdiv(pos - margin, wdt));
   if (x >= 1.f) return s1;
   if (x <= 0.f) return s0;
   // both branches of the power sigmoid are base^pw / bm^(pw-1) of a mirrored argument; base and bm lie in (0, 1],
@@ -258,12 +258,52 @@ __device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const 
 }
 
 // J_r . x for contact row r (u must hold dev_basis_dot(x))
-HD float dev_crow_times(const Work& w, int r) {
+HD float dev_crow_times(const Work& w, const float* u, int r) {
   const int ce = w.cr_ce[r], c = ce >> 3, e = ce & 7;
-  const float un = w.u[c * 4];
+  const float un = u[c * 4];
   if (w.c_nrow[c] == 1) return un;
   const int k = e >> 1;
-  return un + ((e & 1) ? -1.f : 1.f) * w.c_mu[c][k] * w.u[c * 4 + 1 + k];
+  return un + ((e & 1) ? -1.f : 1.f) * w.c_mu[c][k] * u[c * 4 + 1 + k];
+}
+HD float dev_crow_times(const Work& w, int r) { return dev_crow_times(w, w.u, r); }
+
+// ---- the three Jacobian products of the solve's set-up in ONE pass: u[v][c][k] = (contact-frame Jacobian row k of contact c) .
+// x_v for x = (qvel, a_smooth, warm start).  Separately (dev_basis_dot once in dev_make_constraint and twice in the warm-start
+// choice) each pass paid its own path unpacking, reads of S, contact-frame reads and two hand-over points; per vector the
+// arithmetic is that of dev_basis_dot, in the same order (bit-identical products).  Buffers: sc.mv (the solves' scratch, dead here).
+__device__ __forceinline__ void dev_basis_dot3(const DevModel& m, Work& w, const float* x0, const float* x1, const float* x2) {
+  const int tid = opaque(threadIdx.x);
+  if (w.ncon == 0) return;
+  const unsigned cb = w.cbod;
+  if (tid < m.nbody && ((cb >> tid) & 1u)) {
+    float V[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
+    const float* const xs[3] = {x0, x1, x2};
+    path_gather_multi<3>(w, bp, xs, V, (cb >> 31) != 0u);
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+      for (int i = 0; i < 6; i++) w.sc.mv.bV[v][tid][i] = V[v][i];
+  }
+  wsync();
+  const int nb = w.ncon * 4;
+  for (int t = tid; t < nb; t += NT) {
+    const int c = t >> 2, k = t & 3;
+    const int b1 = w.c_b1[c], b2 = w.c_b2[c];
+    float fr[3], fn[3], cp[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { fr[i] = w.c_frame[c][3 * (k < 3 ? k : 0) + i]; fn[i] = w.c_frame[c][i]; cp[i] = w.c_pos[c][i]; }
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      float dV[6], vp[3];
+#pragma unroll
+      for (int i = 0; i < 6; i++) dV[i] = w.sc.mv.bV[v][b2][i] - w.sc.mv.bV[v][b1][i];
+      cross3(dV, cp, vp);
+      vp[0] += dV[3]; vp[1] += dV[4]; vp[2] += dV[5];
+      w.sc.mv.u[v][t] = (k < 3) ? dot3(fr, vp) : dot3(fn, dV);
+    }
+  }
+  wsync();
 }
 
 // row cost pieces: return the cost, set force = -ds/djar and the curvature
@@ -271,7 +311,7 @@ HD float cost_friction(const DofK& dk, float jar, float& force, float& curv) {
   const float f = dk.floss, R = dk.flR;
   if (jar <= -R * f) { force = f; curv = 0.f; return -f * (0.5f * R * f + jar); }
   if (jar >= R * f) { force = -f; curv = 0.f; return -f * (0.5f * R * f - jar); }
-  const float D = 1.f / R;
+  const float D = frcp(R);
   force = -D * jar; curv = D; return 0.5f * D * jar * jar;
 }
 HD float cost_onesided(float D, float jar, float& force, float& curv) {
@@ -280,8 +320,7 @@ HD float cost_onesided(float D, float jar, float& force, float& curv) {
 }
 
 // ---- constraint rows for the current kinematics / contacts
-// aref_c: reference accelerations of this lane's contact rows (row lane + 64 k, the mapping of RowEval::jar_c)
-__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, float (&aref_c)[NCSLOT], const float* qpos, const float* qvel) {
+__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, const float* qpos, const float* qvel) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   // friction loss and joint limit of dof d (one side per joint can be active: every range is wider than twice
   // the margin; slide and hinge joints have exactly one dof)
@@ -298,8 +337,8 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
       if (sgn != 0.f) {
         const float si[5] = {m.dof_solimp[d][0], m.dof_solimp[d][1], m.dof_solimp[d][2], m.dof_solimp[d][3], m.dof_solimp[d][4]};
         const float imp = dev_impedance(si, dist, margin);
-        const float R = fmaxf(MINVALF, (1.f - imp) * m.dof_limdiag[d] / imp);
-        rk.l_sign = sgn; rk.l_D = 1.f / R;
+        const float R = fmaxf(MINVALF, fdiv((1.f - imp) * m.dof_limdiag[d], imp));
+        rk.l_sign = sgn; rk.l_D = frcp(R);
         rk.l_aref = -m.dof_limB[d] * (sgn * qv) - m.dof_limK[d] * imp * (dist - margin);
       }
     }
@@ -314,8 +353,8 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
       const float incl = m.pair_margin[p] - m.pair_gap[p];
       const float si[5] = {m.pair_solimp[p][0], m.pair_solimp[p][1], m.pair_solimp[p][2], m.pair_solimp[p][3], m.pair_solimp[p][4]};
       const float imp = dev_impedance(si, w.c_dist[c], incl);
-      const float R = fmaxf(MINVALF, (1.f - imp) / imp) * m.pair_Rscale[p];
-      w.c_D[c] = 1.f / fmaxf(R, MINVALF);
+      const float R = fmaxf(MINVALF, fdiv(1.f - imp, imp)) * m.pair_Rscale[p];
+      w.c_D[c] = frcp(fmaxf(R, MINVALF));
       w.c_B[c] = m.pair_B[p];
       w.c_aref0[c] = -m.pair_K[p] * imp * (w.c_dist[c] - incl);
       for (int k = 0; k < 3; k++) w.c_mu[c][k] = m.pair_mu[p][k];
@@ -342,16 +381,36 @@ __device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, 
     if (tid == 0) w.nrow = total;
   }
   wsync();
-  // reference accelerations of the contact rows
-  dev_basis_dot(m, w, qvel);
-  const int nrow_ = w.nrow;
+  // (the reference accelerations of the contact rows need J . qvel: dev_solve forms them together with the Jacobian products of
+  //  its warm-start choice, dev_rows_setup)
+}
+
+// ---- set-up of the solve: reference accelerations of the contact rows (aref_c: rows lane + 64 k, the mapping of
+// RowEval::jar_c) and the row residuals jar = J x - aref at a_smooth (evs) and at the warm start (evw), the three Jacobian
+// products in one pass (dev_basis_dot3)
+__device__ __forceinline__ void dev_rows_setup(const DevModel& m, Work& w, const RowK& rk, float (&aref_c)[NCSLOT], const float* qvel, const float* xs,
+                                               const float* xw, RowEval& evs, RowEval& evw) {
+  const int tid = opaque(threadIdx.x);
+  dev_basis_dot3(m, w, qvel, xs, xw);
+  const bool vd = (tid & 31) < m.nv;
+  const float as = vd ? xs[tid & 31] : 0.f, aw = vd ? xw[tid & 31] : 0.f;
+  evs.jar_f = as - rk.f_aref; evs.jar_l = rk.l_sign * as - rk.l_aref;
+  evw.jar_f = aw - rk.f_aref; evw.jar_l = rk.l_sign * aw - rk.l_aref;
+  const int nrow = w.nrow;
 #pragma unroll
   for (int k = 0; k < NCSLOT; k++) {
-    const int r = tid + k * NT;
-    aref_c[k] = 0.f;
-    if (r < nrow_) { const int c = w.cr_ce[r] >> 3; aref_c[k] = -w.c_B[c] * dev_crow_times(w, r) + w.c_aref0[c]; }
+    aref_c[k] = 0.f; evs.jar_c[k] = 0.f; evw.jar_c[k] = 0.f;
+    if (k * NT < nrow) {
+      const int r = tid + k * NT;
+      if (r < nrow) {
+        const int c = w.cr_ce[r] >> 3;
+        aref_c[k] = -w.c_B[c] * dev_crow_times(w, w.sc.mv.u[0], r) + w.c_aref0[c];
+        evs.jar_c[k] = dev_crow_times(w, w.sc.mv.u[1], r) - aref_c[k];
+        evw.jar_c[k] = dev_crow_times(w, w.sc.mv.u[2], r) - aref_c[k];
+      }
+    }
   }
-  wsync();
+  wsync();      // (the next writer of the solves' scratch -- the first Hessian solve -- comes after every lane has read u)
 }
 
 // ---- row state.  jar = J x - aref of every row: per-dof rows in the registers of lane & 31 = dof (both
@@ -445,10 +504,10 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
 // start (w.qacc), rows.  Out: w.qacc, w.ftot = f_smooth + J'f (LDS).
 // The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
 // line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
-__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const float (&aref_c)[NCSLOT], float fs, float a0, int maxit) {
+__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const float* qvel, float fs, float a0, int maxit) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const bool vd = d < m.nv;
-  const float scale = 1.f / (m.meaninertia * (float)max(m.nv, 1));
+  const float scale = frcp(m.meaninertia * (float)max(m.nv, 1));
   const float wm = w.qacc[d];
   const int nrow = w.nrow;
   const DofK dk{vd ? m.dof_frictionloss[d] : 0.f, vd ? m.dof_flR[d] : 1.f};
@@ -459,9 +518,9 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   const float Mw = vd ? dev_Mx(M, w.qacc) : 0.f;
   const float gw = wave_sum((tid < m.nv) ? 0.5f * (Mw - fs) * (wm - a0) : 0.f);
   RowEval ev, evw;
-  dev_rows_jar(m, w, rk, aref_c, w.sc.vec.x, true, ev);
+  float aref_c[NCSLOT];
+  dev_rows_setup(m, w, rk, aref_c, qvel, w.sc.vec.x, w.qacc, ev, evw);
   const float cs = dev_rows_cost(m, w, dk, rk, D_c, ev);
-  dev_rows_jar(m, w, rk, aref_c, w.qacc, true, evw);
   const float cw = gw + dev_rows_cost(m, w, dk, rk, D_c, evw);
   const bool usewarm = cw < cs;
   float cost_prev = usewarm ? cw : cs;
@@ -478,7 +537,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
     const float g = vd ? (Ma - fs - jtf) : 0.f;
     const float g2 = wave_sum(tid < 32 ? g * g : 0.f);
     PT(11);
-    if (sqrtf(g2) * scale < 1e-6f) { fresh = true; capped = false; break; }
+    if (fsqrt(g2) * scale < 1e-6f) { fresh = true; capped = false; break; }
     // Newton direction: (M + J' diag(curv) J) s = -g ; friction-loss and limit curvature sit on the diagonal
     const float sd = dev_hsolve<true>(m, w, M, ev.curv_f + ev.curv_l, m.nv, -g);
     if (tid < NV) w.sc.vec.x[tid] = vd ? sd : 0.f;      // (a_smooth is in registers by now; T is dead between two solves)
@@ -507,7 +566,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
       alpha = a;
       if (fabsf(dphi) < 1e-4f * fabsf(g0) + 1e-12f) break;
       if (dphi < 0.f) lo = a; else hi = a;
-      float an = a - dphi / ddphi;
+      float an = a - fdiv(dphi, ddphi);
       if (hi >= 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
       if (hi >= 0.f && hi - lo < 1e-6f * (1.f + hi)) break;
       a = an;
@@ -519,7 +578,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
 #pragma unroll
     for (int k = 0; k < NCSLOT; k++) ev.jar_c[k] = fmaf(alpha, jv.jar_c[k], ev.jar_c[k]);
     const float crow = dev_rows_cost(m, w, dk, rk, D_c, ev);
-    const float st = wave_max((tid < m.nv) ? fabsf(dq) / (1.f + fabsf(qacc)) : 0.f);
+    const float st = wave_max((tid < m.nv) ? fdiv(fabsf(dq), 1.f + fabsf(qacc)) : 0.f);
     if (st < 1e-7f) { it++; capped = false; break; }
     // MuJoCo's second criterion (engine_solver.c: improvement = scale * (oldcost - cost) < tolerance): once a Newton
     // step no longer lowers the cost, what is left of the gradient is float32 rounding and another Hessian solve

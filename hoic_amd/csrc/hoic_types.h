@@ -57,6 +57,7 @@ struct DevModel {
   int jnt_type[NJ], jnt_qposadr[NJ], jnt_dofadr[NJ], jnt_bodyid[NJ], jnt_limited[NJ];
   float jnt_pos[NJ][3], jnt_axis[NJ][3], jnt_range[NJ][2], jnt_margin[NJ], jnt_K[NJ], jnt_B[NJ], jnt_solimp[NJ][5];
   float jnt_diag[NJ];  // dof_invweight0 of the joint's dof (limit row diagApprox)
+  int jnt_poszero;     // every hinge / slide joint sits at its body's origin (jnt_pos == 0, the HOIC hand): the kinematics skip the anchor rotations
   float qpos0[NQP];
   int dof_bodyid[NV], dof_jntid[NV], dof_actid[NV];
   // per-dof copies of the joint / body tables (flat: one load level, no joint -> dof -> body index chains)
@@ -196,7 +197,11 @@ union WorkScratch {
   } dyn;
   float T[NV * LD];                  // columns of L during the matrix-core solves
   struct { float x[NV], ctrl[NV]; } vec;   // between two solves: a_smooth / the search direction; the PD torques
+  // the solve's set-up (between the M^-1 f solve and the first Newton solve: T is dead, vec is live): body velocities and
+  // contact-frame products of the THREE vectors that go through the contact Jacobian there (qvel, a_smooth, the warm start)
+  struct { float keep[2 * NV]; float bV[3][NB][6]; float u[3][MAXCON * 4]; } mv;
 };
+static_assert(sizeof(((WorkScratch*)0)->mv) <= sizeof(((WorkScratch*)0)->T), "the set-up's buffers must fit into the solves' scratch");
 #define COLSLOT 2                // contacts staged per lane (= pair) in col_lc
 #define COLPOOL 32               // pairs per pass that can produce more than COLSLOT contacts (DevModel::pair_pool): 2 more each
 struct Work {

@@ -6,11 +6,13 @@ to the chain of inlined device functions the `.loc ... @[ ... ]` comments name (
 are straight-line code per pass, so static count x passes is close to the dynamic count (163 k VALU instructions per env-step
 by SQ_INSTS_VALU); branches that are not taken (narrow-phase routines of pair types that do not occur) make it an upper bound.
 
-usage: python3 tools/static_insn_count.py [kernel-name-prefix, default _Z19hoic_substep_kernelILi2E]"""
+usage: python3 tools/static_insn_count.py [kernel-name-prefix, default _Z19hoic_substep_kernelILi2E] [opcode prefixes, comma list]
+With opcode prefixes (e.g. v_mov,v_cndmask) a third column counts only those instructions, and the table is sorted by it."""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hoic_amd", "csrc")
-kernel = sys.argv[1] if len(sys.argv) > 1 else "_Z19hoic_substep_kernelILi2E"
+kernel = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else "_Z19hoic_substep_kernelILi2E"
+ops = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else None
 asm = os.path.join(tempfile.gettempdir(), "hoic_capi_g1.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form",
                        "-Wno-unused-value", "-S", "--cuda-device-only", "-g1", "-o", asm, "hoic_capi.hip"], cwd=CSRC)
@@ -46,7 +48,7 @@ def fn(file, line):
     return name
 
 
-cnt, cnt_v, chain = collections.Counter(), collections.Counter(), None
+cnt, cnt_v, cnt_o, chain = collections.Counter(), collections.Counter(), collections.Counter(), None
 for l in lines:
     if ".loc" in l and ";" in l:
         chain = [(m.group(1), int(m.group(2))) for m in re.finditer(r"(?:\./)?([\w\.]+):(\d+):\d+", l.split(";", 1)[1])]
@@ -60,6 +62,13 @@ for l in lines:
     cnt[key] += 1
     if m.group(1).startswith("v_"):
         cnt_v[key] += 1
+    if ops and m.group(1).startswith(ops):
+        cnt_o[key] += 1
 print(f"{kernel}: {sum(cnt.values())} instructions, {sum(cnt_v.values())} VALU")
-for k, v in cnt.most_common(45):
-    print(f"{v:6d} {cnt_v[k]:6d}  {k}")
+if ops:
+    print(f"{sum(cnt_o.values())} of them {'/'.join(ops)}")
+    for k, v in cnt_o.most_common(45):
+        print(f"{cnt[k]:6d} {cnt_v[k]:6d} {v:6d}  {k}")
+else:
+    for k, v in cnt.most_common(45):
+        print(f"{v:6d} {cnt_v[k]:6d}  {k}")
