@@ -215,7 +215,15 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    lines = []
+    for l in p.stdout.decode().splitlines():       # rank 0's result line: a JSON object with the contract's keys, not any brace-prefixed banner
+        if l.startswith("{"):
+            try:
+                d = json.loads(l)
+            except ValueError:
+                continue
+            if isinstance(d, dict) and "metric" in d and d.get("n_gpus") == n:
+                lines.append(l)
     if lines:
         sys.stdout.write(lines[-1] + "\n"); sys.stdout.flush()
     sys.exit(p.returncode if p.returncode != 0 or lines else 4)

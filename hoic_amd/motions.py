@@ -139,9 +139,37 @@ def preprocess_seq(model: mjcf.CompiledModel, seq: dict, motion_freq: int = 30, 
     else:
         xpos, xquat = fk_batch(model, qpos)
     hb0, nhb = model.scalar("hand_body0"), model.scalar("hand_nbody")
-    return {"hand_dof_seq": hand, "hand_dof_vel_seq": hv, "obj_pose_seq": obj, "obj_vel_seq": ov,
-            "obj_angle_vel_seq": oav, "body_pos_seq": xpos[:, hb0:hb0 + nhb].copy(),
-            "body_quat_seq": xquat[:, hb0:hb0 + nhb].copy(), "seq_len": T}
+    out = {"hand_dof_seq": hand, "hand_dof_vel_seq": hv, "obj_pose_seq": obj, "obj_vel_seq": ov,
+           "obj_angle_vel_seq": oav, "body_pos_seq": xpos[:, hb0:hb0 + nhb].copy(),
+           "body_quat_seq": xquat[:, hb0:hb0 + nhb].copy(), "seq_len": T}
+    if sim is not None:
+        out["contact_info_seq"] = compute_contact_info(model, hand, obj, sim)
+    return out
+
+
+def compute_contact_info(model: mjcf.CompiledModel, hand_dof_seq, obj_pose_seq, sim):
+    """DatasetSingleDepth.compute_contact_info (dataset_singledepth.py:187-220): per frame the dict
+    ``{hand geom id: contact position}`` of the hand x object contacts of a forward pass on (hand dofs, object pose) of that
+    frame -- geom1 in the hand's geom range, geom2 in the object's (the reference finds the ranges by the name prefixes
+    ``robot0:`` / ``C_``; the compiled model carries them as hand_geom0..1 / obj_geom0..1), the LAST contact of a hand geom
+    wins (dict assignment in contact order).  One probe-kernel launch for all frames (the reference: one ``sim.forward()``
+    per frame); returns an object array of T dicts like the reference's ``np.stack(contact_arr)``."""
+    nh = model.scalar("hand_nq")
+    T = hand_dof_seq.shape[0]
+    qpos = np.zeros((T, model.scalar("nq")))
+    qpos[:, :nh] = hand_dof_seq
+    qpos[:, nh:] = obj_pose_seq
+    pr = sim.probe_forward(qpos, np.zeros((T, model.scalar("nv"))), kinematics_only=True)
+    hg0, hg1, og0, og1 = (model.scalar(k) for k in ("hand_geom0", "hand_geom1", "obj_geom0", "obj_geom1"))
+    info = np.empty(T, dtype=object)
+    for t in range(T):
+        d = {}
+        for row in pr["contacts"][t, :int(pr["ncon"][t])]:           # [dist, pos 3, frame 9, geom1, geom2, .]
+            g1, g2 = int(row[13]), int(row[14])
+            if hg0 <= g1 <= hg1 and og0 <= g2 <= og1:
+                d[g1] = row[1:4].astype(np.float64)
+        info[t] = d
+    return info
 
 
 def load_expert(cfg, model: mjcf.CompiledModel, base_dir: str = "", verbose: bool = False, sim=None):

@@ -105,10 +105,12 @@ def test_two_rank_f16x3_update_equals_the_single_rank_update():
         assert abs(glob - one.last_losses[i]) < 1e-4 * abs(one.last_losses[i]) + 1e-7, (la, lb, one.last_losses)
 
 
-def _loop_worker(rank, world, port, q, update_dtype):
+def _loop_worker(rank, world, port, q, update_dtype, backend="gloo", own_device=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev_index = rank if own_device else 0
+    torch.cuda.set_device(dev_index)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from hoic_amd import mjcf, motions
     from hoic_amd.agent import AgentHandMimic
     from hoic_amd.config import Config
@@ -116,7 +118,7 @@ def _loop_worker(rank, world, port, q, update_dtype):
     cfg.min_batch_size = 2048
     model = mjcf.load_packaged("box")
     expert = motions.synthetic_expert(model, 5, 300)
-    agent = AgentHandMimic(cfg, device=torch.device("cuda", 0), n_envs=256, model="box", expert_seqs=expert, distributed=True, n_groups=2,
+    agent = AgentHandMimic(cfg, device=torch.device("cuda", dev_index), n_envs=256, model="box", expert_seqs=expert, distributed=True, n_groups=2,
                            update_dtype=update_dtype)
     for it in range(3):
         info = agent.optimize_policy(it, save_model=False)
@@ -136,17 +138,35 @@ def test_two_rank_whole_loop_keeps_the_ranks_identical(update_dtype):
     forward (f16x3), asynchronous gradient all-reduces interleaved with the other network's pass, the advantage statistics and
     the observation-filter merge -- as two processes on ONE GPU (gloo between them: RCCL refuses two ranks on one device).  After
     three PPO iterations both ranks hold bit-identical policy and value parameters and the same filter; the logger counts the
-    samples of both ranks.  (was tools/dist_smoke.py.)"""
+    samples of both ranks.  """
+    a, b = _run_loop(update_dtype)
+    assert a[1:8] == b[1:8], ("ranks disagree on parameters / filter", a, b)
+    assert a[9] == b[9] == 2 * 256 * 8            # both ranks' 256 envs x ceil(2048 / 256) steps
+    assert 0.0 < a[8] <= 1.0 and a[8] == b[8]
+
+
+def _run_loop(update_dtype, backend="gloo", own_device=False):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, update_dtype)) for r in range(2)]
+    ps = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, update_dtype, backend, own_device)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(2))
     for p in ps:
         p.join(60)
-    a, b = res
+    return res
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: this pool hands out one MI355X per box")
+def test_rccl_two_ranks_whole_loop():
+    """The same loop as two ranks on TWO devices over RCCL (backend "nccl"): the ranks end with identical parameters and filter,
+    and the result equals the gloo run of the test above -- a sum of two addends does not depend on the order, so the collective
+    library must not change a bit.  Skips on a one-GPU box: until a box with two devices runs it, RCCL has only ever been
+    exercised with one rank and no scaling curve exists."""
+    a, b = _run_loop("f16x3", backend="nccl", own_device=True)
     assert a[1:8] == b[1:8], ("ranks disagree on parameters / filter", a, b)
-    assert a[9] == b[9] == 2 * 256 * 8            # both ranks' 256 envs x ceil(2048 / 256) steps
-    assert 0.0 < a[8] <= 1.0 and a[8] == b[8]
+    assert a[9] == b[9] == 2 * 256 * 8
+    g, _ = _run_loop("f16x3")
+    for x, y in zip(a[1:9], g[1:9]):
+        assert abs(x - y) <= 1e-9 * max(1.0, abs(y)), ("RCCL and gloo runs differ", a, g)

@@ -384,10 +384,18 @@ def test_bench_gpus_flag_refuses_instead_of_running_one_rank():
     has no GPU, so any N > 1 must be refused; the parent never touches the GPU."""
     import subprocess
     env = dict(os.environ); env.pop("WORLD_SIZE", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, env=env, timeout=300)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--other-configs", "0", "--steps", "13",
+                        "--warmup", "13", "--min-iterations", "1"], capture_output=True, env=env, timeout=600)
     if torch.cuda.device_count() < 2:
         assert p.returncode == 3, (p.returncode, p.stderr.decode()[-400:])
         assert b"{" not in p.stdout and b"only" in p.stderr
+    else:       # two devices: the parent relays exactly rank 0's line of a two-rank run over RCCL
+        import json
+        assert p.returncode == 0, (p.returncode, p.stderr.decode()[-2000:])
+        lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "env-dp2" and d["value"] > 0, d
 
 
 def test_library_reports_the_sources_it_was_built_from():

@@ -118,3 +118,24 @@ def test_preprocess_seq_on_device(box_blob, box_model):
         assert np.array_equal(a[k], b[k])
     np.testing.assert_allclose(b["body_pos_seq"], a["body_pos_seq"], atol=2e-6)
     np.testing.assert_allclose(np.abs((b["body_quat_seq"] * a["body_quat_seq"]).sum(-1)), 1.0, atol=1e-6)
+    # contact_info_seq (dataset_singledepth.py:107, 187-220): per frame {hand geom: contact position} of the hand x object
+    # contacts, against the float64 oracle's forward pass on the same (hand dofs, object pose)
+    from oracle import hoo
+    info = b["contact_info_seq"]
+    assert "contact_info_seq" not in a and info.shape == (300,) and all(isinstance(d, dict) for d in info)
+    env = hoo.OracleEnv(box_blob)
+    hg0, hg1, og0, og1 = (box_model.scalar(k) for k in ("hand_geom0", "hand_geom1", "obj_geom0", "obj_geom1"))
+    n_contacts = n_differ = 0
+    for t in range(0, 300, 3):
+        env.set("qpos", np.concatenate([b["hand_dof_seq"][t], b["obj_pose_seq"][t]])); env.set("qvel", np.zeros(32)); env.forward()
+        ref = {}
+        for row in env.contacts():
+            if hg0 <= int(row[13]) <= hg1 and og0 <= int(row[14]) <= og1:
+                ref[int(row[13])] = row[1:4].copy()
+        if set(ref) != set(info[t]):           # a contact within float32 rounding of the margin may appear on one side only
+            n_differ += 1
+            continue
+        n_contacts += len(ref)
+        for g, pos in ref.items():
+            np.testing.assert_allclose(info[t][g], pos, atol=5e-6)
+    assert n_contacts >= 60 and n_differ <= 2, (n_contacts, n_differ)
