@@ -229,7 +229,7 @@ def spawn_ranks(n):
     sys.exit(p.returncode if p.returncode != 0 or lines else 4)
 
 
-def quick_config(obj, args, device, streams=None, value_stream=None, iterations=8, warm=4):
+def quick_config(obj, args, device, streams=None, value_stream=None, iterations=8, warm=4, workload="train", pretrain=0):
     """BASELINE.json configs 3 and 4 (Bottle, Banana: the convex-mesh contact paths) next to the headline: the same loop, `warm`
     untimed and `iterations` timed PPO iterations each (the first iterations of a fresh agent carry one-time costs: allocator,
     stream and engine set-up) -- enough for a driver-timed number, not a substitute for a full run."""
@@ -239,35 +239,56 @@ def quick_config(obj, args, device, streams=None, value_stream=None, iterations=
     from hoic_amd.config import Config
     cfg = Config(f"{obj}_future5_light_add_geom")
     model = mjcf.load_packaged(obj)
-    expert = motions.synthetic_expert(model, 17, 600)
+    expert = motions.synthetic_expert(model, 17, 600, grasp="closed" if workload == "closed-grasp" else "kinematic")
     agent = AgentHandMimic(cfg, device=device, n_envs=args.envs, model=obj, expert_seqs=expert, update_dtype=args.update_dtype,
                            n_groups=args.groups, rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward),
-                           update_streams=args.update_streams, run_ahead=bool(args.run_ahead))
+                           update_streams=args.update_streams, run_ahead=bool(args.run_ahead),
+                           start_min=100 if workload in ("grasp", "closed-grasp") else 0)
     # the headline agent's streams: fresh ones would be mapped onto the process's few hardware queues again, and two env ranges
     # that land on ONE queue run one after the other (measured: Bottle rollout 0.79 M instead of 1.4 M env-steps/s)
     if streams is not None:
         agent._streams = streams
     if value_stream is not None:
         agent.learner._value_stream = value_stream
+    warm += pretrain      # (untimed PPO iterations first: the timed region then runs a policy that tracks the motions and holds the object)
     for it in range(warm):
         agent.optimize_policy(it, save_model=False)
     agent.env.sim.enable_timing(True)
+    agent.env.sim.diagnostics(reset=True)
     torch.cuda.synchronize()
-    t0 = time.time(); k_ms = []; steps = 0; infos = []
+    t0 = time.time(); k_ms = []; p_ms = []; steps = 0; infos = []
     for it in range(iterations):
         infos.append(agent.optimize_policy(warm + it, save_model=False)); steps += int(agent.last_rollout_steps)
-        k_ms += agent.env.sim.step_times()[0]
+        a_, b_ = agent.env.sim.step_times()
+        k_ms += a_; p_ms += b_
     agent.learner.finish_update(); torch.cuda.synchronize()
     el = time.time() - t0
     ts, tu = sum(i["T_sample"] for i in infos), sum(i["T_update"] for i in infos)     # (GPU-timeline durations, read after the region)
     n = steps * args.envs
     diag = agent.env.sim.diagnostics()
-    out = {"workload": f"{obj.capitalize()}, {args.envs} parallel envs, whole loop", "value": n / el, "unit": "env-steps/s", "timed_iterations": iterations,
+    out = {"workload": f"{obj.capitalize()}, {args.envs} parallel envs, whole loop"
+                       + ("; episodes start at frames >= 100, reference motions with the five fingers closed onto the object from frame 160 on"
+                          if workload == "closed-grasp" else "")
+                       + (f"; policy after {pretrain} untimed PPO iterations" if pretrain else ""),
+           "value": n / el, "unit": "env-steps/s", "timed_iterations": iterations,
            "rollout_only_env_steps_per_s": n / ts, "update_s_per_iteration": tu / iterations, "kernel": "hoic_substep_kernel",
-           "kernel_ms": sum(k_ms) / max(len(k_ms), 1), "envs_per_launch": args.envs // len(agent._groups()),
+           "kernel_ms": sum(k_ms) / max(len(k_ms), 1), "poststep_kernel_ms": sum(p_ms) / max(len(p_ms), 1),
+           "envs_per_launch": args.envs // len(agent._groups()),
            "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"]}
+    out.update(contact_stats(agent, model))
     agent.env.close()
     return out
+
+
+def contact_stats(agent, model):
+    """fraction of envs with a hand-object contact right now and contacts per env (one probe launch on the current states of the
+    first 1024 envs)"""
+    q, v, _ = agent.env.sim.get_state()
+    pr = agent.env.sim.probe_forward(q[:1024].cpu().numpy(), v[:1024].cpu().numpy(), kinematics_only=True)
+    hg0, hg1, og0, og1 = [model.scalar(k) for k in ("hand_geom0", "hand_geom1", "obj_geom0", "obj_geom1")]
+    cc = pr["contacts"]
+    ho = (cc[:, :, 13] >= hg0) & (cc[:, :, 13] <= hg1) & (cc[:, :, 14] >= og0) & (cc[:, :, 14] <= og1) & (cc[:, :, 15] > 0)
+    return {"hand_object_contact_env_fraction": float(ho.any(1).mean()), "mean_contacts_per_env": float((cc[:, :, 15] > 0).sum(1).mean())}
 
 
 def main():
@@ -411,12 +432,7 @@ def main():
         envs_per_launch = args.envs // n_groups          # the rollout steps the batch as n_groups env ranges (hoic_step_range)
         achieved = ALGO_BYTES_PER_ENV_STEP * envs_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         diag = agent.env.sim.diagnostics()
-        # fraction of envs with a hand-object contact right now (one probe launch on the current states)
-        q, v, _ = agent.env.sim.get_state()
-        pr = agent.env.sim.probe_forward(q[:1024].cpu().numpy(), v[:1024].cpu().numpy(), kinematics_only=True)
-        hg0, hg1, og0, og1 = [model.scalar(k) for k in ("hand_geom0", "hand_geom1", "obj_geom0", "obj_geom1")]
-        cc = pr["contacts"]
-        ho = (cc[:, :, 13] >= hg0) & (cc[:, :, 13] <= hg1) & (cc[:, :, 14] >= og0) & (cc[:, :, 14] <= og1) & (cc[:, :, 15] > 0)
+        cstats = contact_stats(agent, model)
         dtype_txt = {"f32": "f32", "bf16": "f32 dynamics + bf16 update GEMMs (f64 RFC QP)",
                      "f16x3": "f32 (dynamics f32, RFC QP f64; update GEMMs = float32 operands split error-free into f16 pairs, "
                               "3 f16 MFMAs per product sum into f32 accumulators: 22-bit operands, float32-class accuracy)"}[args.update_dtype]
@@ -447,7 +463,7 @@ def main():
             "host_s_per_iteration": ({"enqueue_rollout": host_phases[0] / n_it, "enqueue_update": host_phases[1] / n_it,
                                       "wait_rollout_statistics": host_phases[2] / n_it} if agent.run_ahead else None),
             "avg_episode_len": float(last_log.avg_episode_len), "avg_c_reward": float(last_log.avg_c_reward),
-            "workload_stats": {"hand_object_contact_env_fraction": float(ho.any(1).mean()), "mean_contacts_per_env": float((cc[:, :, 15] > 0).sum(1).mean()),
+            "workload_stats": {**cstats,
                                "contact_overflow": diag["contact_overflow"], "solver_cap_hits": diag["solver_cap_hits"],
                                "solver_cap_hit_fraction_of_substeps": diag["solver_cap_hits"] / float(K * args.envs * cfg.sim_step)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -464,12 +480,23 @@ def main():
                 and not args.pretrain and args.envs == 4096):
             agent.env.close()
             out["other_configs"] = {}
-            for o in ("bottle", "banana"):
+            # Bottle / Banana (BASELINE.json configs 3, 4) and the CONTACT-RICH Box line: the headline's random initial policy has a
+            # hand-object contact in ~5 % of the envs, this one (closed-grasp motions, 100 untimed PPO iterations first) in ~90 %:
+            # the number that prices the contact solve, the coupled factorisation schedule and the residual-force QP
+            for name, o, kw in (("bottle", "bottle", {}), ("banana", "banana", {}),
+                                ("box_closed_grasp", "box", {"workload": "closed-grasp", "pretrain": 100})):
                 try:
-                    out["other_configs"][o] = quick_config(o, args, torch.device("cuda", local_rank), agent._streams, agent.learner._value_stream)
+                    out["other_configs"][name] = quick_config(o, args, torch.device("cuda", local_rank), agent._streams, agent.learner._value_stream, **kw)
                 except Exception as e:          # the headline line must not die with a secondary measurement
-                    out["other_configs"][o] = {"error": f"{type(e).__name__}: {e}"}
+                    out["other_configs"][name] = {"error": f"{type(e).__name__}: {e}"}
         out["cpu_baseline"] = cpu
+        # a cut contact list (more than 32 contacts, or more constraint rows than the solver's 128) is physics the reference does
+        # not have: never observed, and loud if it ever is
+        over = {"headline": diag["contact_overflow"], **{k: v.get("contact_overflow", 0) for k, v in out.get("other_configs", {}).items()}}
+        if any(over.values()):
+            out["warnings"] = [f"contact list cut in {n} forward passes of {k} (hoic_get_diagnostics): results differ from the reference's uncapped solve"
+                               for k, n in over.items() if n]
+            sys.stderr.write("bench.py WARNING: " + "; ".join(out["warnings"]) + "\n")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:

@@ -38,6 +38,7 @@ import torch
 from . import motions
 from .config import Config
 from .env import BatchedHandObjMimic
+from . import lib
 from .lib import NV as lib_NV
 from .rl import MLP, BatchZFilter, PolicyGaussian, RunningStat, Value, ZFilter, estimate_advantages, ppo_loss
 
@@ -790,6 +791,22 @@ class AgentHandMimic:
         self.env.update_reward_params()
 
     def optimize_policy(self, epoch, save_model=True):
+        """One PPO iteration (agent_handmimic.py:311-336).  Run-ahead mode reads the f16-range checks of the rollout's tiled
+        forward and of the update one phase late: an overflow still raises HoicError, but by then the policy has been stepped
+        on the invalid batch (and, for the update's own check, the next rollout has run).  The agent is therefore POISONED by
+        such an error: every later optimize_policy / save_checkpoint raises, so a caller that catches the exception cannot keep
+        training or checkpoint the corrupted weights (restart from the last checkpoint, which was written after a clean
+        finish_update)."""
+        if getattr(self, "_poisoned", None):
+            raise lib.HoicError(f"this agent stopped after a float16-range overflow was detected one phase late: {self._poisoned}")
+        try:
+            return self._optimize_policy(epoch, save_model)
+        except lib.HoicError as e:
+            if self.run_ahead:
+                self._poisoned = str(e)
+            raise
+
+    def _optimize_policy(self, epoch, save_model=True):
         self.epoch = epoch
         share = self.world if (self.scaling == "strong" and self.distributed) else 1
         if self.run_ahead and self.sample_mode == "fixed":
@@ -836,9 +853,22 @@ class AgentHandMimic:
             t2 = time.time()
             info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
         if save_model and (epoch + 1) % self.cfg.save_n_epochs == 0 and self.rank == 0:
+            self.check_contact_caps()
             self.save_checkpoint(epoch)
             info["log_eval"] = self.eval_policy(epoch)
         return info
+
+    def check_contact_caps(self):
+        """The kernel cuts an env's contact list at 32 contacts / 128 constraint rows (the reference's MuJoCo solve never drops a
+        row): never observed in a rollout, counted per env (hoic_get_diagnostics), and reported here -- at every checkpoint --
+        if it ever happens.  Returns the count since the last reset."""
+        n = int(self.env.sim.diagnostics()["contact_overflow"])
+        if n and not getattr(self, "_cap_warned", False):
+            import warnings
+            warnings.warn(f"hoic: the contact list was cut in {n} forward passes (more than 32 contacts or 128 constraint rows in an env): "
+                          "those substeps differ from the reference's uncapped solve", RuntimeWarning)
+            self._cap_warned = True
+        return n
 
     # ------------------------------------------------------------------ deterministic evaluation (:339-403)
     def _eval_sim(self, n):
@@ -947,6 +977,8 @@ class AgentHandMimic:
 
     # ------------------------------------------------------------------ checkpoints (:175-186, :234-245)
     def save_checkpoint(self, epoch):
+        if getattr(self, "_poisoned", None):
+            raise lib.HoicError(f"not checkpointing: this agent's weights were stepped on an invalid batch ({self._poisoned})")
         self.learner.finish_update()
         os.makedirs(self.cfg.model_dir, exist_ok=True)
         cp = {"policy_dict": {k: v.detach().cpu() for k, v in self.policy_net.state_dict().items()},

@@ -27,6 +27,7 @@
 #define MAXCON 32        // contacts kept per env per substep
 #define NCROW (MAXCON * 4)   // contact rows (pyramid edges): 4 per condim-3 contact, 6 per condim-4, 1 per condim-1; contacts whose rows do not fit are cut
 #define NCSLOT (NCROW / NT)  // contact rows handled per lane
+static_assert(NCROW <= 256 && MAXCON <= 32, "Work::c_row0 holds a row index in 8 bits, Work::cr_ce a contact index in 5 (contact << 3 | edge)");
 #define LD 33            // padded leading dimension of 32-wide LDS matrices (bank-conflict free)
 #define NHB HOIC_NHANDBODY
 #define NHG 19

@@ -99,6 +99,7 @@ ho_env* hoo_env_create(const void* blob, size_t nbytes) {
   c->pos_diff_thresh = 0.1; c->rot_diff_thresh = 1.0; c->jpos_diff_thresh = 0.1;
   c->obj_pos_diff_thresh = 0.1; c->obj_rot_diff_thresh = 1.0;
   c->residual_force_scale = 2.5; c->residual_torque_scale = 0.125;
+  e->m.pd_wrap_cap = 16;
   /* ho_im4.py:103-107 */
   for (int j = 0; j < e->m.hand_nq; j++) {
     double lo = e->m.jnt_range[j][0], hi = e->m.jnt_range[j][1];
@@ -116,6 +117,11 @@ static void free_expert(ho_expert* x) {
 void hoo_env_set_pd_ref_offset(ho_env* e, int off) { e->cfg.pd_ref_offset = off; }
 void hoo_env_set_mesh_single_contact(ho_env* e, int on) { e->m.mesh_single_contact = on ? 1 : 0; }
 void hoo_env_set_obb_reject(ho_env* e, int on) { e->m.no_obb_reject = on ? 0 : 1; }     /* default on (ho_sim.c ho_collision) */
+/* Reference-faithful mode: the two places where this oracle was changed in lock-step with the HIP kernel are switched back to
+   what the reference does -- no oriented-box rejection in the collision driver (MuJoCo's broad phase is bounding spheres /
+   AABBs; the reject only drops shallow hull contacts of separated geoms) and the unbounded angle wrap of compute_torque.
+   tests/test_gpu_parity.py runs whole episodes of the HIP kernel against this mode. */
+void hoo_env_set_reference_faithful(ho_env* e, int on) { e->m.no_obb_reject = on ? 1 : 0; e->m.pd_wrap_cap = on ? 0 : 16; }
 void hoo_env_destroy(ho_env* e) { if (e) { free_expert(&e->e); free(e); } }
 
 void hoo_env_set_cfg(ho_env* e, const double* jkp, const double* jkd, const double* torque_lim,
@@ -213,9 +219,10 @@ void hoo_env_compute_torque(const ho_env* e, const double* ctrl, double* torque)
   /* the reference's while loops (ho_im4.py:476-481) with the trip limit of the HIP kernel (hoic_env.h dev_pd_torque): a
      runaway test-mode state (|err| > 33 pi) would otherwise spin for ages here and hang the GPU launch there; both sides
      give the same result for every |err| */
+  const int cap = m->pd_wrap_cap > 0 ? m->pd_wrap_cap : 0x7fffffff;      /* reference-faithful mode: the plain while loops */
   for (int i = 3; i < n; i++) {
-    for (int k = 0; k < 16 && err[i] > M_PI; k++) err[i] -= 2 * M_PI;
-    for (int k = 0; k < 16 && err[i] < -M_PI; k++) err[i] += 2 * M_PI;
+    for (int k = 0; k < cap && err[i] > M_PI; k++) err[i] -= 2 * M_PI;
+    for (int k = 0; k < cap && err[i] < -M_PI; k++) err[i] += 2 * M_PI;
   }
   /* compute_desired_accel: chol(M[:26,:26] + Kd dt)^-1 (-C - Kp e - Kd qd), M and C from the LAST forward pass */
   for (int i = 0; i < n; i++) {

@@ -48,6 +48,7 @@ def lib():
         L.hoo_env_set_pd_ref_offset.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_set_mesh_single_contact.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_set_obb_reject.argtypes = [C.c_void_p, C.c_int]
+        L.hoo_env_set_reference_faithful.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hoo_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hoo_env_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -144,6 +145,11 @@ class OracleEnv:
     def set_obb_reject(self, on: bool):
         """the collision driver's bounding-box rejection (ho_sim.c ho_collision; default on)"""
         self.L.hoo_env_set_obb_reject(self.h, int(bool(on)))
+
+    def set_reference_faithful(self, on: bool):
+        """switch the oracle's two kernel-motivated deviations back to the reference's behaviour: no oriented-box rejection in the
+        collision driver and the unbounded angle wrap of compute_torque (ho_im4.py:476-481)"""
+        self.L.hoo_env_set_reference_faithful(self.h, int(bool(on)))
 
     def set_expert(self, ex: dict):
         T = ex["hand_dof_seq"].shape[0]

@@ -454,25 +454,31 @@ def test_rltest_streaming_loop(box_blob, box_model, setup):
     print("streaming control step: %.2f ms" % (per_step * 1e3))
 
 
-@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
-def test_episode_reward_parity(obj, oracle_lib):
+@pytest.mark.parametrize("obj,faithful", [("box", False), ("bottle", False), ("banana", False), ("bottle", True), ("banana", True)])
+def test_episode_reward_parity(obj, faithful, oracle_lib):
     """North-star parity statement: the same (seeded, randomly initialised) deterministic policy driven through the
     float64 oracle and through the HIP simulator gives the same episode length and the same episode reward within
     float32 tolerance, over whole episodes of several hundred env steps (6000+ substeps with contacts) -- for the Box and for
-    the two convex-mesh objects (BASELINE.json configs 2-4)."""
+    the two convex-mesh objects (BASELINE.json configs 2-4), sixteen episodes each.
+    ``faithful``: the oracle in its reference-faithful mode (OracleEnv.set_reference_faithful: no oriented-box rejection in the
+    collision driver, unbounded angle wrap) -- the kernel keeps its reject, so this pins "oracle with reject" against "oracle
+    without" on whole episodes of the objects where the reject can drop a (shallow, hull-tip) contact.  Same bounds."""
     from hoic_amd.rl import PolicyGaussian
     box_blob, cfg, ex, thresh = _obj_setup(obj)
-    N = 4
+    N = 16
     sim = _sim(box_blob, N, cfg, ex, thresh)
     torch.manual_seed(3)
     pol = PolicyGaussian(cfg, 32, 617).eval()
     pol_d = PolicyGaussian(cfg, 32, 617).to("cuda").eval(); pol_d.load_state_dict(pol.state_dict())
-    seqs = np.arange(N) % 4; starts = np.array([0, 40, 120, 200])
+    seqs = np.arange(N) % 4; starts = np.array([0, 40, 120, 200] * 4) + 10 * (np.arange(N) // 4)
     wk = cfg.reward_wk()
     # oracle episodes
     ref = []
     for i in range(N):
-        o = _oracle(oracle_lib, box_blob, cfg, thresh, ex[seqs[i]]); obs = o.reset(int(starts[i]))
+        o = _oracle(oracle_lib, box_blob, cfg, thresh, ex[seqs[i]])
+        if faithful:
+            o.set_reference_faithful(True)
+        obs = o.reset(int(starts[i]))
         tot, n = 0.0, 0
         with torch.no_grad():
             for _ in range(600):
@@ -499,6 +505,10 @@ def test_episode_reward_parity(obj, oracle_lib):
             alive &= ~done
             if not bool(alive.any()):
                 break
+    worst_r = max(abs(float(tot[i]) - ref[i][0]) / ref[i][0] for i in range(N))
+    worst_q = max(float(np.abs(qfinal[i][:33] - ref[i][2]).max()) for i in range(N) if int(n[i]) == ref[i][1])
+    print(f"episode parity {obj}{' (reference-faithful oracle)' if faithful else ''}: lengths {[int(x) for x in n.tolist()]}, "
+          f"worst relative reward deviation {worst_r:.2e}, worst final |dq| {worst_q:.2e}")
     for i in range(N):
         assert int(n[i]) == ref[i][1], (i, int(n[i]), ref[i][1])
         assert ref[i][1] > 100
