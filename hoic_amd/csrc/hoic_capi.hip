@@ -35,7 +35,10 @@ __device__ __forceinline__ void load_state(const DevModel& m, const DevState& st
   if (tid < NQP) w.qpos[tid] = as_global(st.qpos)[(size_t)env * NQP + tid];
   if (tid < NV) {
     w.qvel[tid] = as_global(st.qvel)[(size_t)env * NV + tid];
-    w.qacc[tid] = as_global(st.warm)[(size_t)env * NV + tid];       // the warm start of the first solve
+    // the warm start of the first solve: the constraint acceleration of the env's last solve (dev_solve; zero after a reset), or
+    // MuJoCo's plain qacc_warmstart
+    const float wrow = as_global(st.warm)[(size_t)env * NV + tid];
+    w.qacc[tid] = m.warm_shift ? 0.f : wrow; w.acon[tid] = m.warm_shift ? wrow : 0.f;
     w.applied[tid] = 0.f;
   }
   if (tid == 0) { w.ncon = 0; w.nrow = 0; w.solver_iter = 0; w.cbod = 0u; w.capped = 0; }
@@ -53,7 +56,7 @@ template <class W> __device__ __forceinline__ void store_state(const DevState& s
 
 // velocity / acceleration stages of mj_forward on the state in w.qpos/w.qvel with w.applied (applied + actuator forces) and the
 // warm start (w.qacc) set (dev_forward_kin has run on the same state); a0_out: the unconstrained acceleration of dof lane & 31
-__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, float* a0_out) {
+__device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, float* a0_out, bool shift_warm) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   float fs = 0.f;
   if (d < m.nv) fs = -m.dof_damping[d] * w.qvel[d] - w.bias[d] + w.applied[d];   // passive (joint damping) - bias + applied + actuation
@@ -65,7 +68,7 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   wsync();
   RowK rk;
   dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
-  dev_solve(m, w, M, rk, w.qvel, fs, a0, cfg.c.solver_iterations); PT(9);
+  dev_solve(m, w, M, rk, w.qvel, fs, a0, cfg.c.solver_iterations, shift_warm); PT(9);
   // mj_checkPos / mj_checkVel / mj_checkAcc [MJ-doc]: a non-finite or huge (> 1e10) entry of qpos, qvel or qacc is MuJoCo's
   // "Nan, Inf or huge value" warning, which mujoco_py raises and the env turns into fail = True (ho_im4.py:635-637)
   float bad = 0.f;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       continue;
     }
     if (mode == 2) break;
-    ok = dev_forward_dyn(ml, cl, w, M, nullptr);       // :545 mj_step = forward ...
+    ok = dev_forward_dyn(ml, cl, w, M, nullptr, ml.warm_shift != 0);       // :545 mj_step = forward ...
     ncapped += w.capped;
 #ifdef HOIC_TRACE_DISPATCH
     trace_ncon += w.ncon; trace_iter += w.solver_iter; trace_ncon_max = max(trace_ncon_max, w.ncon);
@@ -355,6 +358,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   for (int k = te; k < m.nbody * 3; k += NT) post[PB_XPOS + k] = w.xpos[k / 3][k % 3];
   for (int k = te; k < m.nbody * 4; k += NT) post[PB_XQUAT + k] = w.xquat[k / 4][k % 4];
   for (int k = te; k < m.ngeom * 3; k += NT) post[PB_GXPOS + k] = w.gxpos[k / 3][k % 3];
+  if (m.warm_shift) {          // what persists as the warm start is the constraint acceleration (zero after a failed substep)
+    wsync();
+    if (te < NV) w.qacc[te] = ok ? w.acon[te] : 0.f;
+    wsync();
+  }
   store_state(st, w, env, false);
   if (ok && nsub > 0) {       // hand the last forward pass over to the next launch (it ran on the state that is now qlag, vlag)
 #pragma unroll
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(NT) void hoic_probe_kernel(const DevModel* __restri
   if (a.gxmat) for (int k = tid; k < m.ngeom * 9; k += NT) a.gxmat[(size_t)env * m.ngeom * 9 + k] = w.gxmat[k / 9][k % 9];
   wsync();
   float a0 = 0.f;
-  const bool ok = dev_forward_dyn(m, cfg, w, M, &a0);
+  const bool ok = dev_forward_dyn(m, cfg, w, M, &a0, false);
   if (a.xpos) for (int k = tid; k < m.nbody * 3; k += NT) a.xpos[(size_t)env * m.nbody * 3 + k] = w.xpos[k / 3][k % 3];
   if (a.xquat) for (int k = tid; k < m.nbody * 4; k += NT) a.xquat[(size_t)env * m.nbody * 4 + k] = w.xquat[k / 4][k % 4];
   if (a.gxpos) for (int k = tid; k < m.ngeom * 3; k += NT) a.gxpos[(size_t)env * m.ngeom * 3 + k] = w.gxpos[k / 3][k % 3];
@@ -952,6 +960,7 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     }
     m.mesh_prune = getenv("HOIC_MESH_STREAM") == nullptr ? 1 : 0;
     m.obb_reject = getenv("HOIC_NO_OBB_REJECT") == nullptr ? 1 : 0;
+    m.warm_shift = getenv("HOIC_PLAIN_WARMSTART") == nullptr ? 1 : 0;
   } else { set_err("model blob: mesh tables missing"); return false; }
   return true;
 }

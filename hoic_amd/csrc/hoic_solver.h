@@ -504,10 +504,21 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
 // start (w.qacc), rows.  Out: w.qacc, w.ftot = f_smooth + J'f (LDS).
 // The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
 // line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
-__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const float* qvel, float fs, float a0, int maxit) {
+__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const float* qvel, float fs, float a0, int maxit, bool shift_warm) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const bool vd = d < m.nv;
   const float scale = frcp(m.meaninertia * (float)max(m.nv, 1));
+  // Warm start.  MuJoCo starts from qacc_warmstart = the previous substep's qacc (or from a_smooth if that costs less).  The PD
+  // torques move a_smooth from substep to substep by more than the constraint forces move -- eight of fifteen solves of an env
+  // step fell back to a_smooth -- so the candidate here is a_smooth + (qacc - a_smooth of the previous substep): the previous
+  // solution with the change of the unconstrained acceleration applied, i.e. the previous CONSTRAINT acceleration carried over.
+  // The optimum is unique and the stop criteria are unchanged, so only the number of Newton iterations depends on the start;
+  // it persists across launches in the state's warm-start row (zero after a reset: the start is then a_smooth).
+  // (shift_warm: wave-uniform; the probe kernel passes false and starts from the qacc it was given)
+  if (shift_warm) {
+    if (tid < NV) w.qacc[tid] = vd ? a0 + w.acon[tid] : 0.f;
+    wsync();
+  }
   const float wm = w.qacc[d];
   const int nrow = w.nrow;
   const DofK dk{vd ? m.dof_frictionloss[d] : 0.f, vd ? m.dof_flR[d] : 1.f};
@@ -591,7 +602,7 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   }
   // forces at the final acceleration (the row state already belongs to it)
   if (!fresh) jtf = dev_jt_force(m, w, rk, ev);
-  if (tid < NV) { w.ftot[tid] = vd ? fs + jtf : 0.f; w.qacc[tid] = qacc; }
+  if (tid < NV) { w.ftot[tid] = vd ? fs + jtf : 0.f; w.qacc[tid] = qacc; w.acon[tid] = qacc - a0; }
   if (tid == 0) { w.solver_iter = it; w.capped = capped ? 1 : 0; }
   wsync();
 }

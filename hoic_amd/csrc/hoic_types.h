@@ -89,6 +89,8 @@ struct DevModel {
   // ---- run bounds of the hull tables (build_model; exact pruning of the narrow phase's hull queries, hoic_collide.h)
   int mesh_prune;                                  // 0: stream every table entry (HOIC_MESH_STREAM=1, A/B and the identity test)
   int obb_reject;                                  // 0: no oriented-box reject in the collision driver (HOIC_NO_OBB_REJECT=1, A/B and its test)
+  int warm_shift;                                  // 1: the Newton solve's warm start is a_smooth + (what the constraints added last substep); 0: MuJoCo's
+                                                   //    plain qacc_warmstart = the last substep's qacc (HOIC_PLAIN_WARMSTART=1, A/B)
   int mesh_vrunadr[HOIC_MAX_MESH], mesh_vrunnum[HOIC_MAX_MESH], mesh_frunadr[HOIC_MAX_MESH], mesh_frunnum[HOIC_MAX_MESH];
   __attribute__((aligned(16))) float mesh_aabb[HOIC_MAX_MESH][8];      // lo xyz _, hi xyz _ of the hull vertices (mesh frame)
   __attribute__((aligned(16))) float mesh_vrun[MAXVRUN][4];            // bounding sphere of a run of HOIC_HULL_RUN_VERTS vertices: centre, radius
@@ -145,7 +147,7 @@ static_assert(PB_OBJACC + 6 <= PB_QPOS && PB_DONE + 1 <= PB_SIZE, "post buffer l
 struct DevState {
   float* qpos;   // [n, NQP]
   float* qvel;   // [n, NV]
-  float* warm;   // [n, NV]
+  float* warm;   // [n, NV]  warm start of the next solve: qacc - a_smooth of the last one (DevModel::warm_shift), or MuJoCo's plain qacc
   float* qlag;   // [n, NQP]  state before the last integration (one-substep lag)
   float* vlag;   // [n, NV]
   int* cur_t;    // [n]
@@ -234,6 +236,7 @@ struct Work {
   };
   // contacts of the current forward pass
   int ncon, nrow, solver_iter, capped;
+  float acon[NV];                      // qacc - a_smooth of the last solve: the acceleration the constraints added (warm start of the next solve)
   unsigned cbod;                       // bodies that take part in a contact (bit b), bit 31: one of them has a path of more than six dofs
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
   unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
