@@ -824,6 +824,7 @@ bool build_model(const void* blob, size_t nbytes, DevModel& m) {
     int path[32], np = 0;
     for (int d = lastdof[i]; d >= 0; d = dparent[d]) path[np++] = d;
     if (np > 12) { set_err("model blob: more than 12 dofs on a body's path"); return false; }
+    m.max_path = std::max(m.max_path, np);
     for (int k = 0; k < 3; k++) m.body_path[i][k] = 0xFFFFFFFFu;
     for (int k = 0; k < np; k++) {   // root first
       const int d = path[np - 1 - k];

@@ -849,7 +849,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
   // Constraint rows: 4 per condim-3 contact, 6 per condim-4 (object on the table), 1 per condim-1; the solver holds NCROW = 4
   // MAXCON of them.  The list is cut where the rows run out (a full list with condim-4 contacts in it): counted with the
   // contact overflows, never observed in a rollout (hoic_get_diagnostics).
-  {
+  if (__builtin_amdgcn_readfirstlane(w.ncon) * 6 > NCROW) {      // (up to 21 contacts the rows fit whatever their condim)
     const int nc = w.ncon;
     int nr = 0;
     if (tid < nc) { const int dim = m.pair_condim[w.c_pair[tid]]; nr = dim == 1 ? 1 : 2 * (dim - 1); }

@@ -27,17 +27,19 @@ __device__ __forceinline__ void dev_load_constants(const DevModel& m, Work& w) {
 // sum_{d on the packed path} S[d] * x[d]  (+ optional extra[d]) as straight-line code: all LDS reads are issued
 // before the first FMA needs them (one latency instead of one per dof); `below` keeps only dofs < below
 template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[3], const float* x, const float (*extra)[6],
-                                          int below, float* V, float* A, bool second = true) {
+                                          int below, float* V, float* A, bool second = true, bool tail = true) {
   // (the packed path is loop-invariant over the substeps: hidden from the optimiser, or the 12 unpacked indices and
   // their scaled copies are hoisted out of the substep loop and spilled)
   // second (wave-uniform): also entries 6..11 -- a caller that knows no lane's path is longer than six dofs (the free object,
-  // the palm) skips that batch
+  // the palm) skips that batch; tail (wave-uniform): entries 10, 11 -- no body of the HOIC hand has more than ten dofs on its
+  // path (palm 6 + finger 4: DevModel::max_path), so they would be two masked-off gathers in every call
   const unsigned pk[3] = {path[0], path[1], path[2]};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     if (h == 1) { __builtin_amdgcn_sched_barrier(0); if (!second) break; }   // two batches of six gathers in flight, not twelve (register peak)
 #pragma unroll
     for (int i = 6 * h; i < 6 * h + 6; i++) {
+      if (i == 10 && !tail) break;
       const unsigned e = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
       const bool on = e < (unsigned)below;
       const int d = on ? (int)e : 0;
@@ -56,13 +58,14 @@ template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[
 // the same gather for NX vectors at once (the Jacobian products of the solve's set-up: qvel, a_smooth and the warm start go
 // through the contact Jacobian together): one unpacking of the path and one read of S[d] serve all of them; per vector the
 // multiply-adds run in the order of path_gather, so every product is bit-identical to a separate pass
-template <int NX> HD void path_gather_multi(const Work& w, const unsigned (&path)[3], const float* const (&x)[NX], float (&V)[NX][6], bool second) {
+template <int NX> HD void path_gather_multi(const Work& w, const unsigned (&path)[3], const float* const (&x)[NX], float (&V)[NX][6], bool second, bool tail) {
   const unsigned pk[3] = {path[0], path[1], path[2]};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     if (h == 1) { __builtin_amdgcn_sched_barrier(0); if (!second) break; }
 #pragma unroll
     for (int i = 6 * h; i < 6 * h + 6; i++) {
+      if (i == 10 && !tail) break;
       const unsigned e = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
       const bool on = e != 0xFFu;
       const int d = on ? (int)e : 0;
@@ -347,7 +350,7 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
   if (tid < m.nv) {
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sd[6];
     const unsigned pth[3] = {m.dof_bpath[tid][0], m.dof_bpath[tid][1], m.dof_bpath[tid][2]};
-    path_gather<false>(w, pth, qvel, nullptr, tid, v, nullptr);   // dofs above `tid` on its path
+    path_gather<false>(w, pth, qvel, nullptr, tid, v, nullptr, true, m.max_path > 10);   // dofs above `tid` on its path
     cross_motion(v, w.S[tid], sd);
     const float qd = qvel[tid];
     for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[tid][i] = sd[i] * qd;
@@ -358,7 +361,7 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
     if (bp[0] != 0xFFFFFFFFu) {
       float V[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, A[6] = {0.f, 0.f, 0.f, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-      path_gather<true>(w, bp, qvel, w.sc.dyn.u.f.fS, 0xFF, V, A);
+      path_gather<true>(w, bp, qvel, w.sc.dyn.u.f.fS, 0xFF, V, A, true, m.max_path > 10);
       float Iv[6], Ia[6], x[6];
       inert_mul(w.sc.dyn.I10[tid], V, Iv); inert_mul(w.sc.dyn.I10[tid], A, Ia); cross_force(V, Iv, x);
       for (int i = 0; i < 6; i++) f[i] = Ia[i] + x[i];

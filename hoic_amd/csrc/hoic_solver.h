@@ -134,10 +134,30 @@ __device__ __forceinline__ float dev_hsolve(const DevModel& m, Work& w, const MR
   constexpr bool use_rows = ROWS;
   const int lane = opaque(threadIdx.x), col = lane & 31, hi = lane >> 5;
   f32x16 acc;
-  // this lane holds the diagonal entry (col, col) in register dreg if its half-wave owns row col
-  const int dreg = (((col >> 2) & 1) == hi) ? (col & 3) + 4 * (col >> 3) : -1;
+  // Diagonal shift.  Lane (col, hi) holds the diagonal entry (col, col) in register (col & 3) + 4 (col >> 3) if its half-wave
+  // owns row col, i.e. ((col >> 2) & 1) == hi: register 4 g + q has its two diagonal lanes in the 4-lane banks
+  // {row g >> 1, bank 2 (g & 1)} and {row 2 + (g >> 1), bank 2 (g & 1) + 1} of the wave.  Sixteen compare-select-add triples
+  // become four selects -- x_q = dg on the lanes whose diagonal register has (reg & 3) == q, 0 elsewhere -- and sixteen DPP
+  // adds whose row / bank masks enable exactly those banks (the other enabled lanes add x_q = 0).
+  {
+    float a[16];
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) acc[reg] = M.r[reg] + (dreg == reg ? dg : 0.f);
+    for (int reg = 0; reg < 16; reg++) a[reg] = M.r[reg];
+    if (!(__builtin_constant_p(dg) && dg == 0.f)) {
+      const int qsel = (((col >> 2) & 1) == hi) ? (col & 3) : -1;
+      float x0 = qsel == 0 ? dg : 0.f, x1 = qsel == 1 ? dg : 0.f, x2 = qsel == 2 ? dg : 0.f, x3 = qsel == 3 ? dg : 0.f;
+#define HS_DIAG(r, x, rm, bm) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,1,2,3] row_mask:" rm " bank_mask:" bm : "+v"(a[r]) : "v"(x))
+      // (a DPP operand needs two wait states after the VALU instruction that wrote it: the selects above)
+      asm volatile("s_nop 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      HS_DIAG(0, x0, "0x5", "0x3"); HS_DIAG(1, x1, "0x5", "0x3"); HS_DIAG(2, x2, "0x5", "0x3"); HS_DIAG(3, x3, "0x5", "0x3");
+      HS_DIAG(4, x0, "0x5", "0xc"); HS_DIAG(5, x1, "0x5", "0xc"); HS_DIAG(6, x2, "0x5", "0xc"); HS_DIAG(7, x3, "0x5", "0xc");
+      HS_DIAG(8, x0, "0xa", "0x3"); HS_DIAG(9, x1, "0xa", "0x3"); HS_DIAG(10, x2, "0xa", "0x3"); HS_DIAG(11, x3, "0xa", "0x3");
+      HS_DIAG(12, x0, "0xa", "0xc"); HS_DIAG(13, x1, "0xa", "0xc"); HS_DIAG(14, x2, "0xa", "0xc"); HS_DIAG(15, x3, "0xa", "0xc");
+#undef HS_DIAG
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) acc[reg] = a[reg];
+  }
   if (nact < NV) {           // leading nact x nact block, identity elsewhere (the PD solve on the hand dofs)
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
@@ -238,7 +258,7 @@ __device__ __forceinline__ void dev_basis_dot(const DevModel& m, Work& w, const 
   if (tid < m.nbody && ((cb >> tid) & 1u)) {
     float V[6] = {0, 0, 0, 0, 0, 0};
     const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
-    path_gather<false>(w, bp, x, nullptr, 0xFF, V, nullptr, (cb >> 31) != 0u);
+    path_gather<false>(w, bp, x, nullptr, 0xFF, V, nullptr, (cb >> 31) != 0u, m.max_path > 10);
 #pragma unroll
     for (int i = 0; i < 6; i++) w.bV[tid][i] = V[i];
   }
@@ -279,7 +299,7 @@ __device__ __forceinline__ void dev_basis_dot3(const DevModel& m, Work& w, const
     float V[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
     const unsigned bp[3] = {w.k_bpath[tid][0], w.k_bpath[tid][1], w.k_bpath[tid][2]};
     const float* const xs[3] = {x0, x1, x2};
-    path_gather_multi<3>(w, bp, xs, V, (cb >> 31) != 0u);
+    path_gather_multi<3>(w, bp, xs, V, (cb >> 31) != 0u, m.max_path > 10);
 #pragma unroll
     for (int v = 0; v < 3; v++)
 #pragma unroll

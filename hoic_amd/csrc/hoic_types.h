@@ -53,6 +53,7 @@ struct DevModel {
   unsigned body_kids[NB][2];    // up to 8 children, one byte each (0xFF = none)
   unsigned body_dofmask[NB];    // dofs on the path root -> body
   unsigned body_path[NB][3];    // the same path as up to 12 packed dof indices (0xFF = none), root first
+  int max_path;                 // dofs on the longest path (the gathers skip entries 10, 11 when none has more than ten)
   float body_pos[NB][3], body_quat[NB][4], body_ipos[NB][3], body_iquat[NB][4], body_mass[NB], body_inertia[NB][3];
   // joints / dofs
   int jnt_type[NJ], jnt_qposadr[NJ], jnt_dofadr[NJ], jnt_bodyid[NJ], jnt_limited[NJ];
