@@ -403,8 +403,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 // ---- kernel 2 of a step: contact averaging, the residual-force QP (float64), termination, reward, the optional
 // in-launch reset and the 617-float observation (HandObjMimic4.step after do_simulation, ho_im4.py:631-662)
-template <int PART>      // POST_ALL: everything after the substeps; POST_B: the reward part of the split form (record-only inputs)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
+// WPE: resident wavefronts per SIMD the register budget is set for: 3 = 168 registers (a post-step workgroup costs what a substep
+// workgroup costs; the float64 active-set QP spills 146 values at that budget, inside the branch the envs with a hand-object
+// contact take), 2 = 256 registers (80 B of scratch left; such a wavefront needs a SIMD with at most one substep wavefront on it).
+// HOIC_POSTB_WIDE=1 selects the wide build for the split form's reward part (A/B on the contact-rich workload).
+template <int PART, int WPE = 3>      // POST_ALL: everything after the substeps; POST_B: the reward part of the split form (record-only inputs)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void hoic_poststep_kernel(const DevModel* __restrict__ mp, const DevConfig* __restrict__ cp,
                                                            DevExpert ex, DevState st, const float* __restrict__ action,
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            float* __restrict__ reward_info, int* __restrict__ flags,
@@ -653,6 +657,7 @@ struct hoic_sim {
                       hipStream_t sub = nullptr; int sub_reserve = 0; hipEvent_t in_ready = nullptr; };   // CU-masked substep stream (hoic_set_cu_reserve)
   int reserve_cus = 0;
   bool async_reward = false;
+  bool postb_wide = false;   // HOIC_POSTB_WIDE=1: the split form's reward part on its 256-register build (hoic_poststep_kernel<POST_B, 2>)
   std::vector<AsyncRange> ranges;
   int expert_reserve = 0, expert_cap = 0;   // streaming: room for more frames behind the last sequence
   std::vector<int> h_seq_len, h_seq_off;
@@ -1021,6 +1026,7 @@ extern "C" hoic_sim* hoic_create(const void* model_blob, size_t nbytes, int32_t 
   // 2048-env launch, rollout +3 % (+4 % on a tracking policy).  Whole-batch launches gain nothing measurable.
   s->reorder = !(getenv("HOIC_REORDER") != nullptr && getenv("HOIC_REORDER")[0] == '0');
   s->use_lag = getenv("HOIC_NO_LAGREC") == nullptr;
+  s->postb_wide = getenv("HOIC_POSTB_WIDE") != nullptr;
   hipDeviceSynchronize();
   return s;
 }
@@ -1253,8 +1259,12 @@ static int32_t step_range(hoic_sim* s, int first, int count, const float* d_acti
       hipLaunchKernelGGL(hoic_order_kernel, dim3(1), dim3(ORDER_NT), 0, r->side, s->st.cost, s->st.order, s->n_envs, first, count);
       HIPCHK(hipEventRecord(r->ord_done, r->side)); r->order_ready = true;
     }
-    hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
-                       d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
+    if (s->postb_wide)
+      hipLaunchKernelGGL((hoic_poststep_kernel<POST_B, 2>), dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                         d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
+    else
+      hipLaunchKernelGGL(hoic_poststep_kernel<POST_B>, dim3(count), dim3(NT), 0, r->side, s->d_model, s->d_cfg, s->ex, s->st, d_action, d_obs,
+                         d_reward, d_reward_info, d_flags, d_percent, d_next_seq, d_next_start, first, 0, s->n_envs, buf);
     HIPCHK(hipEventRecord(r->rew_done[buf], r->side)); r->pending[buf] = true;
     if (e) { hipEventRecord(e[2], r->side); s->n_timed++; }      // "post-step" time of this form: end of the substeps -> end of the reward part
     HIPCHK(hipGetLastError());

@@ -631,10 +631,12 @@ __global__ __launch_bounds__(256) void hoic_rowsum_packed_kernel(const u16* __re
 
 // ---------------------------------------------------------------------------------------------- rollout forward
 // The policy's forward pass DURING the rollout runs next to the simulator's substep kernel, whose workgroups hold every
-// CU's LDS (12 x 12.5 KB) and, with two of its wavefronts on a SIMD, 336 of the 512 registers: a GEMM whose workgroups need LDS
-// queues behind them (the hipBLASLt float32 GEMMs of the 2048-row batches took 6 ms of a 36 ms rollout that way).  This kernel
-// needs NO LDS and 152 registers (the room beside two substep wavefronts is 176), so its wavefronts start at once as a third
-// wavefront per SIMD: operands go from L2 straight into MFMA registers, which asks for a layout in which a wavefront's operand load is one contiguous kilobyte --
+// CU's LDS (12 x 12.5 KB) and, at three 168-register wavefronts on a SIMD, 504 of its 512 registers: a GEMM whose workgroups need
+// LDS queues behind them (the hipBLASLt float32 GEMMs of the 2048-row batches took 6 ms of a 36 ms rollout that way).  This kernel
+// needs NO LDS and 152 registers: its wavefronts start on every SIMD that holds at most two substep wavefronts (the room beside
+// two is 176 registers) -- a third of the wave slots are empty over a rollout because a launch ends with its slowest env, which is
+// where this kernel runs; on a SIMD with three substep wavefronts nothing else becomes resident.  Operands go from L2 straight
+// into MFMA registers, which asks for a layout in which a wavefront's operand load is one contiguous kilobyte --
 // "tiled" format T of a matrix [R x K]: tile (a, s) = rows 32 a .. + 31, k = 16 s .. + 15, 2 KB at ((a K/16 + s) * 2048):
 //   hi plane [64 lanes x 16 B], then lo plane; lane = 32 hf + l31 holds row 32 a + l31, k = 16 s + 8 hf .. + 7.
 // One wavefront per workgroup computes 32 rows (m) x 64 columns (n): D = W X^T per tile, i.e. lane = row m, registers =

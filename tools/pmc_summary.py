@@ -61,7 +61,27 @@ def main():
     b.add_argument("--out", required=True); b.add_argument("--command", default=""); b.add_argument("--build-id", default=None)
     c = sub.add_parser("stats")
     c.add_argument("--dir", required=True); c.add_argument("--out", required=True)
+    e = sub.add_parser("clock", help="GRBM_GUI_ACTIVE / duration per kernel: the shader clock a kernel ran at (GRBM_GUI_ACTIVE sums the 8 XCDs)")
+    e.add_argument("--dir", required=True); e.add_argument("--out", required=True); e.add_argument("--min-us", type=float, default=100.0)
     args = ap.parse_args()
+    if args.cmd == "clock":
+        acc = defaultdict(list)
+        for f in glob.glob(os.path.join(args.dir, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] != "GRBM_GUI_ACTIVE":
+                    continue
+                us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+                if us >= args.min_us:
+                    acc[(row["Kernel_Name"][:100], row["Grid_Size"])].append((float(row["Counter_Value"]), us))
+        out = {"what": "per kernel (name, grid size): launches, mean duration (us), mean GRBM_GUI_ACTIVE, GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration", "kernels": []}
+        for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+            g, us = sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)
+            out["kernels"].append({"kernel": name, "grid": grid, "launches": len(v), "dur_us": round(us, 1), "GRBM_GUI_ACTIVE": round(g), "GHz": round(g / 8 / us / 1e3, 3)})
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(out, open(args.out, "w"), indent=1)
+        for k in out["kernels"][:30]:
+            print(k)
+        return
     if args.cmd == "counters":
         per, launches = {}, 0
         for d in args.dir:
