@@ -34,6 +34,13 @@ template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[
   // the palm) skips that batch; tail (wave-uniform): entries 10, 11 -- no body of the HOIC hand has more than ten dofs on its
   // path (palm 6 + finger 4: DevModel::max_path), so they would be two masked-off gathers in every call
   const unsigned pk[3] = {path[0], path[1], path[2]};
+  // The tables' LDS addresses as (wave-uniform) base registers: an entry's address is then ONE multiply-add, d * 24 + base, and
+  // its three two-word reads carry their offsets as immediates.  Left to itself the compiler forms d * 24 and adds the table's
+  // 11 KB offset separately for every read (three adds per table and entry: the offset does not fit the reads' 8-bit fields).
+  LPTR(const float) Sb = (LPTR(const float))&w.S[0][0];
+  LPTR(const float) xb = (LPTR(const float))x;
+  LPTR(const float) eb = (LPTR(const float))(EXTRA ? &extra[0][0] : &w.S[0][0]);
+  asm volatile("" : "+s"(Sb), "+s"(xb), "+s"(eb));
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     if (h == 1) { __builtin_amdgcn_sched_barrier(0); if (!second) break; }   // two batches of six gathers in flight, not twelve (register peak)
@@ -44,12 +51,14 @@ template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[
       const bool on = e < (unsigned)below;
       const int d = on ? (int)e : 0;
       const float msk = on ? 1.f : 0.f;
-      const float xd = x[d] * msk;               // unconditional loads (index 0 when off): no exec-masked branches
+      const float xd = xb[d] * msk;              // unconditional loads (index 0 when off): no exec-masked branches
+      LPTR(const float) Sd = Sb + 6 * d;
 #pragma unroll
-      for (int k = 0; k < 6; k++) V[k] = fmaf(w.S[d][k], xd, V[k]);
+      for (int k = 0; k < 6; k++) V[k] = fmaf(Sd[k], xd, V[k]);
       if (EXTRA) {
+        LPTR(const float) ed = eb + 6 * d;
 #pragma unroll
-        for (int k = 0; k < 6; k++) A[k] = fmaf(extra[d][k], msk, A[k]);
+        for (int k = 0; k < 6; k++) A[k] = fmaf(ed[k], msk, A[k]);
       }
     }
   }
@@ -60,6 +69,11 @@ template <bool EXTRA> HD void path_gather(const Work& w, const unsigned (&path)[
 // multiply-adds run in the order of path_gather, so every product is bit-identical to a separate pass
 template <int NX> HD void path_gather_multi(const Work& w, const unsigned (&path)[3], const float* const (&x)[NX], float (&V)[NX][6], bool second, bool tail) {
   const unsigned pk[3] = {path[0], path[1], path[2]};
+  LPTR(const float) Sb = (LPTR(const float))&w.S[0][0];      // (base registers: see path_gather)
+  LPTR(const float) xb[NX];
+#pragma unroll
+  for (int v = 0; v < NX; v++) { xb[v] = (LPTR(const float))x[v]; asm volatile("" : "+s"(xb[v])); }
+  asm volatile("" : "+s"(Sb));
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     if (h == 1) { __builtin_amdgcn_sched_barrier(0); if (!second) break; }
@@ -71,11 +85,12 @@ template <int NX> HD void path_gather_multi(const Work& w, const unsigned (&path
       const int d = on ? (int)e : 0;
       const float msk = on ? 1.f : 0.f;
       float Sd[6];
+      LPTR(const float) Sp = Sb + 6 * d;
 #pragma unroll
-      for (int k = 0; k < 6; k++) Sd[k] = w.S[d][k];
+      for (int k = 0; k < 6; k++) Sd[k] = Sp[k];
 #pragma unroll
       for (int v = 0; v < NX; v++) {
-        const float xd = x[v][d] * msk;
+        const float xd = xb[v][d] * msk;
 #pragma unroll
         for (int k = 0; k < 6; k++) V[v][k] = fmaf(Sd[k], xd, V[v][k]);
       }
@@ -298,18 +313,34 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
   const unsigned am = vd ? (m.dof_amask[d] | (1u << d)) : 0u, dm = vd ? m.dof_dmask[d] : 0u;
   const float arm = vd ? m.dof_armature[d] : 0.f;
   const int hi = tid >> 5;
+  // Row j = MREG_ROW(reg, hi) = jc(reg) + 4 hi: the half-wave's share goes into per-lane bases (and pre-shifted masks), so that
+  // every entry's LDS reads carry their offsets as immediates (one address add per read otherwise: the two tables sit 8 KB apart)
+  // and its mask tests are bit extracts at constant positions.  Per half-wave uniform addresses: LDS broadcasts.
+  LPTR(const float) Sb = (LPTR(const float))&w.S[4 * hi][0];
+  LPTR(const float) fb = (LPTR(const float))&w.sc.dyn.u.f.fS[4 * hi][0];
+  asm volatile("" : "+v"(Sb), "+v"(fb));      // (kept as two base registers: folded back into one base + 8 KB constants otherwise)
+  const unsigned amh = am >> (4 * hi), dmh = dm >> (4 * hi);
+  const int dh = d - 4 * hi;
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int j = MREG_ROW(reg, hi);          // per half-wave uniform: LDS broadcasts
-    const float a = dot6(w.S[j], fSi), bb = dot6(Si, w.sc.dyn.u.f.fS[j]);
-    float v = ((am >> j) & 1u) ? a : (((dm >> j) & 1u) ? bb : 0.f);
-    if (j == d) v += arm;
-    // The entry is pinned where it is computed: on the path that leaves the substep loop after a failed substep M is not read
-    // again, so the optimiser would otherwise sink the 16 x 12 multiply-adds behind the collision stage (past that exit) and keep
-    // the 192 LDS values they read alive across it -- 231 spilled registers at the 168-register budget.  (The armature used to be
-    // a conditional LDS read per entry, which happened to hold the arithmetic in place.)
-    asm volatile("" : "+v"(v));
-    M.r[reg] = v;
+  for (int rp = 0; rp < 16; rp += 2) {       // two entries at a time: their 24 LDS reads share one round trip
+    float vv[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int jc = ((rp + q) & 3) + 8 * ((rp + q) >> 2);
+      float sj[6], fj[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { sj[k] = Sb[6 * jc + k]; fj[k] = fb[6 * jc + k]; }
+      const float a = dot6(sj, fSi), bb = dot6(Si, fj);
+      float v = ((amh >> jc) & 1u) ? a : (((dmh >> jc) & 1u) ? bb : 0.f);
+      if (jc == dh) v += arm;
+      vv[q] = v;
+    }
+    // The entries are pinned where they are computed: on the path that leaves the substep loop after a failed substep M is not
+    // read again, so the optimiser would otherwise sink the 16 x 12 multiply-adds behind the collision stage (past that exit) and
+    // keep the 192 LDS values they read alive across it -- 231 spilled registers at the 168-register budget.  (The armature used
+    // to be a conditional LDS read per entry, which happened to hold the arithmetic in place.)
+    asm volatile("" : "+v"(vv[0]), "+v"(vv[1]));
+    M.r[rp] = vv[0]; M.r[rp + 1] = vv[1];
   }
   wsync();
 }

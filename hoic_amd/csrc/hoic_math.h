@@ -7,6 +7,8 @@
 // (loaded from a table in memory) is one: accesses become global_load/store instead of flat ones
 #define GPTR(T) T __attribute__((address_space(1)))*
 template <class T> HD GPTR(T) as_global(T* p) { return (GPTR(T))p; }
+// pointer into the workgroup's LDS as such (address space 3, 32 bits)
+#define LPTR(T) T __attribute__((address_space(3)))*
 // Ordering point between lanes of ONE wavefront that talk through LDS (every workgroup of the simulator kernels is a
 // single wavefront).  The LDS pipeline executes a wave's instructions in order, so a ds_read issued after a ds_write
 // sees it without any wait; all that is needed is that the compiler keeps the order.  __syncthreads() drains every
