@@ -693,11 +693,17 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
     const int pool = p < m.npair ? m.pair_pool[p] : -1;
     LaneContacts lc{0, &w.col_lc[tid], w.col_pool[max(pool, 0)], pool >= 0 ? COLSLOT + 2 : COLSLOT};
     int g1 = 0, g2 = 0;
+    float pmargin = 0.f;
     bool isbb = false, ismesh = false;
     if (p < m.npair) {
       g1 = m.pair_geom1[p]; g2 = m.pair_geom2[p];
       const int t1 = m.pair_type1[p], t2 = m.pair_type2[p];
       const float bound = m.pair_bound[p];
+      // (the pair's sizes and margin are fetched with its other constants, not behind the bounding-sphere test: one global-load
+      //  latency for the stage instead of one per nesting level)
+      const float z1[3] = {m.pair_size1[p][0], m.pair_size1[p][1], m.pair_size1[p][2]};
+      const float z2[3] = {m.pair_size2[p][0], m.pair_size2[p][1], m.pair_size2[p][2]};
+      pmargin = m.pair_margin[p];
       const float* p1 = w.gxpos[g1]; const float* R1 = w.gxmat[g1];
       const float* p2 = w.gxpos[g2]; const float* R2 = w.gxmat[g2];
       bool test;
@@ -718,7 +724,6 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         // switches the test off: tests/test_gpu_parity.py test_obb_reject_only_drops_contacts_of_separated_pairs).  What
         // it saves is the pair's turn in the sequential box-box / hull routines (four of five hull turns found nothing) and,
         // when no lane is left, the capsule-box routine.
-        const float* z1 = m.pair_size1[p]; const float* z2 = m.pair_size2[p];
         const bool cap1 = t1 == HOIC_GEOM_CAPSULE, cap2 = t2 == HOIC_GEOM_CAPSULE, hull2 = t2 == HOIC_GEOM_MESH;
         const float h1[3] = {z1[0], cap1 ? z1[0] : z1[1], cap1 ? z1[1] + z1[0] : z1[2]};
         float h2[3] = {z2[0], cap2 ? z2[0] : z2[1], cap2 ? z2[1] + z2[0] : z2[2]}, c2[3] = {0.f, 0.f, 0.f};
@@ -727,7 +732,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
 #pragma unroll
           for (int i = 0; i < 3; i++) { c2[i] = 0.5f * (m.mesh_aabb[me][i] + m.mesh_aabb[me][4 + i]); h2[i] = 0.5f * (m.mesh_aabb[me][4 + i] - m.mesh_aabb[me][i]); }
         }
-        if (obb_separated(p2, R2, c2, h2, p1, R1, h1, m.pair_margin[p])) test = false;
+        if (obb_separated(p2, R2, c2, h2, p1, R1, h1, pmargin)) test = false;
       }
       isbb = test && t1 == HOIC_GEOM_BOX && t2 == HOIC_GEOM_BOX;
       ismesh = test && t2 == HOIC_GEOM_MESH;
@@ -736,7 +741,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         // in the mesh frame (the principal axes: a long object's box is far tighter than its bounding sphere).  A pair
         // farther apart than the margin can only produce contacts that the margin filter below drops: same contact list.
         const int me = m.pair_mesh[p];
-        const float mg = m.pair_margin[p];
+        const float mg = pmargin;
         float q[3], d1[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
         mattvec(R2, d1, q);                              // geom1 centre (plane: a point of it) in the mesh frame
         if (t1 != HOIC_GEOM_PLANE) {
@@ -759,8 +764,7 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
         }
       }
       if (test && !isbb && !ismesh) {
-        const float s1[3] = {m.pair_size1[p][0], m.pair_size1[p][1], m.pair_size1[p][2]};
-        const float s2[3] = {m.pair_size2[p][0], m.pair_size2[p][1], m.pair_size2[p][2]};
+        const float* s1 = z1; const float* s2 = z2;
         if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_CAPSULE) col_plane_capsule(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_PLANE && t2 == HOIC_GEOM_BOX) col_plane_box(p1, R1, p2, R2, s2, lc);
         else if (t1 == HOIC_GEOM_CAPSULE && t2 == HOIC_GEOM_CAPSULE) col_capsule_capsule(p1, R1, s1, p2, R2, s2, lc);
@@ -819,9 +823,8 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
     // margin filter, then the survivors go from the staging column to their positions in the contact list
     int cnt = 0;
     unsigned keepm = 0;
-    float margin = 0.f;
+    const float margin = pmargin;
     if (p < m.npair) {
-      margin = m.pair_margin[p];
       for (int q = 0; q < lc.n; q++) if (lc_at(lc, q, 0) < margin) { keepm |= 1u << q; cnt++; }
     }
     // exclusive prefix sum of per-lane counts over the wave
@@ -831,9 +834,15 @@ __device__ __forceinline__ void dev_collision(const DevModel& m, Work& w, int* o
     for (int q = 0; q < lc.n; q++) {
       if ((keepm >> q) & 1u) {
         if (c < MAXCON) {
-          w.c_dist[c] = lc_at(lc, q, 0); w.c_pair[c] = (unsigned char)p; w.c_g1[c] = (unsigned char)g1; w.c_g2[c] = (unsigned char)g2;
-          for (int i = 0; i < 3; i++) { w.c_pos[c][i] = lc_at(lc, q, 1 + i); w.c_frame[c][i] = lc_at(lc, q, 4 + i); }
-          make_frame(w.c_frame[c]);
+          // (the frame is completed in registers and stored once: built in place in LDS, every step of make_frame was a
+          //  dependent LDS round trip, four contacts of one pair one after the other)
+          float fr[9], ps[3];
+          const float dd = lc_at(lc, q, 0);
+          for (int i = 0; i < 3; i++) { ps[i] = lc_at(lc, q, 1 + i); fr[i] = lc_at(lc, q, 4 + i); }
+          make_frame(fr);
+          w.c_dist[c] = dd; w.c_pair[c] = (unsigned char)p; w.c_g1[c] = (unsigned char)g1; w.c_g2[c] = (unsigned char)g2;
+          for (int i = 0; i < 3; i++) w.c_pos[c][i] = ps[i];
+          for (int i = 0; i < 9; i++) w.c_frame[c][i] = fr[i];
         }
         c++;
       }

@@ -106,6 +106,20 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
   // 0. lane = joint: joint rotation quaternion / slide displacement (all sincos calls in parallel, constants by
   //    independent loads); parked in the inertia scratch, which is not written before step 3
   float (*jrec)[12] = reinterpret_cast<float (*)[12]>(&w.sc.dyn.I10[0][0]);   // [axis 3 | pos 3 | quat 4 or disp | type]
+  // The model constants of steps 1 and 2 are fetched here, under step 0, and those of step 3 under the pointer-jumping rounds:
+  // behind the hand-over point that precedes their use, each group was one more exposed global-load latency of the stage's chain
+  // (a fence keeps a load on its side of it).
+  int ja = 0, jn = 0, jump[MAXROUND];
+  float bpos[3] = {0.f, 0.f, 0.f}, bquat[4] = {1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < MAXROUND; r++) jump[r] = -1;
+  if (isb) {
+    ja = m.body_jntadr[tid]; jn = m.body_jntnum[tid];
+    for (int i = 0; i < 3; i++) bpos[i] = m.body_pos[tid][i];
+    for (int i = 0; i < 4; i++) bquat[i] = m.body_quat[tid][i];
+#pragma unroll
+    for (int r = 0; r < MAXROUND; r++) jump[r] = m.body_jump[r][tid];
+  }
   if (tid < m.njnt) {
     const int j = tid, ty = m.jnt_type[j], qa = m.jnt_qposadr[j];
     float* r = jrec[j];
@@ -119,10 +133,10 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
   wsync();
   // 1. transform of each body relative to its parent, with the joint axes / anchors in the parent frame
   if (isb) {
-    const int b = tid, ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+    const int b = tid;
     const bool jz = m.jnt_poszero != 0;       // wave-uniform
-    for (int i = 0; i < 3; i++) P[i] = m.body_pos[b][i];
-    for (int i = 0; i < 4; i++) Q[i] = m.body_quat[b][i];
+    for (int i = 0; i < 3; i++) P[i] = bpos[i];
+    for (int i = 0; i < 4; i++) Q[i] = bquat[i];
     for (int j = ja; j < ja + jn; j++) {
       const float* r = jrec[j];
       const int ty = __float_as_int(r[10]);
@@ -168,9 +182,29 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
     for (int i = 0; i < 4; i++) w.xquat[b][i] = Q[i];
   }
   wsync();
+  // (constants of step 3, in flight during the rounds below)
+  float ip[3] = {0.f, 0.f, 0.f}, iq[4] = {1.f, 0.f, 0.f, 0.f}, bmass = 0.f, binr[3] = {0.f, 0.f, 0.f};
+  if (isb) {
+    for (int i = 0; i < 3; i++) { ip[i] = m.body_ipos[tid][i]; binr[i] = m.body_inertia[tid][i]; }
+    for (int i = 0; i < 4; i++) iq[i] = m.body_iquat[tid][i];
+    bmass = m.body_mass[tid];
+  }
+  int dj = 0, dty = 0, dbody = 0, dk = 0, dpar = 0;
+  if (tid < m.nv) { dj = m.dof_jntid[tid]; dty = m.dof_jtype[tid]; dbody = m.dof_bodyid[tid]; dk = m.dof_k[tid]; dpar = m.dof_parentbody[tid]; }
+  int gbody = 0; float gp[3] = {0.f, 0.f, 0.f}, gq[4] = {1.f, 0.f, 0.f, 0.f};
+  {
+    const int g = tid - 32;
+    if (g >= 0 && g < m.ngeom) {
+      gbody = m.geom_bodyid[g];
+      for (int i = 0; i < 3; i++) gp[i] = m.geom_pos[g][i];
+      for (int i = 0; i < 4; i++) gq[i] = m.geom_quat[g][i];
+    }
+  }
   // 2. pointer jumping: after round r a body's transform is relative to its ancestor 2^(r+1) levels up
-  for (int r = 0; r < m.nround; r++) {
-    const int src = isb ? m.body_jump[r][tid] : -1;
+#pragma unroll
+  for (int r = 0; r < MAXROUND; r++) {
+    if (r >= m.nround) break;
+    const int src = jump[r];
     if (src >= 0) {
       float Ps[3], Qs[4], t[3], qn[4];
       for (int i = 0; i < 3; i++) Ps[i] = w.xpos[src][i];
@@ -196,14 +230,12 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
   // 3a. per body: spatial inertia about the world origin (m, h = m c, Io: xx yy zz xy xz yz)
   if (isb) {
     const int b = tid;
-    const float ip[3] = {m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]};
-    const float iq[4] = {m.body_iquat[b][0], m.body_iquat[b][1], m.body_iquat[b][2], m.body_iquat[b][3]};
     float c[3], t[3], qi[4], Ri[9];
     qrot(Q, ip, t);
     for (int i = 0; i < 3; i++) c[i] = P[i] + t[i];
     mulquat(Q, iq, qi);
     quat2mat(qi, Ri);
-    const float mass = m.body_mass[b], p0 = m.body_inertia[b][0], p1 = m.body_inertia[b][1], p2 = m.body_inertia[b][2];
+    const float mass = bmass, p0 = binr[0], p1 = binr[1], p2 = binr[2];
     float Ic[6];  // xx yy zz xy xz yz about the centre of mass
     Ic[0] = Ri[0] * p0 * Ri[0] + Ri[1] * p1 * Ri[1] + Ri[2] * p2 * Ri[2];
     Ic[1] = Ri[3] * p0 * Ri[3] + Ri[4] * p1 * Ri[4] + Ri[5] * p2 * Ri[5];
@@ -219,10 +251,10 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
   }
   // 3b. per dof: motion axis about the origin (the joint frames of step 1 moved to the world by the parent pose)
   if (tid < m.nv) {
-    const int d = tid, j = m.dof_jntid[d], ty = m.dof_jtype[d], b = m.dof_bodyid[d];
+    const int d = tid, j = dj, ty = dty, b = dbody;
     float* S = w.S[d];
     if (ty == HOIC_JNT_FREE) {
-      const int kk = m.dof_k[d];
+      const int kk = dk;
       if (kk < 3) { for (int i = 0; i < 6; i++) S[i] = (i == 3 + kk) ? 1.f : 0.f; }
       else {
         const float e[3] = {kk == 3 ? 1.f : 0.f, kk == 4 ? 1.f : 0.f, kk == 5 ? 1.f : 0.f};
@@ -232,7 +264,7 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
         cross3(w.xpos[b], ax, S + 3);
       }
     } else {
-      const int p = m.dof_parentbody[d];
+      const int p = dpar;
       const float la[3] = {w.sc.dyn.u.j.jax[j][0], w.sc.dyn.u.j.jax[j][1], w.sc.dyn.u.j.jax[j][2]};
       float ax[3];
       qrot(w.xquat[p], la, ax);
@@ -252,9 +284,7 @@ template <class W> __device__ __forceinline__ void dev_kinematics(const DevModel
   {
     const int g = tid - 32;
     if (g >= 0 && g < m.ngeom) {
-      const int b = m.geom_bodyid[g];
-      const float gp[3] = {m.geom_pos[g][0], m.geom_pos[g][1], m.geom_pos[g][2]};
-      const float gq[4] = {m.geom_quat[g][0], m.geom_quat[g][1], m.geom_quat[g][2], m.geom_quat[g][3]};
+      const int b = gbody;
       float t[3], qg[4];
       qrot(w.xquat[b], gp, t);
       for (int i = 0; i < 3; i++) w.gxpos[g][i] = w.xpos[b][i] + t[i];
@@ -282,6 +312,14 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
   // composite inertias in two rounds (DevModel::body_sum): small subtrees directly, then the bodies above them from their
   // children's composites -- the longest loop is SUM_DIRECT / the largest child count instead of the whole hand
   const int smode = tid < m.nbody ? m.body_sum[tid] : 0;
+  // (every model constant of the stage is fetched here: behind the hand-over points below each would be one more exposed
+  //  global-load latency)
+  const int dlane = opaque(tid & 31);
+  const bool vdl = dlane < m.nv;
+  const unsigned k0 = smode == 2 ? m.body_kids[tid][0] : 0xFFFFFFFFu, k1 = smode == 2 ? m.body_kids[tid][1] : 0xFFFFFFFFu;
+  const int dbody_ = vdl ? m.dof_bodyid[dlane] : 0;
+  const unsigned am = vdl ? (m.dof_amask[dlane] | (1u << dlane)) : 0u, dm = vdl ? m.dof_dmask[dlane] : 0u;
+  const float arm = vdl ? m.dof_armature[dlane] : 0.f;
   if (smode == 1) {
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
@@ -294,7 +332,6 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
   if (smode == 2) {
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = w.sc.dyn.I10[tid][i];
-    const unsigned k0 = m.body_kids[tid][0], k1 = m.body_kids[tid][1];
     for (int k = 0; k < 8; k++) {
       const unsigned c = ((k < 4 ? k0 : k1) >> (8 * (k & 3))) & 0xFFu;
       if (c == 0xFFu) break;
@@ -303,15 +340,13 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
   wsync();   // (also: the joint frames in sc.dyn.u.j are dead from here on, u.f takes their place)
-  const int d = opaque(tid & 31);
-  const bool vd = d < m.nv;
+  const int d = dlane;
+  const bool vd = vdl;
   float Si[6], fSi[6];
   for (int i = 0; i < 6; i++) { Si[i] = vd ? w.S[d][i] : 0.f; fSi[i] = 0.f; }
-  if (vd) inert_mul(w.sc.dyn.Ic[m.dof_bodyid[d]], Si, fSi);
+  if (vd) inert_mul(w.sc.dyn.Ic[dbody_], Si, fSi);
   if (tid < 32) for (int i = 0; i < 6; i++) w.sc.dyn.u.f.fS[d][i] = fSi[i];
   wsync();
-  const unsigned am = vd ? (m.dof_amask[d] | (1u << d)) : 0u, dm = vd ? m.dof_dmask[d] : 0u;
-  const float arm = vd ? m.dof_armature[d] : 0.f;
   const int hi = tid >> 5;
   // Row j = MREG_ROW(reg, hi) = jc(reg) + 4 hi: the half-wave's share goes into per-lane bases (and pre-shifted masks), so that
   // every entry's LDS reads carry their offsets as immediates (one address add per read otherwise: the two tables sit 8 KB apart)
@@ -378,6 +413,11 @@ HD void cross_force(const float* v, const float* f, float* o) {
 //   f_b = I_b A_b + V_b x* I_b V_b;  subtree range sums;  bias_d = S_d . fsub_body(d)
 __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float* qvel) {
   const int tid = opaque(threadIdx.x);
+  // (the stage's model constants, fetched ahead of the hand-over points: see dev_mass_matrix)
+  const int smode = tid < m.nbody ? m.body_sum[tid] : 0;
+  const int sub_end = smode == 1 ? tid + m.body_subtree[tid] : 0;
+  const unsigned k0 = smode == 2 ? m.body_kids[tid][0] : 0xFFFFFFFFu, k1 = smode == 2 ? m.body_kids[tid][1] : 0xFFFFFFFFu;
+  const int dbody_ = tid < m.nv ? m.dof_bodyid[tid] : 0;
   if (tid < m.nv) {
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sd[6];
     const unsigned pth[3] = {m.dof_bpath[tid][0], m.dof_bpath[tid][1], m.dof_bpath[tid][2]};
@@ -401,10 +441,9 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
   }
   wsync();
   {   // subtree force sums, kept in the Ic slots: the two rounds of the composite inertias
-    const int smode = tid < m.nbody ? m.body_sum[tid] : 0;
     if (smode == 1) {
       float sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int e = tid + m.body_subtree[tid];
+      const int e = sub_end;
       for (int b = tid; b < e; b++)
         for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.u.f.cfrc[b][i];
       for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
@@ -413,7 +452,6 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     if (smode == 2) {
       float sub[6];
       for (int i = 0; i < 6; i++) sub[i] = w.sc.dyn.u.f.cfrc[tid][i];
-      const unsigned k0 = m.body_kids[tid][0], k1 = m.body_kids[tid][1];
       for (int k = 0; k < 8; k++) {
         const unsigned c = ((k < 4 ? k0 : k1) >> (8 * (k & 3))) & 0xFFu;
         if (c == 0xFFu) break;
@@ -423,7 +461,7 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     }
   }
   wsync();
-  if (tid < NV) w.bias[tid] = (tid < m.nv) ? dot6(w.S[tid], w.sc.dyn.Ic[m.dof_bodyid[tid]]) : 0.f;
+  if (tid < NV) w.bias[tid] = (tid < m.nv) ? dot6(w.S[tid], w.sc.dyn.Ic[dbody_]) : 0.f;
   wsync();
 }
 
