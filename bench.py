@@ -122,7 +122,21 @@ def update_gemm_roofline(samples, device):
             "kernel": "hoic_gemm_f16x3_k16_kernel<EPI_FWD> (2048 -> 1024 layer, bias + GELU + repack fused)", "kernel_ms": ms,
             "M": Mr, "N": N, "K": K, "f16_mfma_flops_per_launch": 3 * 2.0 * Mr * N * K,
             "note": "peak = dense f16 MFMA at the nominal clock; with random operands this kernel runs against the board's power limit "
-                    "(all-zero operands: 20 % faster, same instruction stream; measured clock under this load 1.75 GHz of 2.4)"}
+                    "(all-zero operands: 20 % faster, same instruction stream; measured clock under this load 1.75 GHz of 2.4)",
+            "vendor_library_at_equal_mfma_flops": "hipBLASLt f16 (f32 accumulate) of 53248 x 1024 x 6144, the MFMA work of this launch, sustains "
+                                                  "1.01 (NN) / 1.13 (NT) PFLOP/s on random operands = 0.41 / 0.45 of the peak, 1.28-1.34 on all-zero "
+                                                  "operands (profiles/r05_gemm_calibrate_hipblaslt.json, same box as profiles/r05_gemm_bench_same_box.json)"}
+
+
+def update_mfma_frac_overall(samples, update_s, hidden=(2048, 1024, 512), k0=640, epochs=5):
+    """f16 MFMA flops of one PPO update (both networks, `epochs` epochs: forward, weight gradients of all layers, data gradients
+    of the layers above the first; the value network's first forward serves the returns and epoch 0) over the measured update
+    time, against the dense f16 peak."""
+    dims = [(k0, hidden[0])] + [(hidden[i - 1], hidden[i]) for i in range(1, len(hidden))]
+    fwd = sum(k * n for k, n in dims); dgrad = sum(k * n for k, n in dims[1:])
+    macs = 2 * epochs * (2 * fwd + dgrad)              # per sample: fwd + wgrad + dgrad, two networks
+    flops = 3 * 2.0 * macs * samples
+    return {"f16_mfma_flops_per_update": flops, "update_s": update_s, "achieved_tflops": flops / update_s / 1e12, "frac_of_2500": flops / update_s / 2.5e15}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -476,6 +490,7 @@ def main():
         }
         if args.update_dtype == "f16x3":
             out["roofline_update_gemm"] = update_gemm_roofline(steps_per_iter * args.envs, torch.device("cuda", local_rank))
+            out["update_mfma_frac_overall"] = update_mfma_frac_overall(steps_per_iter * args.envs, t_update / n_it)
         if (args.other_configs and world == 1 and args.obj == "box" and args.workload == "train" and args.sample_mode == "fixed"
                 and not args.pretrain and args.envs == 4096):
             agent.env.close()

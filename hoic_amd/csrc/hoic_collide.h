@@ -385,58 +385,156 @@ HD float hull_run_bound(const HullRef& h, int r, float x, float y, float z) {
   return b + (2e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + fabsf(c.w)) + 1e-8f);
 }
 // max over the faces of n.x - d at the point (x, y, z) (hull frame); pl = that face (the first one in face order on ties)
+// Round trips to the (L2-resident) tables are what a query costs -- a capsule pair makes two to five queries one after the other,
+// each two to three dependent reads deep in round 4 -- so: every lane keeps the plane of its best face in registers (the winner's
+// is read across the wave at the end: no final table read), and the runs that pass 1 leaves in play are fetched up to EIGHT per
+// trip (four per half-wave, all four loads in flight) instead of two.  Fetching a run that a raised bar would have pruned changes
+// nothing: the maximum and its first index are those of the runs that reach the final bar.
 HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
   const int lane = threadIdx.x;
   if (h.np <= 0) { pl[0] = pl[1] = pl[2] = pl[3] = 0.f; return -1e30f; }      // a mesh without face planes (wave-uniform): no face, nothing to index
   float bv = -1e30f; int bi = 0x00ffffff;
+  f4v bp = {0.f, 0.f, 0.f, 0.f};
   if (!h.prune || h.np <= HULL_STREAM_BELOW) {          // (small hulls: a handful of streaming passes cost less than bounds + visits)
     for (int t = lane; t < h.np; t += NT) {          // ascending index per lane: '>' keeps the lane's first maximum
-      const float v = hull_plane_val(h.pl[t], x, y, z);
-      if (v > bv) { bv = v; bi = t; }
+      const f4v p = h.pl[t];
+      const float v = hull_plane_val(p, x, y, z);
+      if (v > bv) { bv = v; bi = t; bp = p; }
     }
   } else {
     // pass 1, lane = run (a second sub-pass for hulls of more than 64 runs): the run's upper bound, and its first face as a
     // value that is certainly attained
     float ub0 = -1e30f, ub1 = -1e30f;
-    if (lane < h.nfr) { ub0 = hull_run_bound(h, lane, x, y, z); bv = hull_plane_val(h.pl[lane * HOIC_HULL_RUN_FACES], x, y, z); bi = lane * HOIC_HULL_RUN_FACES; }
+    if (lane < h.nfr) {
+      ub0 = hull_run_bound(h, lane, x, y, z);
+      const f4v p = h.pl[lane * HOIC_HULL_RUN_FACES];
+      bv = hull_plane_val(p, x, y, z); bi = lane * HOIC_HULL_RUN_FACES; bp = p;
+    }
     if (h.nfr > NT && lane + NT < h.nfr) {
       ub1 = hull_run_bound(h, lane + NT, x, y, z);
-      const float v = hull_plane_val(h.pl[(lane + NT) * HOIC_HULL_RUN_FACES], x, y, z);
-      if (v > bv) { bv = v; bi = (lane + NT) * HOIC_HULL_RUN_FACES; }
+      const f4v p = h.pl[(lane + NT) * HOIC_HULL_RUN_FACES];
+      const float v = hull_plane_val(p, x, y, z);
+      if (v > bv) { bv = v; bi = (lane + NT) * HOIC_HULL_RUN_FACES; bp = p; }
     }
     float best = wave_max(bv);
-    // pass 2: the runs that can still reach `best`, two per pass (one per half-wave), in ascending run order, so that a
+    // pass 2: the runs that can still reach `best`, eight per trip (four per half-wave) in ascending run order, so that a
     // lane meets its faces in ascending table order and '>' keeps its first maximum
-    float fv = -1e30f; int fi = 0x00ffffff;
+    // (a lane's running best (bv, bi, bp) takes a face when it is larger, or equal with a smaller index: the selection "largest
+    //  value, first index" does not depend on the order in which candidates are met)
     const int half = lane >> 5, sub = lane & 31;
 #pragma unroll 1
     for (int part = 0; part < 2; part++) {
       if (part == 1 && h.nfr <= NT) break;
       unsigned long long mask = __ballot((part ? ub1 : ub0) >= best);
       while (mask) {
-        const int ra = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        int rb = -1;
-        if (mask) { rb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-        const int r = (half ? rb : ra) + part * NT;
-        const int t = r * HOIC_HULL_RUN_FACES + sub;
-        if ((half ? rb : ra) >= 0 && t < h.np) {
-          const float v = hull_plane_val(h.pl[t], x, y, z);
-          if (v > fv) { fv = v; fi = t; }
+        int tq[4]; bool on[4]; f4v pq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int ra = -1, rb = -1;
+          if (mask) { ra = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+          if (mask) { rb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+          const int rr = half ? rb : ra;
+          tq[q] = (rr + part * NT) * HOIC_HULL_RUN_FACES + sub;
+          on[q] = rr >= 0 && tq[q] < h.np;
+          pq[q] = h.pl[on[q] ? tq[q] : 0];
         }
-        if (mask) {                                  // more candidates: raise the bar with what this pass found
-          best = fmaxf(best, wave_max(fv));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float v = hull_plane_val(pq[q], x, y, z);
+          if (on[q] && (v > bv || (v == bv && tq[q] < bi))) { bv = v; bi = tq[q]; bp = pq[q]; }
+        }
+        if (mask) {                                  // more candidates: raise the bar with what this trip found
+          best = fmaxf(best, wave_max(bv));
           mask &= __ballot((part ? ub1 : ub0) >= best);
         }
       }
     }
-    if (fv > bv || (fv == bv && fi < bi)) { bv = fv; bi = fi; }
   }
   const float mx = wave_max(bv);
   const int idx = min((int)wave_min(bv == mx ? (float)bi : 1e9f), h.np - 1);     // indices < 2^24 are exact in float32 (the clamp: non-finite query points)
-  const f4v w = h.pl[idx];                                         // wave-uniform address
-  pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
+  const unsigned long long win = __ballot(bv == mx && bi == idx);
+  if (win) {                                           // the winner's plane, from its registers
+    const int L = __ffsll((long long)win) - 1;
+    pl[0] = rl(bp.x, L); pl[1] = rl(bp.y, L); pl[2] = rl(bp.z, L); pl[3] = rl(bp.w, L);
+  } else {                                             // (non-finite query point: no lane compares equal)
+    const f4v w = h.pl[idx];                           // wave-uniform address
+    pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
+  }
   return mx;
+}
+// The same query at TWO points at once (the two ends of a capsule's axis: a few centimetres apart, so the runs in play are
+// largely the same): one pass 1 (the run bounds' table reads are shared), and every face row fetched in pass 2 is evaluated at
+// both points -- a row that only one point needed is harmless for the other (see above).  Results per point are those of
+// hull_max_wave, bit for bit: the same faces' values, largest value, first index.
+HD void hull_max_wave2(const HullRef& h, const float* a, const float* b, float* pla, float* plb, float& va, float& vb) {
+  const int lane = threadIdx.x;
+  if (h.np <= 0 || !h.prune || h.np <= HULL_STREAM_BELOW) {     // (wave-uniform: small hulls stream, one point after the other)
+    va = hull_max_wave(h, a[0], a[1], a[2], pla); vb = hull_max_wave(h, b[0], b[1], b[2], plb);
+    return;
+  }
+  float bva = -1e30f, bvb = -1e30f; int bia = 0x00ffffff, bib = 0x00ffffff;
+  f4v bpa = {0.f, 0.f, 0.f, 0.f}, bpb = {0.f, 0.f, 0.f, 0.f};
+  float uba0 = -1e30f, uba1 = -1e30f, ubb0 = -1e30f, ubb1 = -1e30f;
+#pragma unroll
+  for (int part = 0; part < 2; part++) {
+    const int r = lane + part * NT;
+    if (part == 1 && h.nfr <= NT) break;
+    if (r < h.nfr) {
+      const float ua = hull_run_bound(h, r, a[0], a[1], a[2]), ub = hull_run_bound(h, r, b[0], b[1], b[2]);
+      if (part) { uba1 = ua; ubb1 = ub; } else { uba0 = ua; ubb0 = ub; }
+      const int t = r * HOIC_HULL_RUN_FACES;
+      const f4v p = h.pl[t];
+      const float wa = hull_plane_val(p, a[0], a[1], a[2]), wb = hull_plane_val(p, b[0], b[1], b[2]);
+      if (wa > bva) { bva = wa; bia = t; bpa = p; }
+      if (wb > bvb) { bvb = wb; bib = t; bpb = p; }
+    }
+  }
+  float besta = wave_max(bva), bestb = wave_max(bvb);
+  const int half = lane >> 5, sub = lane & 31;
+#pragma unroll 1
+  for (int part = 0; part < 2; part++) {
+    if (part == 1 && h.nfr <= NT) break;
+    unsigned long long mask = __ballot((part ? uba1 : uba0) >= besta || (part ? ubb1 : ubb0) >= bestb);
+    while (mask) {
+      int tq[4]; bool on[4]; f4v pq[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        int ra = -1, rb = -1;
+        if (mask) { ra = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        if (mask) { rb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        const int rr = half ? rb : ra;
+        tq[q] = (rr + part * NT) * HOIC_HULL_RUN_FACES + sub;
+        on[q] = rr >= 0 && tq[q] < h.np;
+        pq[q] = h.pl[on[q] ? tq[q] : 0];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float wa = hull_plane_val(pq[q], a[0], a[1], a[2]), wb = hull_plane_val(pq[q], b[0], b[1], b[2]);
+        if (on[q] && (wa > bva || (wa == bva && tq[q] < bia))) { bva = wa; bia = tq[q]; bpa = pq[q]; }
+        if (on[q] && (wb > bvb || (wb == bvb && tq[q] < bib))) { bvb = wb; bib = tq[q]; bpb = pq[q]; }
+      }
+      if (mask) {
+        besta = fmaxf(besta, wave_max(bva)); bestb = fmaxf(bestb, wave_max(bvb));
+        mask &= __ballot((part ? uba1 : uba0) >= besta || (part ? ubb1 : ubb0) >= bestb);
+      }
+    }
+  }
+#pragma unroll
+  for (int w2 = 0; w2 < 2; w2++) {
+    const float bv = w2 ? bvb : bva; const int bi = w2 ? bib : bia; const f4v bp = w2 ? bpb : bpa;
+    float* pl = w2 ? plb : pla;
+    const float mx = wave_max(bv);
+    const int idx = min((int)wave_min(bv == mx ? (float)bi : 1e9f), h.np - 1);
+    const unsigned long long win = __ballot(bv == mx && bi == idx);
+    if (win) {
+      const int L = __ffsll((long long)win) - 1;
+      pl[0] = rl(bp.x, L); pl[1] = rl(bp.y, L); pl[2] = rl(bp.z, L); pl[3] = rl(bp.w, L);
+    } else {
+      const f4v w = h.pl[idx];
+      pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
+    }
+    if (w2) vb = mx; else va = mx;
+  }
 }
 // the sequential "keep the four deepest" of one pair's contact list, state held uniformly: n, the four distances
 struct Deep4 { int n; float d0, d1, d2, d3; };
@@ -524,8 +622,11 @@ __device__ __forceinline__ int col_capsule_mesh_wave(const HullRef& h, const flo
   for (int i = 0; i < 3; i++) { a[i] = pc[i] - cs[1] * al[i]; d[i] = 2.f * cs[1] * al[i]; }
   const float r = cs[0];
   float p0[4], p1[4], pm[4], pl_[4], pr_[4];
-  const float v0 = hull_max_wave(h, a[0], a[1], a[2], p0);
-  const float v1 = hull_max_wave(h, a[0] + d[0], a[1] + d[1], a[2] + d[2], p1);
+  float v0, v1;
+  {
+    const float e1[3] = {a[0] + d[0], a[1] + d[1], a[2] + d[2]};
+    hull_max_wave2(h, a, e1, p0, p1, v0, v1);
+  }
   const float s0 = p0[0] * d[0] + p0[1] * d[1] + p0[2] * d[2];
   const float s1 = p1[0] * d[0] + p1[1] * d[1] + p1[2] * d[2];
   float ts, vs, nmin[3];
