@@ -321,10 +321,19 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
   const unsigned am = vdl ? (m.dof_amask[dlane] | (1u << dlane)) : 0u, dm = vdl ? m.dof_dmask[dlane] : 0u;
   const float arm = vdl ? m.dof_armature[dlane] : 0.f;
   if (smode == 1) {
+    // (at most SUM_DIRECT bodies: unrolled with the rows beyond the subtree masked off, so that all reads are in flight at once --
+    //  a loop with a per-lane trip count paid one LDS round trip per body)
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
-    const int e = tid + m.body_subtree[tid];
-    for (int b = tid; b < e; b++)
+    const int nsub = m.body_subtree[tid];
+#pragma unroll
+    for (int k = 0; k < SUM_DIRECT; k++) {
+      const bool on = k < nsub;
+      const float* row = w.sc.dyn.I10[on ? tid + k : tid];
+      const float msk = on ? 1.f : 0.f;
+      for (int i = 0; i < 10; i++) acc[i] = fmaf(row[i], msk, acc[i]);
+    }
+    for (int b = tid + SUM_DIRECT; b < tid + nsub; b++)      // (a tree the two-round plan does not fit: plain range sums, build_model)
       for (int i = 0; i < 10; i++) acc[i] += w.sc.dyn.I10[b][i];
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
@@ -332,10 +341,18 @@ __device__ __forceinline__ void dev_mass_matrix(const DevModel& m, Work& w, MReg
   if (smode == 2) {
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = w.sc.dyn.I10[tid][i];
-    for (int k = 0; k < 8; k++) {
-      const unsigned c = ((k < 4 ? k0 : k1) >> (8 * (k & 3))) & 0xFFu;
-      if (c == 0xFFu) break;
-      for (int i = 0; i < 10; i++) acc[i] += w.sc.dyn.Ic[c][i];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {          // the children four at a time (masked), their reads in flight together
+      const unsigned kk = h ? k1 : k0;
+      if (kk == 0xFFFFFFFFu) break;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned c = (kk >> (8 * k)) & 0xFFu;
+        const bool on = c != 0xFFu;
+        const float* row = w.sc.dyn.Ic[on ? c : (kk & 0xFFu)];      // (masked-off slots re-read the batch's first child: a finite row)
+        const float msk = on ? 1.f : 0.f;
+        for (int i = 0; i < 10; i++) acc[i] = fmaf(row[i], msk, acc[i]);
+      }
     }
     for (int i = 0; i < 10; i++) w.sc.dyn.Ic[tid][i] = acc[i];
   }
@@ -443,8 +460,15 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
   {   // subtree force sums, kept in the Ic slots: the two rounds of the composite inertias
     if (smode == 1) {
       float sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int e = sub_end;
-      for (int b = tid; b < e; b++)
+      const int nsub = sub_end - tid;
+#pragma unroll
+      for (int k = 0; k < SUM_DIRECT; k++) {      // (unrolled and masked: see dev_mass_matrix)
+        const bool on = k < nsub;
+        const float* row = w.sc.dyn.u.f.cfrc[on ? tid + k : tid];
+        const float msk = on ? 1.f : 0.f;
+        for (int i = 0; i < 6; i++) sub[i] = fmaf(row[i], msk, sub[i]);
+      }
+      for (int b = tid + SUM_DIRECT; b < sub_end; b++)
         for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.u.f.cfrc[b][i];
       for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
     }
@@ -452,10 +476,18 @@ __device__ __forceinline__ void dev_bias(const DevModel& m, Work& w, const float
     if (smode == 2) {
       float sub[6];
       for (int i = 0; i < 6; i++) sub[i] = w.sc.dyn.u.f.cfrc[tid][i];
-      for (int k = 0; k < 8; k++) {
-        const unsigned c = ((k < 4 ? k0 : k1) >> (8 * (k & 3))) & 0xFFu;
-        if (c == 0xFFu) break;
-        for (int i = 0; i < 6; i++) sub[i] += w.sc.dyn.Ic[c][i];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const unsigned kk = h ? k1 : k0;
+        if (kk == 0xFFFFFFFFu) break;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned c = (kk >> (8 * k)) & 0xFFu;
+          const bool on = c != 0xFFu;
+          const float* row = w.sc.dyn.Ic[on ? c : (kk & 0xFFu)];      // (masked-off slots re-read the batch's first child: a finite row)
+          const float msk = on ? 1.f : 0.f;
+          for (int i = 0; i < 6; i++) sub[i] = fmaf(row[i], msk, sub[i]);
+        }
       }
       for (int i = 0; i < 6; i++) w.sc.dyn.Ic[tid][i] = sub[i];
     }
