@@ -7,8 +7,7 @@ mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
 BID=$(python3 -c "from hoic_amd import lib; print(lib.build_id())")
 J='import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d["value"]), "rollout", round(d["rollout_only_env_steps_per_s"]), "update_s", round(d["update_s_per_iteration"],5), "substep_ms", round(d["roofline"]["kernel_ms"],3), d["workload_stats"])'
 if [ "$PART" = 1 ]; then
-timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/r05_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/r05_pytest_gpu.log
-for i in 1 2 3; do timeout 400 python bench.py > gpurun_out/r05_bench_box_$i.json 2> gpurun_out/r05_bench_box.err; python -c "$J" gpurun_out/r05_bench_box_$i.json; done
+for i in 1 2 3; do timeout 600 python bench.py > gpurun_out/r05_bench_box_$i.json 2> gpurun_out/r05_bench_box.err; python -c "$J" gpurun_out/r05_bench_box_$i.json; done
 timeout 300 python bench.py --pretrain 60 --no-cpu-baseline --min-iterations 10 > gpurun_out/r05_bench_box_tracking.json 2>/dev/null; python -c "$J" gpurun_out/r05_bench_box_tracking.json
 timeout 400 python bench.py --workload closed-grasp --pretrain 100 --no-cpu-baseline --min-iterations 10 > gpurun_out/r05_bench_box_closed_grasp.json 2>/dev/null; python -c "$J" gpurun_out/r05_bench_box_closed_grasp.json
 for o in bottle banana; do timeout 300 python bench.py --obj $o --no-cpu-baseline --min-iterations 10 > gpurun_out/r05_bench_$o.json 2>/dev/null; python -c "$J" gpurun_out/r05_bench_$o.json; done
