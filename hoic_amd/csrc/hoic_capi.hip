@@ -59,7 +59,7 @@ template <class W> __device__ __forceinline__ void store_state(const DevState& s
 __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, float* a0_out, bool shift_warm) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   float fs = 0.f;
-  if (d < m.nv) fs = -m.dof_damping[d] * w.qvel[d] - w.bias[d] + w.applied[d];   // passive (joint damping) - bias + applied + actuation
+  if (d < m.nv) fs = -w.k_damp[d] * w.qvel[d] - w.bias[d] + w.applied[d];   // passive (joint damping) - bias + applied + actuation
   PT(20);
   float a0 = dev_hsolve<false>(m, w, M, 0.f, m.nv, fs); PT(8);     // unconstrained acceleration
   a0 = (d < m.nv) ? a0 : 0.f;
@@ -67,8 +67,9 @@ __device__ __forceinline__ bool dev_forward_dyn(const DevModel& m, const DevConf
   if (tid < NV) w.sc.vec.x[tid] = a0;           // a_smooth as an LDS vector for the first row evaluation (dead once Newton starts)
   wsync();
   RowK rk;
-  dev_make_constraint(m, w, rk, w.qpos, w.qvel); PT(7);
-  dev_solve(m, w, M, rk, w.qvel, fs, a0, cfg.c.solver_iterations, shift_warm); PT(9);
+  DofK dk;
+  dev_make_constraint(m, w, rk, dk, w.qpos, w.qvel); PT(7);
+  dev_solve(m, w, M, rk, dk, w.qvel, fs, a0, cfg.c.solver_iterations, shift_warm); PT(9);
   // mj_checkPos / mj_checkVel / mj_checkAcc [MJ-doc]: a non-finite or huge (> 1e10) entry of qpos, qvel or qacc is MuJoCo's
   // "Nan, Inf or huge value" warning, which mujoco_py raises and the env turns into fail = True (ho_im4.py:635-637)
   float bad = 0.f;
@@ -86,7 +87,7 @@ __device__ __forceinline__ void dev_euler(const DevModel& m, Work& w, const MReg
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const float h = m.timestep;
   const float rhs = (d < m.nv) ? w.ftot[d] : 0.f;
-  const float damp = (d < m.nv) ? m.dof_damping[d] : 0.f;
+  const float damp = w.k_damp[d];
   PT(20);
   const float acc = dev_hsolve<false>(m, w, M, h * damp, m.nv, rhs);
   if (gqlag) {
@@ -275,8 +276,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const DevModel& ml = *(const DevModel*)mq; const DevConfig& cl = *(const DevConfig*)cq;
     PT(0);
     if (mode == 1) {
+      const PdFetch pf = dev_pd_fetch(ml, cl, ev, act);
       dev_record_contact(ml, w, post); PT(2);          // :543 (contacts of the previous forward pass)
-      dev_pd_torque(ml, cl, w, M, ev, act); PT(1);     // :518-523
+      dev_pd_torque(ml, cl, w, M, pf); PT(1);          // :518-523
       dev_applied(ml, cl, w, act);                     // :526-540
     }
     if (mode == 0) {   // the lagged pass runs on (qlag, vlag): into the workspace's state for the pass, the state proper comes back below

@@ -21,6 +21,7 @@
 __device__ __forceinline__ void dev_load_constants(const DevModel& m, Work& w) {
   const int t = threadIdx.x;
   if (t < NB) for (int i = 0; i < 3; i++) w.k_bpath[t][i] = t < m.nbody ? m.body_path[t][i] : 0xFFFFFFFFu;
+  if (t < NV) w.k_damp[t] = t < m.nv ? m.dof_damping[t] : 0.f;
   wsync();
 }
 

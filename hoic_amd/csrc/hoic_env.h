@@ -33,17 +33,29 @@ __device__ __forceinline__ void dev_forward_kin(const DevModel& m, const DevConf
 
 // ---- stable PD torque (ho_im4.py:412-486) using M (registers) and bias (LDS) of the previous forward pass
 // act: this env's row of the action buffer (global memory; clipped on the fly, ho_im4.py:613)
-__device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const ExpertView& ev, GPTR(const float) act) {
+// What dev_pd_torque reads from global memory for dof lane & 31 (expert frame, action, gains): fetched at the head of the substep,
+// ahead of dev_record_contact, so that the two dependent read latencies (expert table pointer, then the row) pass under that
+// stage instead of in front of the PD solve.  Raw values only: the arithmetic -- and with it the wait -- stays in dev_pd_torque.
+struct PdFetch { float ref, act, base, scale, kp, kd; };
+__device__ __forceinline__ PdFetch dev_pd_fetch(const DevModel& m, const DevConfig& cfg, const ExpertView& ev, GPTR(const float) act) {
+  const int d = opaque(threadIdx.x) & 31;
+  PdFetch f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (d < m.hand_nv) {
+    GPTR(const float) ref = as_global(ev.ex->hand_dof) + (size_t)ev.frame(cfg.c.pd_ref_offset) * m.hand_nq;   // 0; 1 in the streaming env
+    f.ref = ref[d]; f.act = act[d]; f.base = cfg.base_pose[d]; f.scale = cfg.ctrl_scale[d]; f.kp = cfg.c.jkp[d]; f.kd = cfg.c.jkd[d];
+  }
+  return f;
+}
+__device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig& cfg, Work& w, const MReg& M, const PdFetch& pf) {
   const int tid = opaque(threadIdx.x), d = tid & 31, n = m.hand_nv;
   const float dt = m.timestep;
   float err = 0.f, kp = 0.f, kd = 0.f, qv = 0.f, rhs = 0.f;
   if (d < n) {
-    GPTR(const float) ref = as_global(ev.ex->hand_dof) + (size_t)ev.frame(cfg.c.pd_ref_offset) * m.hand_nq;   // 0; 1 in the streaming env
     float target;
-    const float a = fminf(fmaxf(act[d], -1.f), 1.f);
-    if (d < 3) target = ref[d] + 0.1f * a;
-    else if (d < 6) target = ref[d] + 0.3f * a;
-    else target = (cfg.c.pd_rel ? ref[d] : cfg.base_pose[d]) + cfg.ctrl_scale[d] * a;
+    const float a = fminf(fmaxf(pf.act, -1.f), 1.f);
+    if (d < 3) target = pf.ref + 0.1f * a;
+    else if (d < 6) target = pf.ref + 0.3f * a;
+    else target = (cfg.c.pd_rel ? pf.ref : pf.base) + pf.scale * a;
     qv = w.qvel[d];
     err = w.qpos[d] + qv * dt - target;
     if (d >= 3) {
@@ -53,7 +65,7 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
       for (int k = 0; k < 16 && err > 3.14159265358979f; k++) err -= 6.28318530717959f;
       for (int k = 0; k < 16 && err < -3.14159265358979f; k++) err += 6.28318530717959f;
     }
-    kp = cfg.c.jkp[d]; kd = cfg.c.jkd[d];
+    kp = pf.kp; kd = pf.kd;
     rhs = -w.bias[d] - kp * err - kd * qv;
   }
   PT(20);

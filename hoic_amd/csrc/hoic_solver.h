@@ -340,8 +340,10 @@ HD float cost_onesided(float D, float jar, float& force, float& curv) {
 }
 
 // ---- constraint rows for the current kinematics / contacts
-__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, const float* qpos, const float* qvel) {
+__device__ __forceinline__ void dev_make_constraint(const DevModel& m, Work& w, RowK& rk, DofK& dk, const float* qpos, const float* qvel) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
+  // (the friction-loss constants of dev_solve are fetched with this stage's per-dof constants: one global-read latency for both)
+  dk.floss = d < m.nv ? m.dof_frictionloss[d] : 0.f; dk.flR = d < m.nv ? m.dof_flR[d] : 1.f;
   // friction loss and joint limit of dof d (one side per joint can be active: every range is wider than twice
   // the margin; slide and hinge joints have exactly one dof)
   rk.f_aref = 0.f; rk.l_sign = 0.f; rk.l_D = 0.f; rk.l_aref = 0.f;
@@ -524,7 +526,7 @@ __device__ __forceinline__ float dev_jt_force(const DevModel& m, Work& w, const 
 // start (w.qacc), rows.  Out: w.qacc, w.ftot = f_smooth + J'f (LDS).
 // The row residuals jar, M qacc and qacc itself are carried along and updated by alpha * (J s, M s, s) after each
 // line search (as MuJoCo's solver does), so an iteration costs one Jacobian product, not three.
-__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const float* qvel, float fs, float a0, int maxit, bool shift_warm) {
+__device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg& M, const RowK& rk, const DofK& dk, const float* qvel, float fs, float a0, int maxit, bool shift_warm) {
   const int tid = opaque(threadIdx.x), d = tid & 31;
   const bool vd = d < m.nv;
   const float scale = frcp(m.meaninertia * (float)max(m.nv, 1));
@@ -541,7 +543,6 @@ __device__ __forceinline__ void dev_solve(const DevModel& m, Work& w, const MReg
   }
   const float wm = w.qacc[d];
   const int nrow = w.nrow;
-  const DofK dk{vd ? m.dof_frictionloss[d] : 0.f, vd ? m.dof_flR[d] : 1.f};
   float D_c[NCSLOT];
 #pragma unroll
   for (int k = 0; k < NCSLOT; k++) { const int r = tid + k * NT; D_c[k] = (r < nrow) ? w.c_D[w.cr_ce[r] >> 3] : 0.f; }

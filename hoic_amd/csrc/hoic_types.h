@@ -242,6 +242,8 @@ struct Work {
   float c_pos[MAXCON][3], c_frame[MAXCON][9], c_dist[MAXCON];
   unsigned char c_pair[MAXCON], c_g1[MAXCON], c_g2[MAXCON];
   unsigned k_bpath[NB][3];             // packed dof paths of the bodies (model constant, loaded once per launch)
+  float k_damp[NV];                    // joint damping per dof (model constant, loaded once per launch: read at the head of two of a
+                                       // substep's solves, where a global read was an exposed latency each time)
   float applied[NV], bias[NV], ftot[NV];   // applied + actuator forces; bias forces; f_smooth + J'f of the last solve
   float S[NV][6];                      // motion axes [angular; linear at the world origin]
 #ifdef HOIC_PHASE_TIMING
