@@ -657,17 +657,20 @@ class AgentHandMimic:
                 sl = slice(first, first + count)
                 ctx = torch.cuda.stream(self._streams[gi]) if use_streams else contextlib.nullcontext()
                 with ctx:
+                    eng = fwd[gi] if (fwd is not None and direct) else None      # the filter launch also writes the forward's operand
+                    filt = forks[gi] if (use_streams and not frozen) else self.running_state
                     if frozen:
                         raw_all[t, sl] = obs[sl]
                         state = (torch.clamp(obs[sl], -5.0, 5.0).to(dt) if identity else
-                                 self.running_state(obs[sl], update=False, out=states[t, sl] if direct else None))
+                                 filt(obs[sl], update=False, out=states[t, sl] if direct else None, tiled=eng))
                     else:
-                        state = (forks[gi] if use_streams else self.running_state)(obs[sl], out=states[t, sl] if direct else None)
+                        state = filt(obs[sl], out=states[t, sl] if direct else None, tiled=eng)
+                    packed = bool(getattr(filt, "last_call_packed", False)) and not (frozen and identity)
                     if state.data_ptr() != states[t, sl].data_ptr():
                         states[t, sl] = state
                     if direct:
                         if fwd is not None:
-                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state), out=actions[t, sl], std=std, eps=noise_all[t, sl])
+                            action = self.policy_net.select_action_from_hidden(fwd[gi].forward(state, prepacked=packed), out=actions[t, sl], std=std, eps=noise_all[t, sl])
                         else:
                             # library GEMMs: never from two streams at once (the BLAS library's stream-K kernels share their
                             # flag workspace per handle and deadlock when two of them interleave) -- a range's

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <string>
 #include "../../include/hoic.h"
+#include "hoic_zfilter_core.h"
 
 extern "C" const char* hoic_last_error(void);
 void hoic_set_error(const std::string& s);    // hoic_capi.hip
@@ -662,6 +663,78 @@ __global__ __launch_bounds__(64) void hoic_pack_tiled_kernel(const float* __rest
   *(u32x4*)t = hi; *(u32x4*)(t + 1024) = lo;
 }
 
+// ---- the sampler's observation filter and the forward's operand in ONE launch (round 5): running-filter update, normalisation
+// of the range's observations (float32 rows for the batch) AND their split into format T for hoic_fwd_tiled_kernel, plus the
+// exponent refresh of the engine's hidden-activation slots -- four launches of a range's chain (filter moments, filter apply,
+// hoic_update_exps, hoic_pack_tiled) as one, with no inter-workgroup dependency: a workgroup owns a strip of 16 columns x 128
+// rows and computes the moments of ALL chunks of its 16 columns itself (thread = (chunk, column): exactly the per-chunk
+// arithmetic of hoic_zfilter_moments_kernel; the observations are L2-resident, the sixteen-fold re-read is 80 MB of L2 traffic),
+// merges them in chunk order (hoic_zfilter_core.h: the same source as the two-launch form, so states and filter are bit-identical),
+// then normalises and packs its own 128 rows.  Needs n % 128 == 0 and n <= 2048 (one thread per chunk and column).
+__global__ __launch_bounds__(256) void hoic_zfilter_tiled_kernel(const float* __restrict__ x, int n, int dim, const double* __restrict__ state_in,
+                                                                 double* __restrict__ state_out, int update, float clip, float* __restrict__ y,
+                                                                 char* __restrict__ T, int Kp, int* __restrict__ exps, int slot_x,
+                                                                 float* __restrict__ amax, int nslots, unsigned long long mask, int target,
+                                                                 int* __restrict__ overflow) {
+  __shared__ double s_mean[16][16], s_m2[16][16], s_mu[16], s_rd[16];
+  const int tid = threadIdx.x, strip = blockIdx.x, rowblk = blockIdx.y;
+  const int nchunk = n / ZF_ROWS;
+  {   // hidden-activation exponents of the forward engine from the last pass's maxima (hoic_update_exps_kernel, delayed slots)
+    if (strip == 0 && rowblk == 0 && tid < nslots && ((mask >> tid) & 1ull)) {
+      const float m = amax[tid];
+      if (m > 0.f && isfinite(m)) {
+        int ex; frexpf(m, &ex);
+        if (ldexpf(m, exps[tid]) > 60000.f && overflow) atomicAdd(overflow, 1);
+        exps[tid] = target - ex;
+      } else if (!isfinite(m) && overflow) atomicAdd(overflow, 1);
+      amax[tid] = 0.f;
+    }
+  }
+  if (update) {
+    const int c = tid & 15, k = tid >> 4, col = strip * 16 + c;
+    if (col < dim && k < nchunk) zf_chunk_moments(x, dim, col, k * ZF_ROWS, (k + 1) * ZF_ROWS, s_mean[k][c], s_m2[k][c]);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int col = strip * 16 + tid;
+    double mu = 0.0, rd = 0.0;
+    if (col < dim) {
+      double cnt = state_in[0], mean = state_in[1 + col], S = state_in[1 + dim + col];
+      if (update) {
+        for (int k = 0; k < nchunk; k++) zf_merge(cnt, mean, S, (double)ZF_ROWS, s_mean[k][tid], s_m2[k][tid]);
+        if (rowblk == 0) {
+          state_out[1 + col] = mean; state_out[1 + dim + col] = S;
+          if (col == 0) state_out[0] = cnt;
+        }
+      }
+      mu = mean; rd = zf_rden(cnt, mean, S);
+    }
+    s_mu[tid] = mu; s_rd[tid] = rd;
+  }
+  __syncthreads();
+  // normalise + pack: wavefront w of the workgroup = tile row a = 4 rowblk + w, k step = strip; lane (l31, hf) = row 32 a + l31,
+  // columns 16 strip + 8 hf .. + 7 (the lane mapping of hoic_pack_tiled_kernel)
+  const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int a = 4 * rowblk + wv, r = 32 * a + l31, c0 = 16 * strip + 8 * hf;
+  const float sc = ldexpf(1.f, exps[slot_x]);
+  const double lim = (double)clip;
+  unsigned w[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float v = 0.f;
+    if (c0 + k < dim) {
+      v = zf_apply(x[(size_t)r * dim + c0 + k], s_mu[8 * hf + k], s_rd[8 * hf + k], lim);
+      y[(size_t)r * dim + c0 + k] = v;
+    }
+    w[k] = pack_hl(v * sc);
+  }
+  u32x4 hi, lo;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { hi[k] = (w[2 * k] & 0xffffu) | (w[2 * k + 1] << 16); lo[k] = (w[2 * k] >> 16) | (w[2 * k + 1] & 0xffff0000u); }
+  char* t = T + ((size_t)a * (Kp >> 4) + strip) * 2048 + lane * 16;
+  *(u32x4*)t = hi; *(u32x4*)(t + 1024) = lo;
+}
+
 struct FwdArgs {
   const char* X; const char* W;      // format T: X [M x K], W [N x K]
   int M, N, K;
@@ -1014,6 +1087,19 @@ extern "C" int32_t hoic_mlp_pack_tiled(const float* d_x, int32_t R, int32_t C, i
   }
   const long long n = (long long)(Rp >> 5) * (Kp >> 4);
   hipLaunchKernelGGL(hoic_pack_tiled_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_x, R, C, (long long)ld, (char*)d_T, Rp, Kp, d_exps, slot);
+  MCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int32_t hoic_zfilter_tiled(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out, int32_t update,
+                                      float clip, float* d_y, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x, float* d_amax,
+                                      int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream) {
+  if (n <= 0 || dim <= 0 || !d_x || !d_state_in || !d_y || !d_T || !d_exps || (n % ZF_ROWS) || n > 16 * ZF_ROWS || Kp < dim || (Kp & 15) ||
+      nslots < 0 || nslots > 64 || (mask && !d_amax)) {
+    hoic_set_error("hoic_zfilter_tiled: n must be a multiple of 128 and at most 2048, Kp a multiple of 16 and >= dim"); return HOIC_ERR_ARG;
+  }
+  if (update && (!d_state_out || d_state_out == d_state_in)) { hoic_set_error("hoic_zfilter_tiled: update needs a state_out that is not state_in"); return HOIC_ERR_ARG; }
+  hipLaunchKernelGGL(hoic_zfilter_tiled_kernel, dim3((unsigned)(Kp >> 4), (unsigned)(n / ZF_ROWS)), dim3(256), 0, (hipStream_t)stream, d_x, n, dim,
+                     d_state_in, d_state_out, update, clip, d_y, (char*)d_T, Kp, d_exps, slot_x, d_amax, nslots, (unsigned long long)mask, target, d_overflow);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

@@ -9,8 +9,8 @@
 // depend on the launch geometry.  Two launches replace ~30 small tensor kernels of the host mirror.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "hoic_zfilter_core.h"
 
-#define ZF_ROWS 128      // rows per chunk
 #define ZF_NT 64
 
 // partial[(chunk * dim + col) * 2 + {0, 1}] = mean, M2 of the chunk's rows
@@ -19,23 +19,10 @@ __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_moments_kernel(const float
   const int col = blockIdx.x * ZF_NT + threadIdx.x, chunk = blockIdx.y;
   if (col >= dim) return;
   const int r0 = chunk * ZF_ROWS, r1 = min(r0 + ZF_ROWS, n);
-  const float* p = x + (size_t)r0 * dim + col;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int r = r0;
-  for (; r + 4 <= r1; r += 4, p += (size_t)4 * dim) {
-    s0 += (double)p[0]; s1 += (double)p[dim]; s2 += (double)p[2 * (size_t)dim]; s3 += (double)p[3 * (size_t)dim];
-  }
-  for (; r < r1; r++, p += dim) s0 += (double)p[0];
-  const double mean = ((s0 + s1) + (s2 + s3)) / (double)(r1 - r0);
-  p = x + (size_t)r0 * dim + col;
-  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-  for (r = r0; r + 4 <= r1; r += 4, p += (size_t)4 * dim) {
-    const double d0 = (double)p[0] - mean, d1 = (double)p[dim] - mean, d2 = (double)p[2 * (size_t)dim] - mean, d3 = (double)p[3 * (size_t)dim] - mean;
-    q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
-  }
-  for (; r < r1; r++, p += dim) { const double d0 = (double)p[0] - mean; q0 += d0 * d0; }
+  double mean, m2;
+  zf_chunk_moments(x, dim, col, r0, r1, mean, m2);
   partial[((size_t)chunk * dim + col) * 2] = mean;
-  partial[((size_t)chunk * dim + col) * 2 + 1] = (q0 + q1) + (q2 + q3);
+  partial[((size_t)chunk * dim + col) * 2 + 1] = m2;
 }
 
 // state = (count, mean[dim], S[dim]).  Every workgroup merges the chunks of its 64 columns itself (a few hundred
@@ -51,11 +38,7 @@ __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_apply_kernel(const float* 
     const int nchunk = (n + ZF_ROWS - 1) / ZF_ROWS;
     for (int c = 0; c < nchunk; c++) {
       const double nb = (double)(min((c + 1) * ZF_ROWS, n) - c * ZF_ROWS);
-      const double mb = partial[((size_t)c * dim + col) * 2], Sb = partial[((size_t)c * dim + col) * 2 + 1];
-      const double tot = cnt + nb, delta = mb - mean;
-      S = S + Sb + delta * delta * cnt * nb / tot;
-      mean = mean + delta * nb / tot;
-      cnt = tot;
+      zf_merge(cnt, mean, S, nb, partial[((size_t)c * dim + col) * 2], partial[((size_t)c * dim + col) * 2 + 1]);
     }
     if (chunk == 0) {
       state_out[1 + col] = mean; state_out[1 + dim + col] = S;
@@ -63,15 +46,11 @@ __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_apply_kernel(const float* 
     }
   }
   if (!y) return;
-  const double var = cnt > 1.0 ? S / fmax(cnt - 1.0, 1.0) : mean * mean;       // zfilter.py:35
-  const double rden = 1.0 / (sqrt(var) + 1e-8);      // one division per column; the rows multiply (float64: the float32 result sees no difference)
+  const double rden = zf_rden(cnt, mean, S);      // one division per column; the rows multiply (float64: the float32 result sees no difference)
   const int r0 = chunk * ZF_ROWS, r1 = min(r0 + ZF_ROWS, n);
   const double lim = (double)clip;
 #pragma unroll 4
-  for (int r = r0; r < r1; r++) {
-    const double v = ((double)x[(size_t)r * dim + col] - mean) * rden;
-    y[(size_t)r * dim + col] = (float)fmin(fmax(v, -lim), lim);
-  }
+  for (int r = r0; r < r1; r++) y[(size_t)r * dim + col] = zf_apply(x[(size_t)r * dim + col], mean, rden, lim);
 }
 
 // ---- generalized advantage estimation over a time-major rollout (khrylib core/common.py:12-19): thread = env, the

@@ -75,6 +75,8 @@ class _Kernels:
         L.hoic_mlp_update_exps_rel.argtypes = [vp, vp, i32, C.c_uint64, i32, i32, vp, vp, vp]
         L.hoic_mlp_pack_tiled.argtypes = [vp, i32, i32, i64, vp, i32, i32, vp, i32, vp]
         L.hoic_mlp_forward_tiled.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+        L.hoic_zfilter_tiled.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, i32, vp, i32, vp, i32, C.c_uint64, i32, vp, vp]
+        L.hoic_zfilter_tiled.restype = i32
         L.hoic_mlp_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
         L.hoic_mlp_head.restype = i32
         L.hoic_mlp_head_backward.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, vp]
@@ -653,12 +655,10 @@ class TiledForward:
             K.chk(K.L.hoic_mlp_pack_tiled(_ptr(W), W.shape[0], W.shape[1], W.stride(0), _ptr(self.WT[i]), self.dims_out[i], self.Kp[i],
                                           _ptr(t.exps), self.SLOT_W0 + i, _stream(self.dev)), "hoic_mlp_pack_tiled")
 
-    @_on_device
-    def forward(self, x):
-        """x: float32 [M, in] (M % 32 == 0) -> float32 [M, out] last hidden activation"""
-        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] % 32 == 0
-        M_ = x.shape[0]
-        K, t, L = kernels(), self.table, len(self.layers)
+    def _prepare(self, M_):
+        """buffers for M_ rows; first pass of a size: fixed start exponents.  Returns the mask of the hidden-activation slots whose
+        delayed exponents are due for a refresh from the last pass's maxima (0 on a first pass)."""
+        t, L = self.table, len(self.layers)
         if self.WT is None:
             self.refresh()
         if self.M != M_:
@@ -667,21 +667,43 @@ class TiledForward:
             self.HT = [torch.empty(M_ * n * 4, dtype=torch.uint8, device=self.dev) for n in self.dims_out[:-1]]
             self.out = torch.empty(M_, self.dims_out[-1], dtype=torch.float32, device=self.dev)
             self.first = True
-        st = _stream(self.dev)
-        if self.x_bound is None:
-            t.measure(self.SLOT_X, x if x.is_contiguous() else x.contiguous()); t.update([self.SLOT_X], exact=True)
-        elif self.first:
+        if self.x_bound is not None and self.first:
             with torch.no_grad():
                 t.exps[self.SLOT_X] = TARGET_LOG2 - int(np.ceil(np.log2(float(self.x_bound))))
+        mask = 0
         if self.first:
             with torch.no_grad():
                 for i in range(L - 1):
                     t.exps[self.SLOT_H0 + i] = 4
             self.first = False
-        elif L > 1:
-            t.update([self.SLOT_H0 + i for i in range(L - 1)])          # hidden activations: last pass's maxima
-        K.chk(K.L.hoic_mlp_pack_tiled(_ptr(x), M_, x.shape[1], x.stride(0), _ptr(self.XT), M_, self.Kp[0], _ptr(t.exps), self.SLOT_X, st),
-              "hoic_mlp_pack_tiled")
+        else:
+            for i in range(L - 1):
+                mask |= 1 << (self.SLOT_H0 + i)
+        return mask
+
+    def fused_filter_ok(self, rows):
+        """hoic_zfilter_tiled can write this engine's operand: known input bound (constant input exponent), rows a multiple of
+        128 and at most 2048"""
+        return self.x_bound is not None and rows % 128 == 0 and 0 < rows <= 2048
+
+    @_on_device
+    def forward(self, x, prepacked=False):
+        """x: float32 [M, in] (M % 32 == 0) -> float32 [M, out] last hidden activation.  ``prepacked``: the operand XT was written
+        (and the delayed exponents refreshed) by hoic_zfilter_tiled through ``BatchZFilter(..., tiled=self)``."""
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] % 32 == 0
+        M_ = x.shape[0]
+        K, t, L = kernels(), self.table, len(self.layers)
+        st = _stream(self.dev)
+        if not prepacked:
+            mask = self._prepare(M_)
+            if self.x_bound is None:
+                t.measure(self.SLOT_X, x if x.is_contiguous() else x.contiguous()); t.update([self.SLOT_X], exact=True)
+            if mask:
+                t.update([self.SLOT_H0 + i for i in range(L - 1)])          # hidden activations: last pass's maxima
+            K.chk(K.L.hoic_mlp_pack_tiled(_ptr(x), M_, x.shape[1], x.stride(0), _ptr(self.XT), M_, self.Kp[0], _ptr(t.exps), self.SLOT_X, st),
+                  "hoic_mlp_pack_tiled")
+        else:
+            assert self.M == M_, "prepacked forward: the operand was written for another batch size"
         A, sa = self.XT, self.SLOT_X
         for i, l in enumerate(self.layers):
             last = i == L - 1

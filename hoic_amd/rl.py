@@ -284,14 +284,35 @@ class BatchZFilter:
     def _device_path(self, x):
         return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.dim
 
-    def _call_device(self, x, update, out=None):
-        """hoic_zfilter: two launches (chunk moments; merge + normalise) instead of ~30 tensor kernels."""
+    def _call_device(self, x, update, out=None, tiled=None):
+        """hoic_zfilter: two launches (chunk moments; merge + normalise) instead of ~30 tensor kernels -- or, with ``tiled`` (a
+        hoic_amd.mlp.TiledForward engine whose operand the normalised rows are), hoic_zfilter_tiled: ONE launch that also writes
+        the engine's operand and refreshes its delayed exponents (bit-identical states and filter)."""
         from . import lib
         import ctypes as C
         L = lib.load()
         x = x.contiguous()
         n = x.shape[0]
         y = out if (out is not None and out.is_contiguous() and out.dtype == torch.float32 and out.shape == x.shape) else torch.empty_like(x)
+        if tiled is not None and tiled.fused_filter_ok(n) and tiled.dims_in[0] == self.dim:
+            from . import mlp as _mlp
+            K = _mlp.kernels()
+            mask = tiled._prepare(n)
+            if update and self._alt is None:
+                self._alt = torch.empty_like(self._st)
+            ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            tb = tiled.table
+            with torch.cuda.device(x.device):
+                rc = K.L.hoic_zfilter_tiled(n, self.dim, ptr(x), ptr(self._st), ptr(self._alt if update else None), int(bool(update)), float(self.clip),
+                                            ptr(y), ptr(tiled.XT), tiled.Kp[0], ptr(tb.exps), tiled.SLOT_X, ptr(tb.amax), _mlp.NSLOT, C.c_uint64(mask),
+                                            _mlp.TARGET_LOG2, ptr(tb.overflow), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise lib.HoicError(f"hoic_zfilter_tiled failed ({rc}): {L.hoic_last_error().decode()}")
+            if update:
+                self._st, self._alt = self._alt, self._st
+            self.last_call_packed = True
+            return y
+        self.last_call_packed = False
         out = scratch = None
         if update:
             if self._alt is None:
@@ -310,10 +331,13 @@ class BatchZFilter:
             self._st, self._alt = self._alt, self._st
         return y
 
-    def __call__(self, x, update=True, out=None):
-        """``out``: optional float32 tensor the normalised rows are written into (device path; otherwise ignored)."""
+    def __call__(self, x, update=True, out=None, tiled=None):
+        """``out``: optional float32 tensor the normalised rows are written into (device path; otherwise ignored).  ``tiled``: a
+        TiledForward engine that consumes the rows next: when the one-launch form applies, its operand is written here and
+        ``self.last_call_packed`` says so (the engine's forward then takes ``prepacked=True``)."""
+        self.last_call_packed = False
         if self._device_path(x) and self._st.device == x.device:
-            return self._call_device(x, update, out)
+            return self._call_device(x, update, out, tiled)
         if update:
             self.push(x)
         # var = S/(n-1), and mean^2 when n == 1 (zfilter.py:35)

@@ -404,7 +404,7 @@ def test_library_reports_the_sources_it_was_built_from():
     (id "unknown") must not pass for the current sources."""
     import hashlib
     csrc = os.path.join(ROOT, "hoic_amd", "csrc")
-    hdr = ["hoic_zfilter.h", "hoic_types.h", "hoic_math.h", "hoic_dynamics.h", "hoic_collide.h", "hoic_solver.h", "hoic_env.h",
+    hdr = ["hoic_zfilter.h", "hoic_zfilter_core.h", "hoic_types.h", "hoic_math.h", "hoic_dynamics.h", "hoic_collide.h", "hoic_solver.h", "hoic_env.h",
            "../../include/hoic.h", "../../include/hoic_model.h"]
     h = hashlib.sha256()
     for f in hdr + ["hoic_capi.hip", "hoic_mlp.hip"]:

@@ -168,6 +168,41 @@ def test_tiled_rollout_forward_matches_float64(rows, bound):
     assert (net(x).double() - ref).abs().max().item() > 0.2 * err
 
 
+@gpu
+@pytest.mark.parametrize("update", [True, False])
+def test_filter_and_forward_operand_in_one_launch_match_the_separate_launches(update):
+    """hoic_zfilter_tiled (round 5: observation filter, the rollout forward's operand and the engine's exponent refresh in ONE launch
+    of a sampler range's chain) against the four launches it replaces -- hoic_zfilter (moments, apply), hoic_mlp_update_exps,
+    hoic_mlp_pack_tiled: normalised states, filter state, operand bytes, exponents and the forward's output are bit-identical, over
+    three consecutive steps (the second and third refresh the delayed exponents), with and without the filter update (frozen mode)."""
+    from hoic_amd.rl import BatchZFilter
+    hidden = (512, 256, 128)
+    net, _ = _nets(hidden, seed=6)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    fa, fb = BatchZFilter(617, clip=5.0, device="cuda"), BatchZFilter(617, clip=5.0, device="cuda")
+    warm = torch.randn(512, 617, device="cuda", generator=g) * 3.0 + 0.5
+    fa(warm); fb(warm)                                   # both filters hold statistics before the compared steps
+    ea, eb = M.TiledForward(net, x_bound=5.0), M.TiledForward(net, x_bound=5.0)
+    assert ea.fused_filter_ok(2048) and not ea.fused_filter_ok(2048 + 64) and not ea.fused_filter_ok(4096)
+    for step in range(3):
+        x = torch.randn(2048, 617, device="cuda", generator=g) * (1.0 + step) + 0.3 * step
+        ya = fa(x, update=update, tiled=ea)
+        assert fa.last_call_packed
+        ha = ea.forward(ya, prepacked=True).clone()
+        yb = fb(x, update=update)
+        assert not fb.last_call_packed
+        hb = eb.forward(yb).clone()
+        assert torch.equal(ya, yb), step
+        assert torch.equal(fa._st, fb._st), step
+        assert torch.equal(ea.XT, eb.XT), step
+        assert torch.equal(ea.table.exps, eb.table.exps), step
+        assert torch.equal(ha, hb), step
+        ea.check_overflow(); eb.check_overflow()
+    # sizes the one-launch form does not take fall back to the separate launches
+    y = fa(torch.randn(96, 617, device="cuda", generator=g), tiled=ea)
+    assert not fa.last_call_packed and y.shape == (96, 617)
+
+
 def test_split_choice_for_the_weight_gradient_kernels():
     """pick_splits16: tiles x splits fill the 512 workgroup slots (two per CU) in whole rounds, no split is empty"""
     for n, k, want in ((2048, 640, 12), (1024, 2048, 8), (512, 1024, 32)):
