@@ -339,6 +339,8 @@ def main():
     ap.add_argument("--min-iterations", type=int, default=30,
                     help="the timed region holds at least this many PPO iterations whatever --steps asks for (30 iterations = 2 s; a 2-iteration "
                          "region is 0.14 s and a 10-iteration one sits inside the box-to-box spread: not measurements); steps_requested keeps the flag's value")
+    ap.add_argument("--fused-filter", type=int, default=1, help="1 = observation filter, the rollout forward's operand and its exponent refresh in one "
+                    "launch per range-step (hoic_zfilter_tiled; default); 0 = the four separate launches (A/B)")
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1 (one rank, default Box run only): append `other_configs` = Bottle and Banana at the same settings, 8 timed iterations each")
     args = ap.parse_args()
@@ -370,6 +372,9 @@ def main():
     from hoic_amd import mjcf, motions
     from hoic_amd.agent import AgentHandMimic
     from hoic_amd.config import Config
+    if not args.fused_filter:
+        from hoic_amd import mlp as _mlp
+        _mlp.FUSED_FILTER = False
 
     cfg = Config(f"{args.obj}_future5_light_add_geom")
     model = mjcf.load_packaged(args.obj)
