@@ -663,45 +663,47 @@ __global__ __launch_bounds__(64) void hoic_pack_tiled_kernel(const float* __rest
   *(u32x4*)t = hi; *(u32x4*)(t + 1024) = lo;
 }
 
-// ---- the sampler's observation filter and the forward's operand in ONE launch (round 5): running-filter update, normalisation
-// of the range's observations (float32 rows for the batch) AND their split into format T for hoic_fwd_tiled_kernel, plus the
-// exponent refresh of the engine's hidden-activation slots -- four launches of a range's chain (filter moments, filter apply,
-// hoic_update_exps, hoic_pack_tiled) as one, with no inter-workgroup dependency: a workgroup owns a strip of 16 columns x 128
-// rows and computes the moments of ALL chunks of its 16 columns itself (thread = (chunk, column): exactly the per-chunk
-// arithmetic of hoic_zfilter_moments_kernel; the observations are L2-resident, the sixteen-fold re-read is 80 MB of L2 traffic),
-// merges them in chunk order (hoic_zfilter_core.h: the same source as the two-launch form, so states and filter are bit-identical),
-// then normalises and packs its own 128 rows.  Needs n % 128 == 0 and n <= 2048 (one thread per chunk and column).
-__global__ __launch_bounds__(256) void hoic_zfilter_tiled_kernel(const float* __restrict__ x, int n, int dim, const double* __restrict__ state_in,
-                                                                 double* __restrict__ state_out, int update, float clip, float* __restrict__ y,
-                                                                 char* __restrict__ T, int Kp, int* __restrict__ exps, int slot_x,
-                                                                 float* __restrict__ amax, int nslots, unsigned long long mask, int target,
-                                                                 int* __restrict__ overflow) {
-  __shared__ double s_mean[16][16], s_m2[16][16], s_mu[16], s_rd[16];
+// ---- the sampler's observation filter WITH the forward's operand (round 5): the filter's second launch -- merge of the chunk
+// moments, new filter state, normalisation of the range's observations (float32 rows for the batch) -- also writes the rows in format
+// T for hoic_fwd_tiled_kernel and refreshes the engine's delayed exponents: four launches of a range's chain (filter moments,
+// filter apply, hoic_update_exps, hoic_pack_tiled) become two.  The arithmetic is that of hoic_zfilter (hoic_zfilter_core.h: the
+// same source), so states and filter are bit-identical.  A workgroup owns 16 columns x 128 rows (one k step of four tile rows).
+// (A first version also recomputed the chunk moments per workgroup to be ONE launch: sixteen-fold re-reads in 64-byte pieces,
+//  373 us against 58 us for the four launches it replaced.)
+__global__ __launch_bounds__(64) void hoic_zfilter_moments2_kernel(const float* __restrict__ x, int n, int dim, double* __restrict__ partial) {
+  const int col = blockIdx.x * 64 + threadIdx.x, chunk = blockIdx.y;
+  if (col >= dim) return;
+  const int r0 = chunk * ZF_ROWS, r1 = min(r0 + ZF_ROWS, n);
+  double mean, m2;
+  zf_chunk_moments(x, dim, col, r0, r1, mean, m2);
+  partial[((size_t)chunk * dim + col) * 2] = mean;
+  partial[((size_t)chunk * dim + col) * 2 + 1] = m2;
+}
+__global__ __launch_bounds__(256) void hoic_zfilter_tiled_kernel(const float* __restrict__ x, int n, int dim, const double* __restrict__ partial,
+                                                                 const double* __restrict__ state_in, double* __restrict__ state_out, int update,
+                                                                 float clip, float* __restrict__ y, char* __restrict__ T, int Kp,
+                                                                 int* __restrict__ exps, int slot_x, float* __restrict__ amax, int nslots,
+                                                                 unsigned long long mask, int target, int* __restrict__ overflow) {
+  __shared__ double s_mu[16], s_rd[16];
   const int tid = threadIdx.x, strip = blockIdx.x, rowblk = blockIdx.y;
   const int nchunk = n / ZF_ROWS;
-  {   // hidden-activation exponents of the forward engine from the last pass's maxima (hoic_update_exps_kernel, delayed slots)
-    if (strip == 0 && rowblk == 0 && tid < nslots && ((mask >> tid) & 1ull)) {
-      const float m = amax[tid];
-      if (m > 0.f && isfinite(m)) {
-        int ex; frexpf(m, &ex);
-        if (ldexpf(m, exps[tid]) > 60000.f && overflow) atomicAdd(overflow, 1);
-        exps[tid] = target - ex;
-      } else if (!isfinite(m) && overflow) atomicAdd(overflow, 1);
-      amax[tid] = 0.f;
-    }
+  // hidden-activation exponents of the forward engine from the last pass's maxima (hoic_update_exps_kernel, delayed slots)
+  if (strip == 0 && rowblk == 0 && tid < nslots && ((mask >> tid) & 1ull)) {
+    const float m = amax[tid];
+    if (m > 0.f && isfinite(m)) {
+      int ex; frexpf(m, &ex);
+      if (ldexpf(m, exps[tid]) > 60000.f && overflow) atomicAdd(overflow, 1);
+      exps[tid] = target - ex;
+    } else if (!isfinite(m) && overflow) atomicAdd(overflow, 1);
+    amax[tid] = 0.f;
   }
-  if (update) {
-    const int c = tid & 15, k = tid >> 4, col = strip * 16 + c;
-    if (col < dim && k < nchunk) zf_chunk_moments(x, dim, col, k * ZF_ROWS, (k + 1) * ZF_ROWS, s_mean[k][c], s_m2[k][c]);
-  }
-  __syncthreads();
   if (tid < 16) {
     const int col = strip * 16 + tid;
     double mu = 0.0, rd = 0.0;
     if (col < dim) {
       double cnt = state_in[0], mean = state_in[1 + col], S = state_in[1 + dim + col];
       if (update) {
-        for (int k = 0; k < nchunk; k++) zf_merge(cnt, mean, S, (double)ZF_ROWS, s_mean[k][tid], s_m2[k][tid]);
+        for (int k = 0; k < nchunk; k++) zf_merge(cnt, mean, S, (double)ZF_ROWS, partial[((size_t)k * dim + col) * 2], partial[((size_t)k * dim + col) * 2 + 1]);
         if (rowblk == 0) {
           state_out[1 + col] = mean; state_out[1 + dim + col] = S;
           if (col == 0) state_out[0] = cnt;
@@ -1091,14 +1093,16 @@ extern "C" int32_t hoic_mlp_pack_tiled(const float* d_x, int32_t R, int32_t C, i
   return HOIC_OK;
 }
 extern "C" int32_t hoic_zfilter_tiled(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out, int32_t update,
-                                      float clip, float* d_y, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x, float* d_amax,
-                                      int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream) {
-  if (n <= 0 || dim <= 0 || !d_x || !d_state_in || !d_y || !d_T || !d_exps || (n % ZF_ROWS) || n > 16 * ZF_ROWS || Kp < dim || (Kp & 15) ||
+                                      float clip, float* d_y, double* d_scratch, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x,
+                                      float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream) {
+  if (n <= 0 || dim <= 0 || !d_x || !d_state_in || !d_y || !d_T || !d_exps || (n % ZF_ROWS) || Kp < dim || (Kp & 15) ||
       nslots < 0 || nslots > 64 || (mask && !d_amax)) {
-    hoic_set_error("hoic_zfilter_tiled: n must be a multiple of 128 and at most 2048, Kp a multiple of 16 and >= dim"); return HOIC_ERR_ARG;
+    hoic_set_error("hoic_zfilter_tiled: n must be a multiple of 128, Kp a multiple of 16 and >= dim"); return HOIC_ERR_ARG;
   }
-  if (update && (!d_state_out || d_state_out == d_state_in)) { hoic_set_error("hoic_zfilter_tiled: update needs a state_out that is not state_in"); return HOIC_ERR_ARG; }
-  hipLaunchKernelGGL(hoic_zfilter_tiled_kernel, dim3((unsigned)(Kp >> 4), (unsigned)(n / ZF_ROWS)), dim3(256), 0, (hipStream_t)stream, d_x, n, dim,
+  if (update && (!d_state_out || !d_scratch || d_state_out == d_state_in)) { hoic_set_error("hoic_zfilter_tiled: update needs a scratch buffer and a state_out that is not state_in"); return HOIC_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (update) hipLaunchKernelGGL(hoic_zfilter_moments2_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(n / ZF_ROWS)), dim3(64), 0, st, d_x, n, dim, d_scratch);
+  hipLaunchKernelGGL(hoic_zfilter_tiled_kernel, dim3((unsigned)(Kp >> 4), (unsigned)(n / ZF_ROWS)), dim3(256), 0, st, d_x, n, dim, d_scratch,
                      d_state_in, d_state_out, update, clip, d_y, (char*)d_T, Kp, d_exps, slot_x, d_amax, nslots, (unsigned long long)mask, target, d_overflow);
   MCHK(hipGetLastError());
   return HOIC_OK;

@@ -77,7 +77,7 @@ class _Kernels:
         L.hoic_mlp_forward_tiled.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         self.has_zfilter_tiled = hasattr(L, "hoic_zfilter_tiled")      # (absent only in earlier development builds loaded through HOIC_LIB)
         if self.has_zfilter_tiled:
-            L.hoic_zfilter_tiled.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, i32, vp, i32, vp, i32, C.c_uint64, i32, vp, vp]
+            L.hoic_zfilter_tiled.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, vp, i32, vp, i32, vp, i32, C.c_uint64, i32, vp, vp]
             L.hoic_zfilter_tiled.restype = i32
         L.hoic_mlp_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
         L.hoic_mlp_head.restype = i32
@@ -99,7 +99,7 @@ class _Kernels:
 
 
 GEMM_MODE = 3      # set by kernels() from HOIC_GEMM_MODE when given
-FUSED_FILTER = True      # the sampler's filter + forward operand + exponent refresh as one launch (bench.py --fused-filter 0: A/B)
+FUSED_FILTER = True      # the sampler's filter apply + forward operand + exponent refresh as one launch (bench.py --fused-filter 0: A/B)
 
 
 def set_pipeline(mode: int):
@@ -685,9 +685,8 @@ class TiledForward:
         return mask
 
     def fused_filter_ok(self, rows):
-        """hoic_zfilter_tiled can write this engine's operand: known input bound (constant input exponent), rows a multiple of
-        128 and at most 2048"""
-        return FUSED_FILTER and kernels().has_zfilter_tiled and self.x_bound is not None and rows % 128 == 0 and 0 < rows <= 2048
+        """hoic_zfilter_tiled can write this engine's operand: known input bound (constant input exponent), rows a multiple of 128"""
+        return FUSED_FILTER and kernels().has_zfilter_tiled and self.x_bound is not None and rows % 128 == 0 and rows > 0
 
     @_on_device
     def forward(self, x, prepacked=False):

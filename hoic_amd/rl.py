@@ -286,8 +286,8 @@ class BatchZFilter:
 
     def _call_device(self, x, update, out=None, tiled=None):
         """hoic_zfilter: two launches (chunk moments; merge + normalise) instead of ~30 tensor kernels -- or, with ``tiled`` (a
-        hoic_amd.mlp.TiledForward engine whose operand the normalised rows are), hoic_zfilter_tiled: ONE launch that also writes
-        the engine's operand and refreshes its delayed exponents (bit-identical states and filter)."""
+        hoic_amd.mlp.TiledForward engine whose operand the normalised rows are), hoic_zfilter_tiled: the second launch also writes
+        the engine's operand and refreshes its delayed exponents (bit-identical states and filter; two launches instead of four)."""
         from . import lib
         import ctypes as C
         L = lib.load()
@@ -300,11 +300,15 @@ class BatchZFilter:
             mask = tiled._prepare(n)
             if update and self._alt is None:
                 self._alt = torch.empty_like(self._st)
+            if update:
+                need = int(L.hoic_zfilter_scratch_doubles(n, self.dim))
+                if self._scratch is None or self._scratch.numel() < need:
+                    self._scratch = torch.empty(need, dtype=torch.float64, device=x.device)
             ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
             tb = tiled.table
             with torch.cuda.device(x.device):
                 rc = K.L.hoic_zfilter_tiled(n, self.dim, ptr(x), ptr(self._st), ptr(self._alt if update else None), int(bool(update)), float(self.clip),
-                                            ptr(y), ptr(tiled.XT), tiled.Kp[0], ptr(tb.exps), tiled.SLOT_X, ptr(tb.amax), _mlp.NSLOT, C.c_uint64(mask),
+                                            ptr(y), ptr(self._scratch if update else None), ptr(tiled.XT), tiled.Kp[0], ptr(tb.exps), tiled.SLOT_X, ptr(tb.amax), _mlp.NSLOT, C.c_uint64(mask),
                                             _mlp.TARGET_LOG2, ptr(tb.overflow), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             if rc != 0:
                 raise lib.HoicError(f"hoic_zfilter_tiled failed ({rc}): {L.hoic_last_error().decode()}")

@@ -160,14 +160,15 @@ int32_t hoic_gae(int32_t T, int32_t N, const float* d_rewards, const float* d_ma
 int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim);
 int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out,
                      int32_t update, float clip, float* d_y, double* d_scratch, void* stream);
-/* The same filter step for the fixed-horizon sampler's env ranges, in ONE launch together with what follows it in a range's
- * chain (agent_handmimic.py:463-465: running_state(state) then policy_net.select_action): the normalised rows also leave in the
- * rollout forward's operand format T (hoic_mlp_pack_tiled; d_T [n x Kp] at 2^d_exps[slot_x]) and the forward engine's delayed
- * exponents (slots in `mask`) are refreshed from d_amax as hoic_mlp_update_exps does.  States and filter are bit-identical to
- * hoic_zfilter.  n must be a multiple of 128 and at most 2048; update = 0 normalises with d_state_in (d_state_out unused). */
+/* The same filter step for the fixed-horizon sampler's env ranges together with what follows it in a range's chain
+ * (agent_handmimic.py:463-465: running_state(state) then policy_net.select_action): the launch that normalises the rows also
+ * writes them in the rollout forward's operand format T (hoic_mlp_pack_tiled; d_T [n x Kp] at 2^d_exps[slot_x]) and refreshes the
+ * forward engine's delayed exponents (slots in `mask`) from d_amax as hoic_mlp_update_exps does -- two launches instead of four.
+ * States and filter are bit-identical to hoic_zfilter.  n must be a multiple of 128; d_scratch as for hoic_zfilter; update = 0
+ * normalises with d_state_in (d_state_out, d_scratch unused). */
 int32_t hoic_zfilter_tiled(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out, int32_t update,
-                           float clip, float* d_y, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x, float* d_amax,
-                           int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream);
+                           float clip, float* d_y, double* d_scratch, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x,
+                           float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream);
 
 /* The residual-force QP of HandObjMimic4.get_rfc_score (ho_im4.py:1040-1083) on caller-supplied data, n independent
  * problems:  min_x |A x - b|^2 + c.x + 1e-7/2 |x|^2, x >= 0.  d_cols [n, max_col, 7] float32: column k of problem i
