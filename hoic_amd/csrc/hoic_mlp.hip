@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64) void hoic_pack_tiled_kernel(const float* __rest
 // moments, new filter state, normalisation of the range's observations (float32 rows for the batch) -- also writes the rows in format
 // T for hoic_fwd_tiled_kernel and refreshes the engine's delayed exponents: four launches of a range's chain (filter moments,
 // filter apply, hoic_update_exps, hoic_pack_tiled) become two.  The arithmetic is that of hoic_zfilter (hoic_zfilter_core.h: the
-// same source), so states and filter are bit-identical.  A workgroup owns 16 columns x 128 rows (one k step of four tile rows).
+// same source), so states and filter are bit-identical.  A workgroup is one wavefront: 16 columns x 32 rows (one tile of format T).
 // (A first version also recomputed the chunk moments per workgroup to be ONE launch: sixteen-fold re-reads in 64-byte pieces,
 //  373 us against 58 us for the four launches it replaced.)
 __global__ __launch_bounds__(64) void hoic_zfilter_moments2_kernel(const float* __restrict__ x, int n, int dim, double* __restrict__ partial) {
@@ -679,13 +679,16 @@ __global__ __launch_bounds__(64) void hoic_zfilter_moments2_kernel(const float* 
   partial[((size_t)chunk * dim + col) * 2] = mean;
   partial[((size_t)chunk * dim + col) * 2 + 1] = m2;
 }
-__global__ __launch_bounds__(256) void hoic_zfilter_tiled_kernel(const float* __restrict__ x, int n, int dim, const double* __restrict__ partial,
+__global__ __launch_bounds__(64) void hoic_zfilter_tiled_kernel(const float* __restrict__ x, int n, int dim, const double* __restrict__ partial,
                                                                  const double* __restrict__ state_in, double* __restrict__ state_out, int update,
                                                                  float clip, float* __restrict__ y, char* __restrict__ T, int Kp,
                                                                  int* __restrict__ exps, int slot_x, float* __restrict__ amax, int nslots,
                                                                  unsigned long long mask, int target, int* __restrict__ overflow) {
+  // ONE wavefront per workgroup (a 32-row tile x 16 columns), like every other kernel of a range's chain: beside three 168-register
+  // substep wavefronts a SIMD has no room for another wavefront, and a workgroup of four must find four free slots on one CU at the
+  // same time -- the 256-thread form of this kernel took 280 us of mostly waiting.
   __shared__ double s_mu[16], s_rd[16];
-  const int tid = threadIdx.x, strip = blockIdx.x, rowblk = blockIdx.y;
+  const int tid = threadIdx.x, strip = blockIdx.x, rowblk = blockIdx.y;       // rowblk: tile row (32 rows)
   const int nchunk = n / ZF_ROWS;
   // hidden-activation exponents of the forward engine from the last pass's maxima (hoic_update_exps_kernel, delayed slots)
   if (strip == 0 && rowblk == 0 && tid < nslots && ((mask >> tid) & 1ull)) {
@@ -714,10 +717,10 @@ __global__ __launch_bounds__(256) void hoic_zfilter_tiled_kernel(const float* __
     s_mu[tid] = mu; s_rd[tid] = rd;
   }
   __syncthreads();
-  // normalise + pack: wavefront w of the workgroup = tile row a = 4 rowblk + w, k step = strip; lane (l31, hf) = row 32 a + l31,
-  // columns 16 strip + 8 hf .. + 7 (the lane mapping of hoic_pack_tiled_kernel)
-  const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
-  const int a = 4 * rowblk + wv, r = 32 * a + l31, c0 = 16 * strip + 8 * hf;
+  // normalise + pack: tile row a = rowblk, k step = strip; lane (l31, hf) = row 32 a + l31, columns 16 strip + 8 hf .. + 7 (the lane
+  // mapping of hoic_pack_tiled_kernel)
+  const int lane = tid, l31 = lane & 31, hf = lane >> 5;
+  const int a = rowblk, r = 32 * a + l31, c0 = 16 * strip + 8 * hf;
   const float sc = ldexpf(1.f, exps[slot_x]);
   const double lim = (double)clip;
   unsigned w[8];
@@ -1102,7 +1105,7 @@ extern "C" int32_t hoic_zfilter_tiled(int32_t n, int32_t dim, const float* d_x, 
   if (update && (!d_state_out || !d_scratch || d_state_out == d_state_in)) { hoic_set_error("hoic_zfilter_tiled: update needs a scratch buffer and a state_out that is not state_in"); return HOIC_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   if (update) hipLaunchKernelGGL(hoic_zfilter_moments2_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(n / ZF_ROWS)), dim3(64), 0, st, d_x, n, dim, d_scratch);
-  hipLaunchKernelGGL(hoic_zfilter_tiled_kernel, dim3((unsigned)(Kp >> 4), (unsigned)(n / ZF_ROWS)), dim3(256), 0, st, d_x, n, dim, d_scratch,
+  hipLaunchKernelGGL(hoic_zfilter_tiled_kernel, dim3((unsigned)(Kp >> 4), (unsigned)(n / 32)), dim3(64), 0, st, d_x, n, dim, d_scratch,
                      d_state_in, d_state_out, update, clip, d_y, (char*)d_T, Kp, d_exps, slot_x, d_amax, nslots, (unsigned long long)mask, target, d_overflow);
   MCHK(hipGetLastError());
   return HOIC_OK;
