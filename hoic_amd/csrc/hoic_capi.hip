@@ -1405,6 +1405,18 @@ extern "C" int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim) {
   if (n <= 0 || dim <= 0) return 0;
   return (int64_t)((n + ZF_ROWS - 1) / ZF_ROWS) * dim * 2;
 }
+extern "C" int32_t hoic_zfilter_absorb(int32_t dim, const double* d_state, const double* const* d_fork_states, int32_t n_forks, double* d_state_out,
+                                       void* stream) {
+  if (dim <= 0 || !d_state || !d_fork_states || n_forks < 0 || n_forks > ZF_MAXFORK || !d_state_out || d_state_out == d_state) {
+    set_err("hoic_zfilter_absorb: bad arguments (at most 8 forks; state_out must not alias state)"); return HOIC_ERR_ARG;
+  }
+  ZfForks f{};
+  f.n = n_forks;
+  for (int i = 0; i < n_forks; i++) { if (!d_fork_states[i]) { set_err("hoic_zfilter_absorb: null fork state"); return HOIC_ERR_ARG; } f.st[i] = d_fork_states[i]; }
+  hipLaunchKernelGGL(hoic_zfilter_absorb_kernel, dim3((dim + ZF_NT - 1) / ZF_NT), dim3(ZF_NT), 0, (hipStream_t)stream, d_state, f, dim, d_state_out);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
 extern "C" int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out,
                                 int32_t update, float clip, float* d_y, double* d_scratch, void* stream) {
   if (n <= 0 || dim <= 0 || !d_x || !d_state_in) { set_err("hoic_zfilter: bad arguments"); return HOIC_ERR_ARG; }

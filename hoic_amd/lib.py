@@ -40,7 +40,7 @@ class RewardParams(C.Structure):
 
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error", "hoic_build_id",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_reward_params_async", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
-           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_tiled", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
+           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_tiled", "hoic_zfilter_absorb", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame", "hoic_get_diagnostics", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps",
            "hoic_mlp_gemm", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed", "hoic_mlp_set_pipeline", "hoic_mlp_gemm_tn",
@@ -108,6 +108,8 @@ def load():
     L.hoic_append_expert_frame.argtypes = [vp] * 9
     L.hoic_get_diagnostics.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(i32), i32]
     L.hoic_last_poststep_ms.restype = f32
+    if hasattr(L, "hoic_zfilter_absorb"):
+        L.hoic_zfilter_absorb.argtypes = [i32, vp, C.POINTER(vp), i32, vp, vp]
     for n in EXPORTS:
         if os.environ.get("HOIC_LIB") and not hasattr(L, n):
             continue      # a development build of an earlier revision (A/B runs): entry points added since are absent there

@@ -160,6 +160,13 @@ int32_t hoic_gae(int32_t T, int32_t N, const float* d_rewards, const float* d_ma
 int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim);
 int32_t hoic_zfilter(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out,
                      int32_t update, float clip, float* d_y, double* d_scratch, void* stream);
+/* Merge of the per-range forks of the filter after a pipelined rollout (each env range updates its own copy of the running
+ * statistics, like the reference's sampler threads: uhc/khrylib/rl/agents/agent.py:64-120; here all copies are merged, the
+ * reference keeps worker 0's): d_state = the filter the forks were copied from (unchanged since), d_fork_states = host array of
+ * n_forks (<= 8) device pointers to the forks' (count, mean[dim], S[dim]); d_state_out (not aliasing d_state) receives the
+ * statistics of pushing every fork's new rows into d_state.  One launch; bit-identical to hoic_amd.rl.BatchZFilter.absorb. */
+int32_t hoic_zfilter_absorb(int32_t dim, const double* d_state, const double* const* d_fork_states, int32_t n_forks, double* d_state_out,
+                            void* stream);
 /* The same filter step for the fixed-horizon sampler's env ranges together with what follows it in a range's chain
  * (agent_handmimic.py:463-465: running_state(state) then policy_net.select_action): the launch that normalises the rows also
  * writes them in the rollout forward's operand format T (hoic_mlp_pack_tiled; d_T [n x Kp] at 2^d_exps[slot_x]) and refreshes the

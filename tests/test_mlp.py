@@ -203,6 +203,29 @@ def test_filter_and_forward_operand_in_one_launch_match_the_separate_launches(up
     assert not fa.last_call_packed and y.shape == (96, 617)
 
 
+@gpu
+def test_fork_merge_in_one_launch_is_the_tensor_expression():
+    """hoic_zfilter_absorb (the per-range filter forks merged after a pipelined rollout in ONE launch; the tensor form was 77
+    launches of 5.6 us at the end of every rollout) gives bit-identical statistics to BatchZFilter._absorb_tensors, including a
+    fork that saw nothing and forks of very different row counts."""
+    from hoic_amd.rl import BatchZFilter
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a, b = BatchZFilter(617, clip=5.0, device="cuda"), BatchZFilter(617, clip=5.0, device="cuda")
+    x0 = torch.randn(4096, 617, device="cuda", generator=g) * 2.0 + 0.7
+    a(x0); b(x0)
+    for rnd in range(3):
+        fa, fb = [a.fork() for _ in range(3)], [b.fork() for _ in range(3)]
+        for k, rows in enumerate((2048, 0, 128)):
+            for step in range(2 + rnd):
+                if rows:
+                    x = torch.randn(rows, 617, device="cuda", generator=g) * (1.0 + k) - 0.2 * step
+                    fa[k](x); fb[k](x)
+        a.absorb(fa)                    # device kernel
+        b._absorb_tensors(fb)           # tensor expression
+        assert torch.equal(a._st, b._st), rnd
+    assert float(a.n) == 4096 + (2 + 3 + 4) * (2048 + 128)
+
+
 def test_split_choice_for_the_weight_gradient_kernels():
     """pick_splits16: tiles x splits fill the 512 workgroup slots (two per CU) in whole rounds, no split is empty"""
     for n, k, want in ((2048, 640, 12), (1024, 2048, 8), (512, 1024, 32)):
