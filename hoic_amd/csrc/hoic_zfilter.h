@@ -61,24 +61,32 @@ __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_apply_kernel(const float* 
 #define ZF_MAXFORK 8
 struct ZfForks { const double* st[ZF_MAXFORK]; int n; };
 __global__ __launch_bounds__(ZF_NT) void hoic_zfilter_absorb_kernel(const double* __restrict__ base, ZfForks forks, int dim, double* __restrict__ out) {
+  // (the library is built with -ffp-contract=fast, which lets the backend fuse any product into a following sum whatever the
+  //  source says -- pragma and __dmul_rn included: fn * fm - n0 * m0 must stay two products and a difference, so the products
+  //  that feed a sum pass through an empty asm)
   const int col = blockIdx.x * ZF_NT + threadIdx.x;
   if (col >= dim) return;
   const double n0 = base[0], m0 = base[1 + col], S0 = base[1 + dim + col];
   double n1 = n0, m1 = m0, S1 = S0;
   for (int f = 0; f < forks.n; f++) {
     const double fn = forks.st[f][0], fm = forks.st[f][1 + col], fS = forks.st[f][1 + dim + col];
-    const double nb = __dsub_rn(fn, n0);
+    const double nb = fn - n0;
     const double safe = fmax(nb, 1.0);
-    const double mb = __ddiv_rn(__dsub_rn(__dmul_rn(fn, fm), __dmul_rn(n0, m0)), safe);
-    const double dm = __dsub_rn(mb, m0);
-    const double corr = __ddiv_rn(__dmul_rn(__dmul_rn(__dmul_rn(dm, dm), n0), nb), fmax(fn, 1.0));
-    const double Sb = fmax(__dsub_rn(__dsub_rn(fS, S0), corr), 0.0);
-    const double tot = __dadd_rn(n1, nb), delta = __dsub_rn(mb, m1);
+    double p1 = fn * fm, p0 = n0 * m0;
+    asm volatile("" : "+v"(p1), "+v"(p0));        // (products that feed a sum are pinned: see above)
+    const double mb = (p1 - p0) / safe;
+    const double dm = mb - m0;
+    const double corr = dm * dm * n0 * nb / fmax(fn, 1.0);
+    const double Sb = fmax((fS - S0) - corr, 0.0);
+    const double tot = n1 + nb, delta = mb - m1;
     const double w = nb > 0.0 ? 1.0 : 0.0;                     // a fork that saw nothing changes nothing
     const double den = fmax(tot, 1.0);
-    const double Sadd = __dadd_rn(Sb, __ddiv_rn(__dmul_rn(__dmul_rn(__dmul_rn(delta, delta), n1), nb), den));
-    S1 = __dadd_rn(S1, __dmul_rn(w, Sadd));
-    m1 = __dadd_rn(m1, __ddiv_rn(__dmul_rn(__dmul_rn(w, delta), nb), den));
+    const double Sadd = Sb + delta * delta * n1 * nb / den;
+    double wS = w * Sadd;
+    asm volatile("" : "+v"(wS));
+    S1 = S1 + wS;
+    const double dmean = w * delta * nb / den;
+    m1 = m1 + dmean;
     n1 = tot;
   }
   out[1 + col] = m1; out[1 + dim + col] = S1;
