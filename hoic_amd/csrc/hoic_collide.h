@@ -384,12 +384,60 @@ HD float hull_run_bound(const HullRef& h, int r, float x, float y, float z) {
   const float b = fmaxf(lo.x * wx, hi.x * wx) + fmaxf(lo.y * wy, hi.y * wy) + fmaxf(lo.z * wz, hi.z * wz) + c.w;
   return b + (2e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + fabsf(c.w)) + 1e-8f);
 }
+// pass 2 of a query: the runs whose bound (ub0: run = lane, ub1: run = lane + 64) can still reach `best` -- a value some face
+// certainly attains at the point -- eight per trip (four per half-wave, all loads in flight) in ascending run order.  A lane's
+// running best (bv, bi, bp) takes a face when it is larger, or equal with a smaller index: the selection "largest value, first
+// index" does not depend on the order in which candidates are met, nor on rows fetched beyond need.
+HD void hull_visit(const HullRef& h, float x, float y, float z, float ub0, float ub1, float best, float& bv, int& bi, f4v& bp) {
+  const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+#pragma unroll 1
+  for (int part = 0; part < 2; part++) {
+    if (part == 1 && h.nfr <= NT) break;
+    unsigned long long mask = __ballot((part ? ub1 : ub0) >= best);
+    while (mask) {
+      int tq[4]; bool on[4]; f4v pq[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        int ra = -1, rb = -1;
+        if (mask) { ra = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        if (mask) { rb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        const int rr = half ? rb : ra;
+        tq[q] = (rr + part * NT) * HOIC_HULL_RUN_FACES + sub;
+        on[q] = rr >= 0 && tq[q] < h.np;
+        pq[q] = h.pl[on[q] ? tq[q] : 0];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float v = hull_plane_val(pq[q], x, y, z);
+        if (on[q] && (v > bv || (v == bv && tq[q] < bi))) { bv = v; bi = tq[q]; bp = pq[q]; }
+      }
+      if (mask) {                                  // more candidates: raise the bar with what this trip found
+        best = fmaxf(best, wave_max(bv));
+        mask &= __ballot((part ? ub1 : ub0) >= best);
+      }
+    }
+  }
+}
+// the wave's result from the lanes' running bests: the largest value, its first face; that face's plane comes out of the winning
+// lane's registers (no table read)
+HD float hull_select(const HullRef& h, float bv, int bi, const f4v bp, float* pl) {
+  const float mx = wave_max(bv);
+  const int idx = min((int)wave_min(bv == mx ? (float)bi : 1e9f), h.np - 1);     // indices < 2^24 are exact in float32 (the clamp: non-finite query points)
+  const unsigned long long win = __ballot(bv == mx && bi == idx);
+  if (win) {
+    const int L = __ffsll((long long)win) - 1;
+    pl[0] = rl(bp.x, L); pl[1] = rl(bp.y, L); pl[2] = rl(bp.z, L); pl[3] = rl(bp.w, L);
+  } else {                                             // (non-finite query point: no lane compares equal)
+    const f4v w = h.pl[idx];                           // wave-uniform address
+    pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
+  }
+  return mx;
+}
 // max over the faces of n.x - d at the point (x, y, z) (hull frame); pl = that face (the first one in face order on ties)
 // Round trips to the (L2-resident) tables are what a query costs -- a capsule pair makes two to five queries one after the other,
-// each two to three dependent reads deep in round 4 -- so: every lane keeps the plane of its best face in registers (the winner's
-// is read across the wave at the end: no final table read), and the runs that pass 1 leaves in play are fetched up to EIGHT per
-// trip (four per half-wave, all four loads in flight) instead of two.  Fetching a run that a raised bar would have pruned changes
-// nothing: the maximum and its first index are those of the runs that reach the final bar.
+// each two to three dependent reads deep -- so: every lane keeps the plane of its best face in registers, the runs that pass 1
+// leaves in play are fetched up to EIGHT per trip, the two ends of a capsule share their passes (hull_max_wave2) and the queries
+// between them need no pass 1 at all (hull_max_wave_seg).
 HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
   const int lane = threadIdx.x;
   if (h.np <= 0) { pl[0] = pl[1] = pl[2] = pl[3] = 0.f; return -1e30f; }      // a mesh without face planes (wave-uniform): no face, nothing to index
@@ -416,72 +464,39 @@ HD float hull_max_wave(const HullRef& h, float x, float y, float z, float* pl) {
       const float v = hull_plane_val(p, x, y, z);
       if (v > bv) { bv = v; bi = (lane + NT) * HOIC_HULL_RUN_FACES; bp = p; }
     }
-    float best = wave_max(bv);
-    // pass 2: the runs that can still reach `best`, eight per trip (four per half-wave) in ascending run order, so that a
-    // lane meets its faces in ascending table order and '>' keeps its first maximum
-    // (a lane's running best (bv, bi, bp) takes a face when it is larger, or equal with a smaller index: the selection "largest
-    //  value, first index" does not depend on the order in which candidates are met)
-    const int half = lane >> 5, sub = lane & 31;
-#pragma unroll 1
-    for (int part = 0; part < 2; part++) {
-      if (part == 1 && h.nfr <= NT) break;
-      unsigned long long mask = __ballot((part ? ub1 : ub0) >= best);
-      while (mask) {
-        int tq[4]; bool on[4]; f4v pq[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          int ra = -1, rb = -1;
-          if (mask) { ra = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-          if (mask) { rb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-          const int rr = half ? rb : ra;
-          tq[q] = (rr + part * NT) * HOIC_HULL_RUN_FACES + sub;
-          on[q] = rr >= 0 && tq[q] < h.np;
-          pq[q] = h.pl[on[q] ? tq[q] : 0];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float v = hull_plane_val(pq[q], x, y, z);
-          if (on[q] && (v > bv || (v == bv && tq[q] < bi))) { bv = v; bi = tq[q]; bp = pq[q]; }
-        }
-        if (mask) {                                  // more candidates: raise the bar with what this trip found
-          best = fmaxf(best, wave_max(bv));
-          mask &= __ballot((part ? ub1 : ub0) >= best);
-        }
-      }
-    }
+    hull_visit(h, x, y, z, ub0, ub1, wave_max(bv), bv, bi, bp);
   }
-  const float mx = wave_max(bv);
-  const int idx = min((int)wave_min(bv == mx ? (float)bi : 1e9f), h.np - 1);     // indices < 2^24 are exact in float32 (the clamp: non-finite query points)
-  const unsigned long long win = __ballot(bv == mx && bi == idx);
-  if (win) {                                           // the winner's plane, from its registers
-    const int L = __ffsll((long long)win) - 1;
-    pl[0] = rl(bp.x, L); pl[1] = rl(bp.y, L); pl[2] = rl(bp.z, L); pl[3] = rl(bp.w, L);
-  } else {                                             // (non-finite query point: no lane compares equal)
-    const f4v w = h.pl[idx];                           // wave-uniform address
-    pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
-  }
-  return mx;
+  return hull_select(h, bv, bi, bp, pl);
 }
 // The same query at TWO points at once (the two ends of a capsule's axis: a few centimetres apart, so the runs in play are
 // largely the same): one pass 1 (the run bounds' table reads are shared), and every face row fetched in pass 2 is evaluated at
 // both points -- a row that only one point needed is harmless for the other (see above).  Results per point are those of
-// hull_max_wave, bit for bit: the same faces' values, largest value, first index.
-HD void hull_max_wave2(const HullRef& h, const float* a, const float* b, float* pla, float* plb, float& va, float& vb) {
+// hull_max_wave, bit for bit: the same faces' values, largest value, first index.  `sg` keeps the lanes' run bounds at the two
+// points for the queries between them.
+struct HullSeg { float ua0, ua1, ub0, ub1; };
+HD void hull_max_wave2(const HullRef& h, const float* a, const float* b, float* pla, float* plb, float& va, float& vb, HullSeg& sg) {
   const int lane = threadIdx.x;
-  if (h.np <= 0 || !h.prune || h.np <= HULL_STREAM_BELOW) {     // (wave-uniform: small hulls stream, one point after the other)
-    va = hull_max_wave(h, a[0], a[1], a[2], pla); vb = hull_max_wave(h, b[0], b[1], b[2], plb);
-    return;
-  }
+  sg.ua0 = sg.ua1 = sg.ub0 = sg.ub1 = -1e30f;
+  if (h.np <= 0) { va = hull_max_wave(h, a[0], a[1], a[2], pla); vb = va; for (int i = 0; i < 4; i++) plb[i] = pla[i]; return; }
   float bva = -1e30f, bvb = -1e30f; int bia = 0x00ffffff, bib = 0x00ffffff;
   f4v bpa = {0.f, 0.f, 0.f, 0.f}, bpb = {0.f, 0.f, 0.f, 0.f};
-  float uba0 = -1e30f, uba1 = -1e30f, ubb0 = -1e30f, ubb1 = -1e30f;
+  if (!h.prune || h.np <= HULL_STREAM_BELOW) {     // (wave-uniform: small hulls stream, every row evaluated at both points)
+    for (int t = lane; t < h.np; t += NT) {
+      const f4v p = h.pl[t];
+      const float wa = hull_plane_val(p, a[0], a[1], a[2]), wb = hull_plane_val(p, b[0], b[1], b[2]);
+      if (wa > bva) { bva = wa; bia = t; bpa = p; }
+      if (wb > bvb) { bvb = wb; bib = t; bpb = p; }
+    }
+    va = hull_select(h, bva, bia, bpa, pla); vb = hull_select(h, bvb, bib, bpb, plb);
+    return;
+  }
 #pragma unroll
   for (int part = 0; part < 2; part++) {
     const int r = lane + part * NT;
     if (part == 1 && h.nfr <= NT) break;
     if (r < h.nfr) {
       const float ua = hull_run_bound(h, r, a[0], a[1], a[2]), ub = hull_run_bound(h, r, b[0], b[1], b[2]);
-      if (part) { uba1 = ua; ubb1 = ub; } else { uba0 = ua; ubb0 = ub; }
+      if (part) { sg.ua1 = ua; sg.ub1 = ub; } else { sg.ua0 = ua; sg.ub0 = ub; }
       const int t = r * HOIC_HULL_RUN_FACES;
       const f4v p = h.pl[t];
       const float wa = hull_plane_val(p, a[0], a[1], a[2]), wb = hull_plane_val(p, b[0], b[1], b[2]);
@@ -494,7 +509,7 @@ HD void hull_max_wave2(const HullRef& h, const float* a, const float* b, float* 
 #pragma unroll 1
   for (int part = 0; part < 2; part++) {
     if (part == 1 && h.nfr <= NT) break;
-    unsigned long long mask = __ballot((part ? uba1 : uba0) >= besta || (part ? ubb1 : ubb0) >= bestb);
+    unsigned long long mask = __ballot((part ? sg.ua1 : sg.ua0) >= besta || (part ? sg.ub1 : sg.ub0) >= bestb);
     while (mask) {
       int tq[4]; bool on[4]; f4v pq[4];
 #pragma unroll
@@ -515,26 +530,30 @@ HD void hull_max_wave2(const HullRef& h, const float* a, const float* b, float* 
       }
       if (mask) {
         besta = fmaxf(besta, wave_max(bva)); bestb = fmaxf(bestb, wave_max(bvb));
-        mask &= __ballot((part ? uba1 : uba0) >= besta || (part ? ubb1 : ubb0) >= bestb);
+        mask &= __ballot((part ? sg.ua1 : sg.ua0) >= besta || (part ? sg.ub1 : sg.ub0) >= bestb);
       }
     }
   }
-#pragma unroll
-  for (int w2 = 0; w2 < 2; w2++) {
-    const float bv = w2 ? bvb : bva; const int bi = w2 ? bib : bia; const f4v bp = w2 ? bpb : bpa;
-    float* pl = w2 ? plb : pla;
-    const float mx = wave_max(bv);
-    const int idx = min((int)wave_min(bv == mx ? (float)bi : 1e9f), h.np - 1);
-    const unsigned long long win = __ballot(bv == mx && bi == idx);
-    if (win) {
-      const int L = __ffsll((long long)win) - 1;
-      pl[0] = rl(bp.x, L); pl[1] = rl(bp.y, L); pl[2] = rl(bp.z, L); pl[3] = rl(bp.w, L);
-    } else {
-      const f4v w = h.pl[idx];
-      pl[0] = w.x; pl[1] = w.y; pl[2] = w.z; pl[3] = w.w;
-    }
-    if (w2) vb = mx; else va = mx;
-  }
+  va = hull_select(h, bva, bia, bpa, pla); vb = hull_select(h, bvb, bib, bpb, plb);
+}
+// The query at a point BETWEEN the two of hull_max_wave2, x = a + t (b - a) with 0 <= t <= 1, without pass 1.  A run's bound --
+// like the largest face value of the run that it bounds -- is a convex function of the point, so between the two points it lies
+// below the chord of its values at them: (1 - t) ua + t ub, plus room for the rounding of the chord, of the point and of the
+// face values themselves (1e-6: a micron, the bounds carry that much themselves), bounds the run at x with no table read.  The
+// bar is the larger of the two faces `qa`, `qb` of this hull at x (the search's bracketing faces: their lines cross at x, so it is
+// close to the answer) -- a value some face attains, which is all pass 2 needs: the maximum, and every face that ties with it,
+// sits in a run whose bound reaches the bar.  Same face values, same selection: the result is that of hull_max_wave, bit for bit
+// (test_mesh_pruning_changes_no_contact compares with the streaming form).
+HD float hull_max_wave_seg(const HullRef& h, float x, float y, float z, float t, const HullSeg& sg, const float* qa, const float* qb, float* pl) {
+  if (h.np <= 0 || !h.prune || h.np <= HULL_STREAM_BELOW) return hull_max_wave(h, x, y, z, pl);
+  const f4v fa = {qa[0], qa[1], qa[2], qa[3]}, fb = {qb[0], qb[1], qb[2], qb[3]};
+  const float bar = fmaxf(hull_plane_val(fa, x, y, z), hull_plane_val(fb, x, y, z));
+  const float u0 = fmaf(t, sg.ub0 - sg.ua0, sg.ua0) + (1e-6f + 1e-6f * (fabsf(sg.ua0) + fabsf(sg.ub0)));
+  const float u1 = fmaf(t, sg.ub1 - sg.ua1, sg.ua1) + (1e-6f + 1e-6f * (fabsf(sg.ua1) + fabsf(sg.ub1)));
+  float bv = -1e30f; int bi = 0x00ffffff;
+  f4v bp = {0.f, 0.f, 0.f, 0.f};
+  hull_visit(h, x, y, z, u0, u1, bar, bv, bi, bp);
+  return hull_select(h, bv, bi, bp, pl);
 }
 // the sequential "keep the four deepest" of one pair's contact list, state held uniformly: n, the four distances
 struct Deep4 { int n; float d0, d1, d2, d3; };
@@ -623,24 +642,32 @@ __device__ __forceinline__ int col_capsule_mesh_wave(const HullRef& h, const flo
   const float r = cs[0];
   float p0[4], p1[4], pm[4], pl_[4], pr_[4];
   float v0, v1;
+  HullSeg sg;
   {
     const float e1[3] = {a[0] + d[0], a[1] + d[1], a[2] + d[2]};
-    hull_max_wave2(h, a, e1, p0, p1, v0, v1);
+    hull_max_wave2(h, a, e1, p0, p1, v0, v1, sg);
   }
   const float s0 = p0[0] * d[0] + p0[1] * d[1] + p0[2] * d[2];
   const float s1 = p1[0] * d[0] + p1[1] * d[1] + p1[2] * d[2];
   float ts, vs, nmin[3];
+  bool far = false;
   if (s0 >= 0.f) { ts = 0.f; vs = v0; for (int i = 0; i < 3; i++) nmin[i] = p0[i]; }
   else if (s1 <= 0.f) { ts = 1.f; vs = v1; for (int i = 0; i < 3; i++) nmin[i] = p1[i]; }
-  else {
+  else if (v0 < r && v1 < r) {      // both ends touch: the list is full with them, the interior minimum is never looked at
+    ts = 0.f; vs = v0; for (int i = 0; i < 3; i++) nmin[i] = p0[i];
+  } else {
     float tl = 0.f, vl = v0, sl = s0, tr = 1.f, vr = v1, sr = s1;
     for (int i = 0; i < 4; i++) { pl_[i] = p0[i]; pr_[i] = p1[i]; }
     ts = 0.f; vs = v0;
     for (int it = 0; it < 8; it++) {
       float t = fdiv((vr - sr * tr) - (vl - sl * tl), sl - sr);
       t = fminf(fmaxf(t, tl), tr);
-      const float v = hull_max_wave(h, a[0] + t * d[0], a[1] + t * d[1], a[2] + t * d[2], pm);
       const float lineval = vl + sl * (t - tl);
+      // the distance along the axis is convex and lies above both bracketing faces' lines, whose crossing is `lineval`: once
+      // that is clear of the radius (by far more than the rounding of these few operations) no point of the axis is within
+      // the radius, every value met so far included -- the remaining queries could only refine a minimum that is no contact
+      if (lineval > r + 1e-6f) { far = true; break; }
+      const float v = hull_max_wave_seg(h, a[0] + t * d[0], a[1] + t * d[1], a[2] + t * d[2], t, sg, pl_, pr_, pm);
       ts = t; vs = v;
       if (v <= lineval + 1e-7f) break;
       const float sm = pm[0] * d[0] + pm[1] * d[1] + pm[2] * d[2];
@@ -654,7 +681,7 @@ __device__ __forceinline__ int col_capsule_mesh_wave(const HullRef& h, const flo
   // candidates in the order of the sequential list (end 0, end 1, interior minimum), at most two contacts
   const bool c0 = v0 < r, c1 = v1 < r;
   bool c2 = false;
-  if (!(c0 && c1) && vs < r) c2 = !((c0 && fabsf(ts) < 1e-4f) || (c1 && fabsf(ts - 1.f) < 1e-4f));
+  if (!(c0 && c1) && !far && vs < r) c2 = !((c0 && fabsf(ts) < 1e-4f) || (c1 && fabsf(ts - 1.f) < 1e-4f));
   int cnt = 0;
 #pragma unroll
   for (int q = 0; q < 3; q++) {
