@@ -341,6 +341,12 @@ def main():
                          "region is 0.14 s and a 10-iteration one sits inside the box-to-box spread: not measurements); steps_requested keeps the flag's value")
     ap.add_argument("--fused-filter", type=int, default=1, help="1 = observation filter, the rollout forward's operand and its exponent refresh in one "
                     "launch per range-step (hoic_zfilter_tiled; default); 0 = the four separate launches (A/B)")
+    ap.add_argument("--side-stream", type=int, default=1, help="1 = the rollout's set-up (noise, episode draws, filter forks) and tail (masks, bootstrap "
+                    "values, statistics) on a side stream beside the update (default); 0 = on the main stream (A/B)")
+    ap.add_argument("--pack-in-rollout", type=int, default=1, help="1 = the rollout's filter launches also write the update's packed first-layer "
+                    "operand (default); 0 = the update measures and packs the stacked states itself (A/B)")
+    ap.add_argument("--prepack", type=int, default=1, help="1 = the next update's packed weights are made behind this update's last optimizer steps "
+                    "(default); 0 = every first pass packs its own (A/B)")
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1 (one rank, default Box run only): append `other_configs` = Bottle and Banana at the same settings, 8 timed iterations each")
     args = ap.parse_args()
@@ -384,7 +390,9 @@ def main():
                            solver_iterations=args.solver_iterations, n_groups=args.groups, reserve_cus=args.reserve_cus, run_ahead=bool(args.run_ahead), scaling=args.scaling,
                            start_min=100 if args.workload in ("grasp", "closed-grasp") else 0, overlap_value_update=bool(args.overlap),
                            rollout_forward=args.rollout_forward, async_reward=bool(args.async_reward), update_streams=args.update_streams,
-                           sample_mode=args.sample_mode)
+                           sample_mode=args.sample_mode, side_stream=bool(args.side_stream))
+    agent.learner.prepack_weights = bool(args.prepack)
+    agent.pack_in_rollout = bool(args.pack_in_rollout)
     share = world if args.scaling == "strong" else 1
     steps_per_iter = int(math.ceil(math.ceil(cfg.min_batch_size / share) / args.envs))
     n_warm_it = int(math.ceil(args.warmup / steps_per_iter)) if args.warmup > 0 else 0

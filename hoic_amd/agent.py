@@ -146,6 +146,8 @@ class PPOLearner:
         self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
         self.opt_num_epochs = cfg.num_optim_epoch
         self._losses = None
+        self.on_value_updated = None           # called behind the value network's last optimizer step of an update, on that chain's stream
+        self.prepack_weights = True            # f16x3, two streams: the next update's packed weights are made behind this update's last steps
         self.overlap_value_update = False      # f16x3 only: value phase on a side stream, under the next rollout (AgentHandMimic sets it)
         self._value_stream = self._value_event = self._value_keep = None
         assert update_dtype in ("f32", "bf16", "f16x3")
@@ -199,7 +201,8 @@ class PPOLearner:
             states, actions = states[vflat], actions[vflat]
         if self.update_dtype == "f16x3" and states.is_cuda and states.dtype == torch.float32:
             from .mlp import PackedInput
-            states = PackedInput(states)            # split once per iteration, shared by both networks and all epochs
+            # split once per iteration, shared by both networks and all epochs -- by the rollout's own launches when it could
+            states = getattr(batch, "packed_states", None) or PackedInput(states)
             # this forward pass is also the value network's first training pass (the weights do not change in between)
             veng = self._split_engines()[0]
             self._v_first = veng.forward(states)
@@ -210,6 +213,9 @@ class PPOLearner:
                 values = self.value_net(states).float()
         if valid is not None:
             values = torch.zeros(T * N, 1, device=values.device, dtype=values.dtype).masked_scatter_(vflat[:, None], values)
+        ready = getattr(batch, "ready", None)
+        if ready is not None:            # rewards, masks and bootstrap values were finished on the sampler's side stream
+            torch.cuda.current_stream(self.device).wait_event(ready)
         advantages, returns = estimate_advantages(batch.rewards, batch.masks, values.reshape(T, N), self.gamma, self.tau,
                                                   getattr(batch, "next_values", None),
                                                   dist_group=True if self.distributed else None, valid=valid)
@@ -269,6 +275,9 @@ class PPOLearner:
                 veng.backward(dh)
                 self._allreduce_finish(self._allreduce_start(vparams))
                 self.optimizer_value.step()
+                veng.weights_changed()
+            if self.on_value_updated is not None:
+                self.on_value_updated()          # (on this chain's stream: e.g. the sampler's packed copy of the new value weights)
             return loss.detach()
 
         def policy_phase():
@@ -313,6 +322,9 @@ class PPOLearner:
                 p_pending, p_waiting = self._allreduce_start(pparams), True
                 self._allreduce_finish(v_pending)
                 self.optimizer_value.step()
+                veng.weights_changed()
+            if self.on_value_updated is not None:
+                self.on_value_updated()
             policy_step(p_pending)
             self._losses = (value_loss.detach(), surr.detach())
         elif self.update_streams == 2:
@@ -331,6 +343,13 @@ class PPOLearner:
             surr = policy_phase()
             cur.wait_stream(self._value_stream)
             self._losses = (value_loss, surr)
+            # Both networks' weights in the GEMMs' operand format for the NEXT update's first passes, packed on the side stream
+            # behind the last optimizer steps: ~25 launch-latency-bound kernels that otherwise sit in front of the next update's
+            # first value forward and first policy forward (0.25 ms of an iteration); here they run beside the next rollout's start.
+            if self.prepack_weights:
+                self._value_stream.wait_stream(cur)
+                with torch.cuda.stream(self._value_stream):
+                    veng.prepack(); peng.prepack()
         else:
             value_loss = value_phase()
             self._losses = (value_loss, policy_phase())
@@ -393,6 +412,8 @@ class PPOLearner:
                 torch.nn.utils.clip_grad_norm_(pparams, 40)
                 self._policy_clip_used = True
             self.optimizer_policy.step()
+            if self._engines is not None:
+                self._engines[1].weights_changed()
 
         if f16x3:
             return self._optimize_f16x3(states, actions, advantages, returns, weight, policy_step, vparams, pparams)
@@ -425,7 +446,7 @@ class AgentHandMimic:
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
                  start_min=0, overlap_value_update=False, rollout_forward="tiled", async_reward=True, fused_adam=True,
-                 update_streams=2, filter_mode="online", reserve_cus=0, run_ahead=True):
+                 update_streams=2, filter_mode="online", reserve_cus=0, run_ahead=True, side_stream=True):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
@@ -452,6 +473,9 @@ class AgentHandMimic:
         # rollout pipelining: 2 half-batches once a half still fills the GPU's 2048 wavefront slots
         self.n_groups = int(n_groups) if n_groups is not None else (2 if n_envs >= 4096 and n_envs % 2 == 0 else 1)
         self._streams = None
+        self._side_stream = None
+        self.pack_in_rollout = True            # the rollout's filter launches also write the update's packed input
+        self.side_stream = bool(side_stream)
         self.dtype = dtype
         self.training = training
         self.distributed = distributed
@@ -505,11 +529,26 @@ class AgentHandMimic:
             self.load_checkpoint(checkpoint_epoch)
             self.epoch = checkpoint_epoch
 
+    def _side(self):
+        """the stream for work beside the critical path (the rollout's set-up and tail, sample())"""
+        if self._streams:
+            # the LAST env range's stream: idle between rollouts, which is when the side work runs.  (A stream of its own cost
+            # a third of the rollout's throughput: the runtime maps streams onto four hardware queues in creation order, one more
+            # stream moved a range's reward stream onto the other range's queue and the two ranges took turns -- measured:
+            # rollout 2.16 M -> 1.24 M env-steps/s.)
+            return self._streams[-1]
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+            self._side_stream.wait_stream(torch.cuda.current_stream(self.device))      # everything set up so far (filter state, tables)
+        return self._side_stream
+
     def _groups(self):
         """env ranges stepped independently during the rollout ((first, count) pairs)"""
         G = max(1, min(self.n_groups, self.n_envs)) if self.device.type == "cuda" else 1
         if G > 1 and (self._streams is None or len(self._streams) != G):
             self._streams = [torch.cuda.Stream(self.device) for _ in range(G)]
+            for st_ in self._streams:       # (the side work at a rollout's start reads what was set up on the current stream so far)
+                st_.wait_stream(torch.cuda.current_stream(self.device))
         # ranges in units of 64 envs when the batch allows it (the tiled policy forward wants multiples of 32 rows), the first
         # ranges one unit longer; otherwise env by env
         unit = 64 if (self.n_envs % 64 == 0 and self.n_envs // 64 >= G) else 1
@@ -532,11 +571,13 @@ class AgentHandMimic:
             start = (u * self._max_start[seq].to(u.dtype)).to(torch.int32)
         return seq.to(torch.int32), start
 
-    def _make_log(self, steps, rewards, end_flags, done_flags, rinfo, valid, t0, defer=False):
+    def _make_log(self, steps, rewards, end_flags, done_flags, rinfo, valid, t0, defer=False, stats_dev=None):
         """LoggerRL of a rollout held as [T, N] tensors.  ``rewards`` carry the end bonus the kernel added on 'end'
         steps (hoic_capi.hip dev_poststep); the c_reward statistics are taken without it, as LoggerRL.step sees them
         (agent_handmimic.py:476-482) — they feed env.end_reward of the next iteration (:318-319)."""
         bonus = float(self.env.pushed_end_reward) if self.end_reward else 0.0
+        if stats_dev is not None:           # one launch made them (and the masks): hoic_rollout_stats, see sample()
+            return self._finish_log(steps, stats_dev[:4], stats_dev[4:], time.time() - t0, bonus, defer, both=stats_dev)
         cr = rewards.to(torch.float64) - bonus * end_flags.to(torch.float64)
         if valid is None:
             cmin, cmax, csum = cr.min(), cr.max(), cr.sum()
@@ -559,18 +600,87 @@ class AgentHandMimic:
             # (fixed horizon: every rank holds the same T x N, no need to read the reduced count back)
             steps = int(tot[-1].item()) if valid is not None else steps * self.world
         sample_time = time.time() - t0
+        return self._finish_log(steps, stats, c_info, sample_time, bonus, defer)
 
+    def _finish_log(self, steps, stats, c_info, sample_time, bonus, defer, both=None):
         def build(s, ci):
             return LoggerRL(num_steps=steps, num_episodes=int(s[3]), total_c_reward=s[0], min_c_reward=s[1], max_c_reward=s[2],
                             total_c_info=ci, sample_time=sample_time, end_bonus=bonus)
         if not (defer and stats.is_cuda):
             return build(stats.cpu().numpy(), c_info.cpu().numpy())
         # the host runs ahead: copy into pinned memory behind the reductions, wait for that copy only (PendingLog)
-        both = torch.cat([stats, c_info])
+        both = torch.cat([stats, c_info]) if both is None else both
         host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)      # (its own buffer: a log may be read after the next rollout was enqueued)
         host.copy_(both, non_blocking=True)
         ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
         return PendingLog(ev, lambda: build(host[:4].numpy().copy(), host[4:].numpy().copy()))
+
+    def _value_forward(self):
+        """TiledForward engine of the VALUE network's body for the bootstrap values of a rollout's final observations (f16x3
+        learner, GELU body, env count a multiple of 32): the rollout's own LDS-free forward kernels -- three launches and the
+        head kernel, behind a filter launch that writes their operand -- instead of PyTorch's float32 forward (three library
+        GEMMs, three GELU kernels, the head: 0.3 ms of every iteration).  Its packed weights are refreshed behind the value
+        network's last optimizer step of an update (PPOLearner.on_value_updated: on the update's value stream, under the policy
+        chain), or here when the weights changed in any other way (version counters)."""
+        if (self.learner.update_dtype != "f16x3" or self.rollout_forward != "tiled" or self.device.type != "cuda" or self.dtype != torch.float32
+                or not hasattr(self.value_net, "net") or not hasattr(self.value_net, "value_head")):
+            return None
+        from . import mlp as _mlp
+        if not _mlp.TiledForward.supports(self.value_net.net, self.n_envs) or self.value_net.value_head.out_features > 32:
+            return None
+        if getattr(self, "_vfwd", None) is None:
+            self._vfwd = _mlp.TiledForward(self.value_net.net, x_bound=getattr(self.running_state, "clip", None))
+            self._vfwd_version = None
+            self.learner.on_value_updated = self._refresh_value_forward
+        if self._vfwd_version != self._value_version():
+            self._refresh_value_forward()
+        return self._vfwd
+
+    def _value_version(self):
+        return tuple(l.weight._version for l in self.value_net.net.affine_layers)
+
+    def _refresh_value_forward(self):
+        if getattr(self, "_vfwd", None) is not None:
+            self._vfwd.refresh()
+            self._vfwd_version = self._value_version()
+
+    def _bootstrap_values(self, obs):
+        """V(s_T) of the final observations, normalised with the rollout's filter (no update) -> [N]"""
+        eng = self._value_forward()
+        if eng is None:
+            return self.value_net(self.running_state(obs, update=False)).squeeze(1)
+        from . import mlp as _mlp
+        state = self.running_state(obs, update=False, tiled=eng)
+        h = eng.forward(state, prepacked=bool(getattr(self.running_state, "last_call_packed", False)))
+        head = self.value_net.value_head
+        v = _mlp.action_head(h, head.weight.detach(), head.bias.detach())
+        eng.post_overflow()
+        if not self.run_ahead:
+            eng.wait_overflow()
+        return v.squeeze(1)
+
+    def _rollout_stats(self, rewards, flags_all, rinfo_all, masks):
+        """hoic_rollout_stats on the rollout's [T, N] storage: the logger's sums (float64 [4 + 9]: sum / min / max of c_reward,
+        finished episodes, the reward terms) and the masks in one launch; None when this is not one rank's float32 CUDA rollout"""
+        if self.distributed or not (rewards.is_cuda and rewards.dtype == torch.float32 and rewards.is_contiguous() and flags_all.is_contiguous()
+                                    and rinfo_all.is_contiguous() and masks.is_contiguous() and masks.dtype == torch.float32):
+            return None
+        L = lib.load()
+        if not hasattr(L, "hoic_rollout_stats"):
+            return None
+        import ctypes as C
+        n_info = rinfo_all.shape[-1]
+        if getattr(self, "_stats_scratch", None) is None:
+            self._stats_scratch = torch.zeros(int(L.hoic_rollout_stats_scratch_doubles(n_info)), dtype=torch.float64, device=rewards.device)
+        out = torch.empty(4 + n_info, dtype=torch.float64, device=rewards.device)
+        bonus = float(self.env.pushed_end_reward) if self.end_reward else 0.0
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(rewards.device):
+            rc = L.hoic_rollout_stats(rewards.numel(), ptr(rewards), ptr(flags_all), ptr(rinfo_all), n_info, bonus, ptr(masks), ptr(self._stats_scratch),
+                                      ptr(out), C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
+        if rc != 0:
+            raise lib.HoicError(f"hoic_rollout_stats failed ({rc}): {L.hoic_last_error().decode()}")
+        return out
 
     # ------------------------------------------------------------------ rollout (sample / sample_process, :430-535)
     def _rollout_forward(self, groups):
@@ -583,8 +693,9 @@ class AgentHandMimic:
             return None
         if getattr(self, "_fwd_engines", None) is None or len(self._fwd_engines) != len(groups):
             self._fwd_engines = [_mlp.TiledForward(self.policy_net.net, x_bound=getattr(self.running_state, "clip", None)) for _ in groups]
-        for e in self._fwd_engines:
-            e.refresh()
+        self._fwd_engines[0].refresh()
+        for e in self._fwd_engines[1:]:       # one packed copy of the weights for all ranges (they are read-only during the rollout)
+            e.refresh(share=self._fwd_engines[0])
         return self._fwd_engines
 
     @torch.no_grad()
@@ -617,16 +728,31 @@ class AgentHandMimic:
         # (measured: 6 ms of a 36 ms rollout).  One engine per range (own buffers and exponents: the ranges run concurrently).
         fwd = self._rollout_forward(groups) if (dt == torch.float32 and dev.type == "cuda") else None
         std = torch.exp(self.policy_net.action_log_std) if fwd is not None else None
-        # the rollout's N(0, 1) draws in one launch up front: a range's chain then samples inside the action-head kernel
-        noise_all = torch.randn(T, N, self.action_dim, device=dev, dtype=dt) if fwd is not None else None
+        # What the rollout needs that does not depend on the update before it -- its N(0, 1) draws, the next-episode draws of all
+        # T steps, the forks of the observation filter -- is enqueued on the SIDE stream: the host runs a phase ahead, so these
+        # ~25 launch-latency-bound kernels run under the update's GEMMs instead of between the update and the first policy
+        # forward (0.3 ms of every iteration, profiles/r05_rollout_trace_2ranges.csv.gz).  Same generators, same call order: the
+        # same numbers.  Tensors made there belong to that stream's memory pool; every stream that reads them is recorded.
+        side = self._side() if (self.side_stream and fwd is not None and not self.distributed) else None
+        users = ([torch.cuda.current_stream(dev)] + (list(self._streams) if use_streams else [])) if side is not None else []
+
+        def on_side(*ts):
+            for t_ in ts:
+                for s_ in users:
+                    t_.record_stream(s_)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            # the rollout's N(0, 1) draws in one launch up front: a range's chain then samples inside the action-head kernel
+            noise_all = torch.randn(T, N, self.action_dim, device=dev, dtype=dt) if fwd is not None else None
+            nseq_all, nstart_all = self._draw_episodes(T * N)
+            nseq_all, nstart_all = nseq_all.view(T, N), nstart_all.view(T, N)
+            if side is not None:
+                on_side(noise_all, nseq_all, nstart_all)
         # Per-step outputs go straight into the rollout's [T, N, .] storage (no copy kernels in a range's chain), the
         # next-episode draws of all T steps are made up front, masks and statistics are derived once at the end.
         direct = dt == torch.float32 and dev.type == "cuda"
         rinfo_all = torch.empty(T, N, 9, device=dev, dtype=torch.float32)
         flags_all = torch.empty(T, N, 4, device=dev, dtype=torch.int32)
         pct = torch.empty(N, device=dev, dtype=torch.float32)
-        nseq_all, nstart_all = self._draw_episodes(T * N)
-        nseq_all, nstart_all = nseq_all.view(T, N), nstart_all.view(T, N)
         # The observation filter of a pipelined rollout: every env range updates its own fork of the filter with its own
         # observations (the reference's sampler threads each run their own copy, agent.py:64-120) and the forks are merged
         # after the rollout -- the same final statistics as one shared filter, and no dependency between the ranges'
@@ -639,9 +765,14 @@ class AgentHandMimic:
         frozen = self.filter_mode == "frozen"
         identity = frozen and float(self.running_state.n) == 0
         raw_all = torch.empty(T, N, self.state_dim, device=dev, dtype=torch.float32) if frozen else None
-        forks = [self.running_state.fork() for _ in groups] if (use_streams and not frozen) else None
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            forks = [self.running_state.fork() for _ in groups] if (use_streams and not frozen) else None
+            if side is not None and forks:
+                on_side(*[f._st for f in forks])
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        if side is not None:
+            main.wait_stream(side)      # (also the previous rollout's tail below: it wrote self._obs's successor state and the masks)
         if use_streams:
-            main = torch.cuda.current_stream(dev)
             for st_ in self._streams:
                 st_.wait_stream(main)
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
@@ -650,6 +781,18 @@ class AgentHandMimic:
         if async_reward:
             self.env.sim.set_async_reward(True)
             self.env.sim.set_cu_reserve(self.reserve_cus if use_streams else 0)
+        # The update's first-layer operand (the batch's states in the f16x3 GEMMs' packed row format) is written by the same
+        # launches, range-step by range-step: the update then starts with its GEMMs instead of a maximum pass and a pack pass
+        # over the 53 k x 617 states.  One buffer per agent, reused: the update of an iteration is over (stream order) before the
+        # next rollout writes -- unless the value phase runs under the next rollout (overlap_value_update: not used then).
+        pin = None
+        if (fwd is not None and direct and not frozen and self.pack_in_rollout and not self.learner.overlap_value_update
+                and all(e.fused_filter_ok(c) for e, (_, c) in zip(fwd, groups))):
+            from .mlp import PackedInput
+            pin = getattr(self, "_rollout_input", None)
+            if pin is None or pin.M != T * N:
+                pin = self._rollout_input = PackedInput.for_rollout(T * N, self.state_dim, getattr(self.running_state, "clip", None), dev)
+        rows_packed = pin is not None
         gemm_done = None
         t_host0 = time.perf_counter()
         for t in range(T):
@@ -664,7 +807,9 @@ class AgentHandMimic:
                         state = (torch.clamp(obs[sl], -5.0, 5.0).to(dt) if identity else
                                  filt(obs[sl], update=False, out=states[t, sl] if direct else None, tiled=eng))
                     else:
-                        state = filt(obs[sl], out=states[t, sl] if direct else None, tiled=eng)
+                        state = filt(obs[sl], out=states[t, sl] if direct else None, tiled=eng,
+                                     packed_rows=None if pin is None else pin.P[t * N + first:t * N + first + count])
+                        rows_packed = rows_packed and bool(getattr(filt, "last_call_packed_rows", False))
                     packed = bool(getattr(filt, "last_call_packed", False)) and not (frozen and identity)
                     if state.data_ptr() != states[t, sl].data_ptr():
                         states[t, sl] = state
@@ -696,31 +841,55 @@ class AgentHandMimic:
         if frozen:
             self.running_state.push(raw_all.view(T * N, self.state_dim))       # the batch's own observations, after the rollout
             del raw_all
-        if async_reward:
-            self.env.sim.set_async_reward(False)        # the main stream waits for every outstanding reward part
-        done_all = flags_all[:, :, 2] != 0
-        masks.copy_((~done_all).to(dt))
-        obs = self.env.get_obs()
-        self._obs = obs
-        if fwd is not None:
-            for e in fwd:           # hidden activations beyond the float16 range under their delayed exponents: loud, not silent
-                e.post_overflow()
-                if not self.run_ahead:
-                    e.wait_overflow()
-        if self.distributed:
-            self.running_state.sync()          # one observation filter for all ranks from here on
-        next_state = self.running_state(obs, update=False)
-        self.learner.wait_value_update()          # the bootstrap below is the first reader of the value network since the update
-        next_values = self.value_net(next_state).squeeze(1)
-        batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
-                                exps=torch.ones(T, N, device=dev, dtype=dt), next_values=next_values, valid=None)
-        log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0, defer=self.run_ahead)
+        # The rollout's TAIL -- the wait for the last reward parts, the masks, the bootstrap values of the final observations (a
+        # float32 forward of the value network through PyTorch) and the logger's statistics: ~45 small launches, 0.8 ms -- is
+        # needed by the advantages only, and those are formed behind the update's first value forward over the whole batch
+        # (1.5 ms of GEMMs that need the states alone).  With the f16x3 learner on one rank it goes to the side stream; the
+        # learner waits for `batch.ready` before it reads rewards, masks or next_values (PPOLearner.update_params).  (Not with
+        # the float32 learner: its library GEMMs must not meet this forward's on another stream)
+        ones = torch.ones(T, N, device=dev, dtype=dt)
+        tail = side if (side is not None and self.learner.update_dtype == "f16x3") else None
+        if tail is not None:
+            tail.wait_stream(main)
+            for t_ in (rewards, rinfo_all, flags_all, masks, self.env.get_obs()):
+                t_.record_stream(tail)
+        ready = None
+        with (torch.cuda.stream(tail) if tail is not None else contextlib.nullcontext()):
+            if async_reward:
+                self.env.sim.set_async_reward(False)        # the current stream waits for every outstanding reward part
+            stats_dev = self._rollout_stats(rewards, flags_all, rinfo_all, masks) if direct else None
+            if stats_dev is None:
+                done_all = flags_all[:, :, 2] != 0
+                masks.copy_((~done_all).to(dt))
+            obs = self.env.get_obs()
+            self._obs = obs
+            if fwd is not None:
+                for e in fwd:           # hidden activations beyond the float16 range under their delayed exponents: loud, not silent
+                    e.post_overflow()
+                    if not self.run_ahead:
+                        e.wait_overflow()
+            if self.distributed:
+                self.running_state.sync()          # one observation filter for all ranks from here on
+            self.learner.wait_value_update()          # the bootstrap below is the first reader of the value network since the update
+            next_values = self._bootstrap_values(obs)
+            if tail is not None:
+                next_values.record_stream(main)
+                ready = torch.cuda.Event(); ready.record(tail)
+            batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
+                                    exps=ones, next_values=next_values, valid=None, ready=ready,
+                                    packed_states=pin if rows_packed else None)
+            if stats_dev is not None:
+                log = self._make_log(T * N, rewards, None, None, rinfo_all, None, t0, defer=self.run_ahead, stats_dev=stats_dev)
+            else:
+                log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0, defer=self.run_ahead)
         self.last_rollout_steps = T
         return batch, log
 
     def _resolve_rollout_checks(self):
         for e in (getattr(self, "_fwd_engines", None) or []):
             e.wait_overflow()
+        if getattr(self, "_vfwd", None) is not None:
+            self._vfwd.wait_overflow()
 
     @torch.no_grad()
     def _sample_episodes(self, min_batch_size, sync_every=8):

@@ -1401,6 +1401,28 @@ extern "C" int32_t hoic_gae(int32_t T, int32_t N, const float* d_rewards, const 
   HIPCHK(hipGetLastError());
   return HOIC_OK;
 }
+extern "C" int32_t hoic_normalize_advantages(int64_t n, float* d_adv, double* d_scratch, void* stream) {
+  if (n < 2 || !d_adv || !d_scratch) { set_err("hoic_normalize_advantages: needs n >= 2, the advantages and 512 doubles of scratch"); return HOIC_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(hoic_adv_moments_kernel, dim3(ADV_BLOCKS), dim3(256), 0, st, d_adv, (long long)n, d_scratch);
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(hoic_adv_apply_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, d_adv, (long long)n, d_scratch);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
+extern "C" int64_t hoic_rollout_stats_scratch_doubles(int32_t n_info) { return (int64_t)RS_BLOCKS * (4 + (n_info > 0 ? n_info : 0)) + 1; }
+extern "C" int32_t hoic_rollout_stats(int64_t n, const float* d_rewards, const int32_t* d_flags, const float* d_reward_info, int32_t n_info,
+                                      float end_bonus, float* d_masks, double* d_scratch, double* d_stats, void* stream) {
+  if (n <= 0 || !d_rewards || !d_flags || n_info < 0 || n_info > RS_MAXINFO || (n_info && !d_reward_info) || !d_scratch || !d_stats) {
+    set_err("hoic_rollout_stats: bad arguments (at most 16 reward terms)"); return HOIC_ERR_ARG;
+  }
+  // the last double of the scratch buffer is the ticket (zero before the first launch; every launch leaves it zero)
+  unsigned* ticket = (unsigned*)(d_scratch + (size_t)RS_BLOCKS * (4 + n_info));
+  hipLaunchKernelGGL(hoic_rollout_stats_kernel, dim3(RS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (long long)n, d_rewards, d_flags, d_reward_info,
+                     n_info, end_bonus, d_masks, d_scratch, ticket, d_stats);
+  HIPCHK(hipGetLastError());
+  return HOIC_OK;
+}
 extern "C" int64_t hoic_zfilter_scratch_doubles(int32_t n, int32_t dim) {
   if (n <= 0 || dim <= 0) return 0;
   return (int64_t)((n + ZF_ROWS - 1) / ZF_ROWS) * dim * 2;

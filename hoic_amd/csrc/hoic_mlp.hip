@@ -683,7 +683,8 @@ __global__ __launch_bounds__(64) void hoic_zfilter_tiled_kernel(const float* __r
                                                                  const double* __restrict__ state_in, double* __restrict__ state_out, int update,
                                                                  float clip, float* __restrict__ y, char* __restrict__ T, int Kp,
                                                                  int* __restrict__ exps, int slot_x, float* __restrict__ amax, int nslots,
-                                                                 unsigned long long mask, int target, int* __restrict__ overflow) {
+                                                                 unsigned long long mask, int target, int* __restrict__ overflow,
+                                                                 u16* __restrict__ P, int KpP) {
   // ONE wavefront per workgroup (a 32-row tile x 16 columns), like every other kernel of a range's chain: beside three 168-register
   // substep wavefronts a SIMD has no room for another wavefront, and a workgroup of four must find four free slots on one CU at the
   // same time -- the 256-thread form of this kernel took 280 us of mostly waiting.
@@ -738,6 +739,10 @@ __global__ __launch_bounds__(64) void hoic_zfilter_tiled_kernel(const float* __r
   for (int k = 0; k < 4; k++) { hi[k] = (w[2 * k] & 0xffffu) | (w[2 * k + 1] << 16); lo[k] = (w[2 * k] >> 16) | (w[2 * k + 1] & 0xffff0000u); }
   char* t = T + ((size_t)a * (Kp >> 4) + strip) * 2048 + lane * 16;
   *(u32x4*)t = hi; *(u32x4*)(t + 1024) = lo;
+  // the same eight columns as one H8L8 group of the UPDATE's row-major operand (hoic_mlp_pack, rows [n x 2 KpP]): the rollout
+  // leaves the batch packed for the update's first-layer GEMMs, which then need neither a maximum pass nor a pack pass over
+  // the 53 k x 617 states (same exponent: the filter's clip bounds the input)
+  if (P) { u16* g8 = P + ((size_t)r * KpP + c0) * 2; *(u32x4*)g8 = hi; *(u32x4*)(g8 + 8) = lo; }
 }
 
 struct FwdArgs {
@@ -1097,16 +1102,19 @@ extern "C" int32_t hoic_mlp_pack_tiled(const float* d_x, int32_t R, int32_t C, i
 }
 extern "C" int32_t hoic_zfilter_tiled(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out, int32_t update,
                                       float clip, float* d_y, double* d_scratch, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x,
-                                      float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream) {
+                                      float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* d_P, int32_t KpP,
+                                      void* stream) {
   if (n <= 0 || dim <= 0 || !d_x || !d_state_in || !d_y || !d_T || !d_exps || (n % ZF_ROWS) || Kp < dim || (Kp & 15) ||
       nslots < 0 || nslots > 64 || (mask && !d_amax)) {
     hoic_set_error("hoic_zfilter_tiled: n must be a multiple of 128, Kp a multiple of 16 and >= dim"); return HOIC_ERR_ARG;
   }
+  if (d_P && (KpP < Kp || (KpP & 7))) { hoic_set_error("hoic_zfilter_tiled: KpP must be a multiple of 8 and >= Kp"); return HOIC_ERR_ARG; }
   if (update && (!d_state_out || !d_scratch || d_state_out == d_state_in)) { hoic_set_error("hoic_zfilter_tiled: update needs a scratch buffer and a state_out that is not state_in"); return HOIC_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   if (update) hipLaunchKernelGGL(hoic_zfilter_moments2_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(n / ZF_ROWS)), dim3(64), 0, st, d_x, n, dim, d_scratch);
   hipLaunchKernelGGL(hoic_zfilter_tiled_kernel, dim3((unsigned)(Kp >> 4), (unsigned)(n / 32)), dim3(64), 0, st, d_x, n, dim, d_scratch,
-                     d_state_in, d_state_out, update, clip, d_y, (char*)d_T, Kp, d_exps, slot_x, d_amax, nslots, (unsigned long long)mask, target, d_overflow);
+                     d_state_in, d_state_out, update, clip, d_y, (char*)d_T, Kp, d_exps, slot_x, d_amax, nslots, (unsigned long long)mask, target, d_overflow,
+                     (u16*)d_P, KpP);
   MCHK(hipGetLastError());
   return HOIC_OK;
 }

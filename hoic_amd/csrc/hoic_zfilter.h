@@ -113,3 +113,90 @@ __global__ void hoic_gae_kernel(int T, int N, const float* __restrict__ rewards,
     prev_v = v;
   }
 }
+
+// ---- normalisation of the batch's advantages (core/common.py:22: (A - mean) / std, torch's unbiased std): two launches instead
+// of the ~15 tensor kernels (two reductions and a dozen scalar operations, each a 5-6 us launch in the middle of the update's
+// first milliseconds).  Sums in float64 in a fixed order -- ADV_BLOCKS chunk sums by a tree per block, then every block of the
+// second launch adds the chunk sums in index order -- so the result does not depend on the launch.
+#define ADV_BLOCKS 256
+__global__ __launch_bounds__(256) void hoic_adv_moments_kernel(const float* __restrict__ a, long long n, double* __restrict__ part) {
+  __shared__ double s0[256], s1[256];
+  const long long per = (n + ADV_BLOCKS - 1) / ADV_BLOCKS, lo = (long long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double x0 = 0.0, x1 = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) { const double v = (double)a[i]; x0 += v; x1 += v * v; }
+  s0[threadIdx.x] = x0; s1[threadIdx.x] = x1;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0[0]; part[2 * blockIdx.x + 1] = s1[0]; }
+}
+__global__ __launch_bounds__(256) void hoic_adv_apply_kernel(float* __restrict__ a, long long n, const double* __restrict__ part) {
+  __shared__ double sm[2];
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int b = 0; b < ADV_BLOCKS; b++) { t0 += part[2 * b]; t1 += part[2 * b + 1]; }
+    const double mean = t0 / (double)n, var = (t1 - (double)n * mean * mean) / (double)(n - 1);
+    sm[0] = mean; sm[1] = 1.0 / sqrt(var);
+  }
+  __syncthreads();
+  const double mean = sm[0], rstd = sm[1];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) a[i] = (float)(((double)a[i] - mean) * rstd);
+}
+
+// ---- the logger's statistics of a fixed-horizon rollout (LoggerRL as the reference's sampler fills it step by step,
+// agent_handmimic.py:476-482, uhc/khrylib/rl/core/logger_rl.py) and the batch's masks, in ONE launch over the rollout's [T x N]
+// storage instead of ~28 tensor kernels at the end of every rollout: c_reward = reward - end bonus on 'end' steps; its sum,
+// minimum and maximum, the number of finished episodes and the sums of the nine reward terms, all in float64; masks = 1 - done.
+// Fixed order: a tree per block, then the LAST block to finish (a ticket) adds the blocks' partial results in block order.
+#define RS_BLOCKS 128
+#define RS_MAXINFO 16
+__global__ __launch_bounds__(256) void hoic_rollout_stats_kernel(long long n, const float* __restrict__ rewards, const int* __restrict__ flags,
+                                                                 const float* __restrict__ rinfo, int n_info, float bonus,
+                                                                 float* __restrict__ masks, double* __restrict__ part, unsigned* __restrict__ ticket,
+                                                                 double* __restrict__ stats) {
+  __shared__ double red[256];
+  __shared__ bool last;
+  const int tid = threadIdx.x, W = 4 + n_info;
+  const long long per = (n + RS_BLOCKS - 1) / RS_BLOCKS, lo = (long long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double acc[4 + RS_MAXINFO];
+  acc[0] = 0.0; acc[1] = 1e300; acc[2] = -1e300; acc[3] = 0.0;
+  for (int k = 0; k < n_info; k++) acc[4 + k] = 0.0;
+  for (long long i = lo + tid; i < hi; i += 256) {
+    const int end = flags[4 * i + 1], done = flags[4 * i + 2];
+    const double cr = (double)rewards[i] - (double)bonus * (end != 0 ? 1.0 : 0.0);
+    acc[0] += cr; acc[1] = cr < acc[1] ? cr : acc[1]; acc[2] = cr > acc[2] ? cr : acc[2]; acc[3] += done != 0 ? 1.0 : 0.0;
+    for (int k = 0; k < n_info; k++) acc[4 + k] += (double)rinfo[i * n_info + k];
+    if (masks) masks[i] = done != 0 ? 0.f : 1.f;
+  }
+  for (int q = 0; q < W; q++) {       // one tree per quantity (sum / min / max)
+    red[tid] = acc[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double a = red[tid], b = red[tid + o];
+        red[tid] = q == 1 ? (b < a ? b : a) : (q == 2 ? (b > a ? b : a) : a + b);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) part[(size_t)blockIdx.x * W + q] = red[0];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == RS_BLOCKS - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (tid < W) {
+    double r = tid == 1 ? 1e300 : (tid == 2 ? -1e300 : 0.0);
+    for (int b = 0; b < RS_BLOCKS; b++) {
+      const double v = __hip_atomic_load(&part[(size_t)b * W + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by other blocks)
+      r = tid == 1 ? (v < r ? v : r) : (tid == 2 ? (v > r ? v : r) : r + v);
+    }
+    stats[tid] = r;
+  }
+  if (tid == 0) *ticket = 0u;       // ready for the next launch
+}

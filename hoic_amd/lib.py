@@ -40,7 +40,7 @@ class RewardParams(C.Structure):
 
 EXPORTS = ["hoic_create", "hoic_destroy", "hoic_num_envs", "hoic_obs_dim", "hoic_action_dim", "hoic_last_error", "hoic_build_id",
            "hoic_set_config", "hoic_set_reward_params", "hoic_set_reward_params_async", "hoic_set_mode", "hoic_set_expert", "hoic_reset", "hoic_step", "hoic_step_range",
-           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_tiled", "hoic_zfilter_absorb", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_enable_timing",
+           "hoic_get_state", "hoic_set_state", "hoic_get_rfc_score", "hoic_probe_forward", "hoic_probe_qp", "hoic_zfilter", "hoic_zfilter_tiled", "hoic_zfilter_absorb", "hoic_zfilter_scratch_doubles", "hoic_gae", "hoic_normalize_advantages", "hoic_rollout_stats", "hoic_rollout_stats_scratch_doubles", "hoic_enable_timing",
            "hoic_last_step_ms", "hoic_last_poststep_ms", "hoic_step_times", "hoic_env_durations", "hoic_set_expert_reserve",
            "hoic_append_expert_frame", "hoic_get_diagnostics", "hoic_mlp_pack", "hoic_mlp_amax", "hoic_mlp_update_exps",
            "hoic_mlp_gemm", "hoic_mlp_slab_reduce", "hoic_mlp_rowsum_packed", "hoic_mlp_set_pipeline", "hoic_mlp_gemm_tn",
@@ -100,6 +100,12 @@ def load():
     L.hoic_step_range.argtypes = [vp, i32, i32] + [vp] * 9
     L.hoic_zfilter.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, vp]
     L.hoic_gae.argtypes = [i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp]
+    if hasattr(L, "hoic_rollout_stats"):
+        L.hoic_rollout_stats.argtypes = [C.c_int64, vp, vp, vp, i32, f32, vp, vp, vp, vp]
+        L.hoic_rollout_stats_scratch_doubles.argtypes = [i32]
+        L.hoic_rollout_stats_scratch_doubles.restype = C.c_int64
+    if hasattr(L, "hoic_normalize_advantages"):
+        L.hoic_normalize_advantages.argtypes = [C.c_int64, vp, vp, vp]
     L.hoic_zfilter_scratch_doubles.argtypes = [i32, i32]
     L.hoic_zfilter_scratch_doubles.restype = C.c_int64
     L.hoic_probe_qp.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp]
@@ -114,7 +120,7 @@ def load():
         if os.environ.get("HOIC_LIB") and not hasattr(L, n):
             continue      # a development build of an earlier revision (A/B runs): entry points added since are absent there
         if n not in ("hoic_create", "hoic_destroy", "hoic_last_error", "hoic_build_id", "hoic_last_step_ms", "hoic_last_poststep_ms",
-                     "hoic_zfilter_scratch_doubles"):
+                     "hoic_zfilter_scratch_doubles", "hoic_rollout_stats_scratch_doubles"):
             getattr(L, n).restype = i32
     _lib = L
     return L

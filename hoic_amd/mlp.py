@@ -77,7 +77,7 @@ class _Kernels:
         L.hoic_mlp_forward_tiled.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         self.has_zfilter_tiled = hasattr(L, "hoic_zfilter_tiled")      # (absent only in earlier development builds loaded through HOIC_LIB)
         if self.has_zfilter_tiled:
-            L.hoic_zfilter_tiled.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, vp, i32, vp, i32, vp, i32, C.c_uint64, i32, vp, vp]
+            L.hoic_zfilter_tiled.argtypes = [i32, i32, vp, vp, vp, i32, f32, vp, vp, vp, i32, vp, i32, vp, i32, C.c_uint64, i32, vp, vp, i32, vp]
             L.hoic_zfilter_tiled.restype = i32
         L.hoic_mlp_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
         L.hoic_mlp_head.restype = i32
@@ -191,10 +191,11 @@ class ScaleTable:
         K.chk(K.L.hoic_mlp_amax(_ptr(x), _ptr(mul), x.numel(), _ptr(self.amax), slot, _stream(self.device)), "hoic_mlp_amax")
 
 
-def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None, measure=True):
+def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None, measure=True, out=None):
     """float32 [R, C] (optionally times ``mul`` elementwise) -> packed tensors (uint16 views of float16 pairs):
     ``rows``: [Rp, 2 Cp], ``transposed``: [Cp, 2 Rp].  ``measure``: set the slot's exponent from this tensor's own maximum
-    first (exact; used for inputs, weights and the loss-side gradient)."""
+    first (exact; used for inputs, weights and the loss-side gradient).  ``out``: (P, PT) buffers of those shapes to fill
+    instead of new ones (None entries as for ``rows`` / ``transposed``)."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
     Rp = R if Rp is None else Rp
@@ -205,8 +206,13 @@ def pack(x, table, slot, Rp=None, Cp=None, rows=True, transposed=False, mul=None
         assert x.is_contiguous()
         table.measure(slot, x, mul)
         table.update([slot], exact=True)
-    P = torch.empty(Rp, 2 * Cp, dtype=torch.float16, device=dev) if rows else None
-    PT = torch.empty(Cp, 2 * Rp, dtype=torch.float16, device=dev) if transposed else None
+    if out is not None:
+        P, PT = out
+        assert (P is None) == (not rows) and (PT is None) == (not transposed)
+        assert (P is None or (P.shape == (Rp, 2 * Cp) and P.is_contiguous())) and (PT is None or (PT.shape == (Cp, 2 * Rp) and PT.is_contiguous()))
+    else:
+        P = torch.empty(Rp, 2 * Cp, dtype=torch.float16, device=dev) if rows else None
+        PT = torch.empty(Cp, 2 * Rp, dtype=torch.float16, device=dev) if transposed else None
     K.chk(K.L.hoic_mlp_pack(_ptr(x), _ptr(mul), R, Cc, x.stride(0), _ptr(P), _ptr(PT), Rp, Cp, _ptr(table.exps), slot, _stream(dev)),
           "hoic_mlp_pack")
     return P, PT
@@ -267,6 +273,23 @@ class PackedInput:
         kernels()
         with torch.cuda.device(x.device):
             self.P, self.PT = pack(x.contiguous(), self.table, 0, self.Mp, self.Kp, rows=True, transposed=(GEMM_MODE != 3))
+
+    @classmethod
+    def for_rollout(cls, rows, cols, x_bound, device):
+        """An input the ROLLOUT fills row range by row range (hoic_zfilter_tiled's d_P: the launch that normalises a range-step's
+        observations also writes them here), at the constant exponent a known bound of |x| gives -- the one TiledForward uses for
+        the same rows.  Zeroed once: the launches never touch the padding.  None when the layout has no such form."""
+        if GEMM_MODE != 3 or x_bound is None or rows % 256:
+            return None
+        self = cls.__new__(cls)
+        self.M, self.K = rows, cols
+        self.Mp, self.Kp = rows, _rup(cols, 128)
+        self.table = ScaleTable(device)
+        with torch.no_grad():
+            self.table.exps[0] = TARGET_LOG2 - int(np.ceil(np.log2(float(x_bound))))
+        self.P = torch.zeros(self.Mp, 2 * self.Kp, dtype=torch.float16, device=device)
+        self.PT = None
+        return self
 
 
 def pick_splits(tiles, nkt, n_cu=256, max_splits=64):
@@ -342,6 +365,9 @@ class SplitMLP:
         self.splits = wgrad_splits
         self.M = None
         self.first = True
+        self.Wp = self.WpT = None
+        self._packed_version = None
+        self._pack_event = None
         self.table = ScaleTable(self.dev)         # this network's own exponents; slot 0 mirrors the shared input's
 
     # ------------------------------------------------------------------ buffers for a batch size
@@ -372,12 +398,36 @@ class SplitMLP:
         self.slabs = torch.empty(max(sp * n * k for sp, n, k in zip(self.layer_splits, self.dims_out, self.Kp)), dtype=torch.float32, device=dev)
         self.first = True
 
+    def _weights_version(self):
+        return tuple(l.weight._version for l in self.layers)
+
     def _pack_weights(self, table):
-        self.Wp, self.WpT = [], []
+        """the weights in the GEMMs' operand format (exact exponents), into buffers this engine keeps: a forward pass on one
+        stream and the backward pass of the pass before it on another never meet in the allocator"""
+        if self.Wp is None:
+            h = lambda r, c: torch.empty(r, 2 * c, dtype=torch.float16, device=self.dev)
+            self.Wp = [h(n, kp) for n, kp in zip(self.dims_out, self.Kp)]
+            self.WpT = [None] + [h(kp, n) for n, kp in zip(self.dims_out[1:], self.Kp[1:])]
         for i, l in enumerate(self.layers):
             W = l.weight.detach()
-            P, PT = pack(W, table, self.SLOT_W0 + i, W.shape[0], self.Kp[i], rows=True, transposed=(i > 0))
-            self.Wp.append(P); self.WpT.append(PT)
+            pack(W, table, self.SLOT_W0 + i, W.shape[0], self.Kp[i], rows=True, transposed=(i > 0), out=(self.Wp[i], self.WpT[i]))
+        self._packed_version = self._weights_version()
+
+    def weights_changed(self):
+        """the caller stepped the weights (an optimizer step): the packed copies are stale, whatever the tensors' version
+        counters say"""
+        self._packed_version = None
+
+    @_on_device
+    def prepack(self):
+        """Pack the weights NOW, on the current stream, for the next forward pass (which then waits for this stream's work
+        instead of packing itself): the learner does this behind an update's last optimizer step, beside the next rollout's
+        start, so that the next update's first passes begin with their GEMMs.  A forward pass packs by itself whenever the
+        weights changed since (version counters of the weight tensors, or ``weights_changed()``)."""
+        if self._packed_version is None or self._packed_version != self._weights_version():
+            self._pack_weights(self.table)
+        self._pack_event = torch.cuda.Event()
+        self._pack_event.record(torch.cuda.current_stream(self.dev))
 
     # ------------------------------------------------------------------ forward
     @_on_device
@@ -396,7 +446,11 @@ class SplitMLP:
             self.first = False
         else:
             t.update([self.SLOT_H0 + i for i in range(L - 1)])         # exponents of the hidden activations from the last pass
-        self._pack_weights(t)
+        if self._pack_event is not None:          # packed ahead on another stream (prepack)
+            torch.cuda.current_stream(self.dev).wait_event(self._pack_event)
+            self._pack_event = None
+        if self._packed_version is None or self._packed_version != self._weights_version():
+            self._pack_weights(t)
         A, sa = inp.P, self.SLOT_X
         for i, l in enumerate(self.layers):
             last = i == L - 1
@@ -647,9 +701,17 @@ class TiledForward:
                 and all(l.out_features % 64 == 0 for l in mlp.affine_layers) and mlp.affine_layers[0].weight.is_cuda)
 
     @_on_device
-    def refresh(self):
-        """pack the current weights (exact exponents) into format T"""
+    def refresh(self, share=None):
+        """pack the current weights (exact exponents) into format T; ``share``: another engine of the same network that has just
+        done so -- its packed weights are used as they are (read-only) and their exponents copied (one small device copy instead
+        of nine launches)"""
         K, t = kernels(), self.table
+        if share is not None:
+            L = len(self.layers)
+            assert share.layers[0] is self.layers[0] and share.WT is not None
+            self.WT = share.WT
+            t.exps[self.SLOT_W0:self.SLOT_W0 + L].copy_(share.table.exps[self.SLOT_W0:self.SLOT_W0 + L])
+            return
         if self.WT is None:
             self.WT = [torch.empty(n * kp * 4, dtype=torch.uint8, device=self.dev) for n, kp in zip(self.dims_out, self.Kp)]
         for i, l in enumerate(self.layers):

@@ -123,6 +123,18 @@ def estimate_advantages(rewards, masks, values, gamma, tau, next_values=None, di
             adv[t] = prev_a
             prev_v = values[t]
         returns = values + adv
+    if valid is None and dist_group is None and adv.is_cuda and adv.dtype == torch.float32 and adv.is_contiguous() and adv.numel() >= 2:
+        from . import lib
+        L = lib.load()
+        if hasattr(L, "hoic_normalize_advantages"):      # two launches (float64 sums in a fixed order) instead of ~15 tensor kernels
+            import ctypes as C
+            scratch = torch.empty(512, dtype=torch.float64, device=adv.device)
+            with torch.cuda.device(adv.device):
+                rc = L.hoic_normalize_advantages(adv.numel(), C.c_void_p(adv.data_ptr()), C.c_void_p(scratch.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(adv.device).cuda_stream))
+            if rc != 0:
+                raise lib.HoicError(f"hoic_normalize_advantages failed ({rc}): {L.hoic_last_error().decode()}")
+            return adv, returns
     if valid is None:
         a, cnt = adv, torch.full((), float(adv.numel()), device=adv.device, dtype=adv.dtype)       # (a fill, not a host-to-device copy)
     else:
@@ -304,7 +316,7 @@ class BatchZFilter:
     def _device_path(self, x):
         return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.dim
 
-    def _call_device(self, x, update, out=None, tiled=None):
+    def _call_device(self, x, update, out=None, tiled=None, packed_rows=None):
         """hoic_zfilter: two launches (chunk moments; merge + normalise) instead of ~30 tensor kernels -- or, with ``tiled`` (a
         hoic_amd.mlp.TiledForward engine whose operand the normalised rows are), hoic_zfilter_tiled: the second launch also writes
         the engine's operand and refreshes its delayed exponents (bit-identical states and filter; two launches instead of four)."""
@@ -329,14 +341,17 @@ class BatchZFilter:
             with torch.cuda.device(x.device):
                 rc = K.L.hoic_zfilter_tiled(n, self.dim, ptr(x), ptr(self._st), ptr(self._alt if update else None), int(bool(update)), float(self.clip),
                                             ptr(y), ptr(self._scratch if update else None), ptr(tiled.XT), tiled.Kp[0], ptr(tb.exps), tiled.SLOT_X, ptr(tb.amax), _mlp.NSLOT, C.c_uint64(mask),
-                                            _mlp.TARGET_LOG2, ptr(tb.overflow), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+                                            _mlp.TARGET_LOG2, ptr(tb.overflow), ptr(packed_rows), 0 if packed_rows is None else packed_rows.shape[1] // 2,
+                                            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             if rc != 0:
                 raise lib.HoicError(f"hoic_zfilter_tiled failed ({rc}): {L.hoic_last_error().decode()}")
             if update:
                 self._st, self._alt = self._alt, self._st
             self.last_call_packed = True
+            self.last_call_packed_rows = packed_rows is not None
             return y
         self.last_call_packed = False
+        self.last_call_packed_rows = False
         out = scratch = None
         if update:
             if self._alt is None:
@@ -355,13 +370,15 @@ class BatchZFilter:
             self._st, self._alt = self._alt, self._st
         return y
 
-    def __call__(self, x, update=True, out=None, tiled=None):
+    def __call__(self, x, update=True, out=None, tiled=None, packed_rows=None):
         """``out``: optional float32 tensor the normalised rows are written into (device path; otherwise ignored).  ``tiled``: a
         TiledForward engine that consumes the rows next: when the one-launch form applies, its operand is written here and
-        ``self.last_call_packed`` says so (the engine's forward then takes ``prepacked=True``)."""
-        self.last_call_packed = False
+        ``self.last_call_packed`` says so (the engine's forward then takes ``prepacked=True``).  ``packed_rows``: float16
+        [rows, 2 Kp] slice of the update's packed input (hoic_amd.mlp.PackedInput.for_rollout) that the same launch fills;
+        ``self.last_call_packed_rows`` says whether it did."""
+        self.last_call_packed = self.last_call_packed_rows = False
         if self._device_path(x) and self._st.device == x.device:
-            return self._call_device(x, update, out, tiled)
+            return self._call_device(x, update, out, tiled, packed_rows)
         if update:
             self.push(x)
         # var = S/(n-1), and mean^2 when n == 1 (zfilter.py:35)

@@ -150,6 +150,23 @@ int32_t hoic_probe_forward(hoic_sim* s, int32_t n, const float* d_qpos, const fl
 int32_t hoic_gae(int32_t T, int32_t N, const float* d_rewards, const float* d_masks, const float* d_values,
                  const float* d_next_values, float gamma, float tau, float* d_adv, float* d_returns, void* stream);
 
+/* Normalisation of the batch's advantages in place (khrylib core/common.py:22: (A - A.mean()) / A.std(), torch's unbiased
+ * standard deviation over the whole batch): d_adv [n] float32 as hoic_gae wrote them, d_scratch 512 float64.  Sums in float64
+ * in a fixed order; two launches. */
+int32_t hoic_normalize_advantages(int64_t n, float* d_adv, double* d_scratch, void* stream);
+
+/* The logger's statistics of a fixed-horizon rollout and the batch's masks in one launch (LoggerRL as the reference's sampler
+ * fills it step by step: agent_handmimic.py:476-482 -- c_reward is the step's reward WITHOUT the end bonus -- and
+ * uhc/khrylib/rl/core/logger_rl.py; masks: agent_handmimic.py:484, mask = 0 if done else 1).  n = T x N entries of the rollout's
+ * storage: d_rewards [n], d_flags [n, 4] (fail, end, done, .) and d_reward_info [n, n_info] as hoic_step wrote them; end_bonus =
+ * the bonus the step kernel added on 'end' steps.  d_stats (float64) = sum, min, max of c_reward, number of done entries,
+ * n_info sums of the reward terms; d_masks [n] float32 (may be null).  d_scratch: hoic_rollout_stats_scratch_doubles(n_info)
+ * float64, ZEROED once by the caller before the first launch (its last entry is a ticket that every launch returns to zero).
+ * Sums in float64 in a fixed order. */
+int64_t hoic_rollout_stats_scratch_doubles(int32_t n_info);
+int32_t hoic_rollout_stats(int64_t n, const float* d_rewards, const int32_t* d_flags, const float* d_reward_info, int32_t n_info,
+                           float end_bonus, float* d_masks, double* d_scratch, double* d_stats, void* stream);
+
 /* The running observation filter of the sampler (khrylib ZFilter / RunningStat, uhc/khrylib/utils/zfilter.py:8-73,
  * called on every observation at agent_handmimic.py:463) on a batch, no handle needed.  d_x [n, dim] float32; state =
  * (count, mean[dim], S[dim]) as 1 + 2 dim float64 on the device.  update != 0: the batch is merged into the state
@@ -172,10 +189,13 @@ int32_t hoic_zfilter_absorb(int32_t dim, const double* d_state, const double* co
  * writes them in the rollout forward's operand format T (hoic_mlp_pack_tiled; d_T [n x Kp] at 2^d_exps[slot_x]) and refreshes the
  * forward engine's delayed exponents (slots in `mask`) from d_amax as hoic_mlp_update_exps does -- two launches instead of four.
  * States and filter are bit-identical to hoic_zfilter.  n must be a multiple of 128; d_scratch as for hoic_zfilter; update = 0
- * normalises with d_state_in (d_state_out, d_scratch unused). */
+ * normalises with d_state_in (d_state_out, d_scratch unused).  d_P (may be null): these n rows of the UPDATE's first-layer
+ * operand as well -- hoic_mlp_pack's row format [n x 2 KpP] at the same exponent (agent_pg.py:39-49 hands the stacked states
+ * of the rollout to update_params; here they arrive packed); columns >= Kp of d_P are not written (the caller zeroes them once). */
 int32_t hoic_zfilter_tiled(int32_t n, int32_t dim, const float* d_x, const double* d_state_in, double* d_state_out, int32_t update,
                            float clip, float* d_y, double* d_scratch, void* d_T, int32_t Kp, int32_t* d_exps, int32_t slot_x,
-                           float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* stream);
+                           float* d_amax, int32_t nslots, uint64_t mask, int32_t target, int32_t* d_overflow, void* d_P, int32_t KpP,
+                           void* stream);
 
 /* The residual-force QP of HandObjMimic4.get_rfc_score (ho_im4.py:1040-1083) on caller-supplied data, n independent
  * problems:  min_x |A x - b|^2 + c.x + 1e-7/2 |x|^2, x >= 0.  d_cols [n, max_col, 7] float32: column k of problem i

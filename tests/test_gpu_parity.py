@@ -683,6 +683,45 @@ def _small_agent(ex, n_envs, min_batch, mode="fixed", seed=1, log_std=-2.3):
     return AgentHandMimic(cfg, n_envs=n_envs, expert_seqs=ex, sample_mode=mode)
 
 
+def test_rollout_tail_on_the_side_stream_gives_the_tensor_results(box_blob, box_model):
+    """The fixed-horizon sampler with the f16x3 learner (round 5): the rollout's tail runs on a side stream and on this package's
+    kernels -- masks + logger statistics in one launch (hoic_rollout_stats), the bootstrap values of the final observations through
+    the tiled forward of the value network, the batch's states packed for the update's first layer by the filter launches.  Each
+    against what the tensor expressions / PyTorch's float32 forward give for the same rollout."""
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config, release_cfg_dict
+    from hoic_amd import mlp as M
+    ex = motions.synthetic_expert(box_model, 3, 40)
+    d = release_cfg_dict("box"); d["min_batch_size"] = 256 * 40; d["policy_hsize"] = [256, 256]; d["value_hsize"] = [256, 256]; d["log_std"] = -6.0
+    cfg = Config("box_future5_light_add_geom", cfg_dict=d)
+    agent = AgentHandMimic(cfg, n_envs=256, expert_seqs=ex, update_dtype="f16x3", n_groups=2)
+    agent.env.end_reward = 7.5; agent.per_epoch_update(0)
+    for it in range(2):          # the second rollout reuses every buffer of the first
+        batch, log = agent.sample(cfg.min_batch_size)
+        assert batch.ready is not None and batch.packed_states is not None
+        log = log.result() if hasattr(log, "result") else log
+        torch.cuda.synchronize()
+        T, N = batch.rewards.shape
+        # bootstrap values: PyTorch's float32 forward of the same network on the same normalised observations
+        ref = agent.value_net(agent.running_state(agent._obs, update=False)).squeeze(1)
+        torch.testing.assert_close(batch.next_values, ref, rtol=0, atol=2e-5)
+        # masks and statistics
+        flags_end = batch.rewards > 2.0
+        assert int(flags_end.sum()) > 20
+        raw = batch.rewards.double() - 7.5 * flags_end.double()
+        np.testing.assert_allclose(log.total_c_reward, float(raw.sum()), rtol=1e-12)
+        np.testing.assert_allclose([log.min_c_reward, log.max_c_reward], [float(raw.min()), float(raw.max())], rtol=0, atol=0)
+        assert log.num_episodes == int((batch.masks == 0).sum()) and set(batch.masks.unique().tolist()) <= {0.0, 1.0}
+        assert log.num_episodes >= int(flags_end.sum())
+        # the packed input the update will read: hoic_mlp_pack of the stacked states at the same exponent
+        pin = batch.packed_states
+        t = M.ScaleTable(torch.device("cuda")); t.exps[0] = pin.table.exps[0]
+        P_ref, _ = M.pack(batch.states.reshape(T * N, -1).contiguous(), t, 0, pin.Mp, pin.Kp, rows=True, transposed=False, measure=False)
+        assert torch.equal(pin.P.view(torch.int16), P_ref.view(torch.int16))
+        agent._resolve_rollout_checks()
+    agent.env.close()
+
+
 def test_logger_statistics_exclude_end_bonus(box_blob, box_model):
     """LoggerRL's c_reward statistics are taken before the end bonus is added (agent_handmimic.py:476-482,
     logger_rl.py:28-34); they feed env.end_reward of the next iteration (:318-319).  Short sequences and a nearly
@@ -1153,6 +1192,13 @@ def test_gae_device_path_is_bit_identical():
         assert torch.equal(a_dev, adv) and torch.equal(ret_dev, v + adv)
     a1, r1 = rl.estimate_advantages(r, m, v, 0.95, 0.95, nv)
     assert torch.isfinite(a1).all() and abs(float(a1.mean())) < 1e-4
+    # the normalisation (hoic_normalize_advantages: float64 sums, two launches) against torch's (A - mean) / std in float64
+    a_raw, _ = rl._gae_device(r, m, v, 0.95, 0.95, nv)
+    ref = ((a_raw.double() - a_raw.double().mean()) / a_raw.double().std()).float()
+    torch.testing.assert_close(a1, ref, rtol=0, atol=5e-7)
+    assert torch.equal(r1, v + a_raw)
+    a2, _ = rl.estimate_advantages(r, m, v, 0.95, 0.95, nv)
+    assert torch.equal(a1, a2)              # fixed summation order: the same bits every time
 
 
 def test_diagnostics_guard_the_compiled_caps(box_blob, setup):

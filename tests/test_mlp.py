@@ -184,10 +184,14 @@ def test_filter_and_forward_operand_in_one_launch_match_the_separate_launches(up
     fa(warm); fb(warm)                                   # both filters hold statistics before the compared steps
     ea, eb = M.TiledForward(net, x_bound=5.0), M.TiledForward(net, x_bound=5.0)
     assert ea.fused_filter_ok(2048) and not ea.fused_filter_ok(2048 + 64) and ea.fused_filter_ok(4096)
+    pin = M.PackedInput.for_rollout(3 * 2048, 617, 5.0, "cuda")       # the update's packed input, filled by the same launches
+    assert pin is not None and pin.P.shape == (3 * 2048, 2 * 640)
+    ys = []
     for step in range(3):
         x = torch.randn(2048, 617, device="cuda", generator=g) * (1.0 + step) + 0.3 * step
-        ya = fa(x, update=update, tiled=ea)
-        assert fa.last_call_packed
+        ya = fa(x, update=update, tiled=ea, packed_rows=pin.P[2048 * step:2048 * (step + 1)])
+        assert fa.last_call_packed and fa.last_call_packed_rows
+        ys.append(ya.clone())
         ha = ea.forward(ya, prepacked=True).clone()
         yb = fb(x, update=update)
         assert not fb.last_call_packed
@@ -198,9 +202,15 @@ def test_filter_and_forward_operand_in_one_launch_match_the_separate_launches(up
         assert torch.equal(ea.table.exps, eb.table.exps), step
         assert torch.equal(ha, hb), step
         ea.check_overflow(); eb.check_overflow()
+    # the packed rows are what hoic_mlp_pack makes of the stacked states at the same exponent (padding columns zero)
+    t = M.ScaleTable(torch.device("cuda"))
+    t.exps[0] = pin.table.exps[0]
+    P_ref, _ = M.pack(torch.cat(ys).contiguous(), t, 0, 3 * 2048, 640, rows=True, transposed=False, measure=False)
+    assert int(pin.table.exps[0]) == int(ea.table.exps[ea.SLOT_X])
+    assert torch.equal(pin.P.view(torch.int16), P_ref.view(torch.int16))
     # sizes the one-launch form does not take fall back to the separate launches
-    y = fa(torch.randn(96, 617, device="cuda", generator=g), tiled=ea)
-    assert not fa.last_call_packed and y.shape == (96, 617)
+    y = fa(torch.randn(96, 617, device="cuda", generator=g), tiled=ea, packed_rows=pin.P[:96])
+    assert not fa.last_call_packed and not fa.last_call_packed_rows and y.shape == (96, 617)
 
 
 @gpu
