@@ -345,7 +345,7 @@ def main():
                     "values, statistics) on a side stream beside the update (default); 0 = on the main stream (A/B)")
     ap.add_argument("--pack-in-rollout", type=int, default=1, help="1 = the rollout's filter launches also write the update's packed first-layer "
                     "operand (default); 0 = the update measures and packs the stacked states itself (A/B)")
-    ap.add_argument("--prepack", type=int, default=1, help="1 = the next update's packed weights are made behind this update's last optimizer steps "
+    ap.add_argument("--prepack", type=int, default=1, help="1 = the next update's packed weights are made on the idle main stream during the rollout "
                     "(default); 0 = every first pass packs its own (A/B)")
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1 (one rank, default Box run only): append `other_configs` = Bottle and Banana at the same settings, 8 timed iterations each")

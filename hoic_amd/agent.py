@@ -147,7 +147,7 @@ class PPOLearner:
         self.opt_num_epochs = cfg.num_optim_epoch
         self._losses = None
         self.on_value_updated = None           # called behind the value network's last optimizer step of an update, on that chain's stream
-        self.prepack_weights = True            # f16x3, two streams: the next update's packed weights are made behind this update's last steps
+        self.prepack_weights = True            # f16x3: the next update's packed weights are made during the rollout (prepack)
         self.overlap_value_update = False      # f16x3 only: value phase on a side stream, under the next rollout (AgentHandMimic sets it)
         self._value_stream = self._value_event = self._value_keep = None
         assert update_dtype in ("f32", "bf16", "f16x3")
@@ -343,13 +343,6 @@ class PPOLearner:
             surr = policy_phase()
             cur.wait_stream(self._value_stream)
             self._losses = (value_loss, surr)
-            # Both networks' weights in the GEMMs' operand format for the NEXT update's first passes, packed on the side stream
-            # behind the last optimizer steps: ~25 launch-latency-bound kernels that otherwise sit in front of the next update's
-            # first value forward and first policy forward (0.25 ms of an iteration); here they run beside the next rollout's start.
-            if self.prepack_weights:
-                self._value_stream.wait_stream(cur)
-                with torch.cuda.stream(self._value_stream):
-                    veng.prepack(); peng.prepack()
         else:
             value_loss = value_phase()
             self._losses = (value_loss, policy_phase())
@@ -358,6 +351,15 @@ class PPOLearner:
         veng.post_overflow(); peng.post_overflow()
         if not self.defer_checks:
             self.resolve_checks()
+
+    def prepack(self):
+        """Both networks' weights in the GEMMs' operand format for the NEXT update's first passes, packed now on the current
+        stream: ~22 launch-latency-bound kernels that otherwise sit in front of the next update's first value forward and first
+        policy forward.  The sampler calls this on the main stream once a rollout's ranges are under way on their own streams
+        (the main stream -- and its hardware queue -- has nothing else to do until they finish)."""
+        if self._engines is not None and self.prepack_weights and self.update_dtype == "f16x3" and not self.overlap_value_update:
+            for eng in self._engines:
+                eng.prepack()
 
     def resolve_checks(self):
         """the host half of the last update's f16-range check (no-op when nothing is outstanding)"""
@@ -532,11 +534,14 @@ class AgentHandMimic:
     def _side(self):
         """the stream for work beside the critical path (the rollout's set-up and tail, sample())"""
         if self._streams:
-            # the LAST env range's stream: idle between rollouts, which is when the side work runs.  (A stream of its own cost
-            # a third of the rollout's throughput: the runtime maps streams onto four hardware queues in creation order, one more
-            # stream moved a range's reward stream onto the other range's queue and the two ranges took turns -- measured:
-            # rollout 2.16 M -> 1.24 M env-steps/s.)
-            return self._streams[-1]
+            # the FIRST env range's stream: idle between rollouts, which is when the side work runs.  The runtime maps streams onto
+            # four hardware queues in creation order and a queue runs its kernels in order, whatever stream they came from:
+            #  * a stream of its own cost a third of the rollout's throughput -- one more stream moved a range's reward stream onto
+            #    the other range's queue and the two ranges took turns (measured: rollout 2.16 M -> 1.24 M env-steps/s);
+            #  * the last range's stream shares its queue with the update's value stream (created later): the set-up of the next
+            #    rollout, enqueued behind the update, then WAITED for the value chain (rocprofv3 trace: it ran after the update).
+            # The first range's queue holds nothing else.
+            return self._streams[0]
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(self.device)
             self._side_stream.wait_stream(torch.cuda.current_stream(self.device))      # everything set up so far (filter state, tables)
@@ -775,6 +780,8 @@ class AgentHandMimic:
         if use_streams:
             for st_ in self._streams:
                 st_.wait_stream(main)
+            if side is not None:
+                self.learner.prepack()      # on the main stream, which idles until the ranges are done
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
         async_reward = direct and self.async_reward
