@@ -482,6 +482,8 @@ def main():
                        "host_runs_ahead": bool(agent.run_ahead),
                        "rollout_policy_forward": "hoic_fwd_tiled_kernel (LDS-free f16x3)" if (args.rollout_forward == "tiled" and args.update_dtype == "f16x3") else "PyTorch float32",
                        "async_reward": bool(args.async_reward), "update_streams": args.update_streams,
+                       "rollout_setup_and_tail_on_side_stream": bool(args.side_stream), "update_input_packed_by_rollout": bool(args.pack_in_rollout),
+                       "weights_prepacked_during_rollout": bool(args.prepack),
                        "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
                                                 if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,

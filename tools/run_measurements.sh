@@ -43,6 +43,7 @@ with gzip.open(out, "wt") as g:
 print("wrote", out)
 PY
 cd $R; python3 tools/rollout_timeline.py gpurun_out/r05_rollout_trace_2ranges.csv.gz > gpurun_out/r05_rollout_timeline.txt 2>&1; tail -12 gpurun_out/r05_rollout_timeline.txt
+python3 tools/seam_timeline.py gpurun_out/r05_rollout_trace_2ranges.csv.gz > gpurun_out/r05_update_seams.txt 2>&1; head -9 gpurun_out/r05_update_seams.txt
 ls -la gpurun_out | grep r05_ | tail -12
 fi
 if [ "$PART" = 3 ]; then
