@@ -762,8 +762,8 @@ class AgentHandMimic:
         # observations (the reference's sampler threads each run their own copy, agent.py:64-120) and the forks are merged
         # after the rollout -- the same final statistics as one shared filter, and no dependency between the ranges'
         # chains (with a shared filter every range's update waited for the previous range's: a convoy).
-        # The forks are made on the main stream BEFORE the side streams take their wait point on it: a fork's state is
-        # the first thing a range's chain reads.
+        # The forks are made (on the side stream, see above) BEFORE the ranges' streams take their wait point on the main
+        # stream, which has waited for the side stream by then: a fork's state is the first thing a range's chain reads.
         # filter_mode="frozen" (attribution arm): the rollout is normalised with the statistics of the iterations before it
         # -- identity (mean 0, std 1) while nothing was seen -- and its raw observations are pushed afterwards, exactly what
         # tools/reward_curve.py's cpu_fixed arm does; no forks: nothing updates the filter inside the rollout
@@ -848,12 +848,14 @@ class AgentHandMimic:
         if frozen:
             self.running_state.push(raw_all.view(T * N, self.state_dim))       # the batch's own observations, after the rollout
             del raw_all
-        # The rollout's TAIL -- the wait for the last reward parts, the masks, the bootstrap values of the final observations (a
-        # float32 forward of the value network through PyTorch) and the logger's statistics: ~45 small launches, 0.8 ms -- is
-        # needed by the advantages only, and those are formed behind the update's first value forward over the whole batch
-        # (1.5 ms of GEMMs that need the states alone).  With the f16x3 learner on one rank it goes to the side stream; the
-        # learner waits for `batch.ready` before it reads rewards, masks or next_values (PPOLearner.update_params).  (Not with
-        # the float32 learner: its library GEMMs must not meet this forward's on another stream)
+        # The rollout's TAIL -- the wait for the last reward parts, masks + logger statistics (one launch, hoic_rollout_stats),
+        # the bootstrap values of the final observations (the value network's body on the tiled forward kernels) -- is needed by
+        # the advantages only, and those are formed behind the update's first value forward over the whole batch (1.5 ms of
+        # GEMMs that need the states alone).  With the f16x3 learner on one rank it goes to the side stream; the learner waits
+        # for `batch.ready` before it reads rewards, masks or next_values (PPOLearner.update_params).  (The tensor forms of
+        # these -- 28 reduction / elementwise kernels, PyTorch's float32 forward -- were 0.8 ms between the last substep launch
+        # and the update's first GEMM; a float32 learner keeps everything on one stream: its library GEMMs must not meet
+        # another library GEMM on a second stream)
         ones = torch.ones(T, N, device=dev, dtype=dt)
         tail = side if (side is not None and self.learner.update_dtype == "f16x3") else None
         if tail is not None:
