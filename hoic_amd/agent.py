@@ -581,8 +581,26 @@ class AgentHandMimic:
         steps (hoic_capi.hip dev_poststep); the c_reward statistics are taken without it, as LoggerRL.step sees them
         (agent_handmimic.py:476-482) — they feed env.end_reward of the next iteration (:318-319)."""
         bonus = float(self.env.pushed_end_reward) if self.end_reward else 0.0
-        if stats_dev is not None:           # one launch made them (and the masks): hoic_rollout_stats, see sample()
+        if stats_dev is not None and not self.distributed:     # one launch made them (and the masks): hoic_rollout_stats, see sample()
             return self._finish_log(steps, stats_dev[:4], stats_dev[4:], time.time() - t0, bonus, defer, both=stats_dev)
+        if stats_dev is not None:           # several ranks: this rank's sums from that launch, reduced below
+            stats, c_info = stats_dev[:4], stats_dev[4:]
+        else:
+            stats, c_info = self._log_sums(rewards, end_flags, done_flags, rinfo, valid, bonus)
+        if self.distributed:
+            import torch.distributed as dist
+            tot = torch.cat([stats[[0, 3]], c_info, torch.full((1,), float(steps), device=stats.device, dtype=torch.float64)])
+            dist.all_reduce(tot)
+            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:-1]
+            # (fixed horizon: every rank holds the same T x N, no need to read the reduced count back)
+            steps = int(tot[-1].item()) if valid is not None else steps * self.world
+        sample_time = time.time() - t0
+        return self._finish_log(steps, stats, c_info, sample_time, bonus, defer)
+
+    def _log_sums(self, rewards, end_flags, done_flags, rinfo, valid, bonus):
+        """the tensor form of the logger's sums: (sum, min, max of c_reward, finished episodes) float64 [4], reward terms float64 [9]"""
         cr = rewards.to(torch.float64) - bonus * end_flags.to(torch.float64)
         if valid is None:
             cmin, cmax, csum = cr.min(), cr.max(), cr.sum()
@@ -595,17 +613,7 @@ class AgentHandMimic:
             n_done = (done_flags & valid).sum().to(torch.float64)
             c_info = (rinfo.to(torch.float64) * valid[..., None]).sum((0, 1))
         stats = torch.stack([csum, cmin, cmax, n_done])
-        if self.distributed:
-            import torch.distributed as dist
-            tot = torch.cat([stats[[0, 3]], c_info, torch.full((1,), float(steps), device=stats.device, dtype=torch.float64)])
-            dist.all_reduce(tot)
-            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:-1]
-            # (fixed horizon: every rank holds the same T x N, no need to read the reduced count back)
-            steps = int(tot[-1].item()) if valid is not None else steps * self.world
-        sample_time = time.time() - t0
-        return self._finish_log(steps, stats, c_info, sample_time, bonus, defer)
+        return stats, c_info
 
     def _finish_log(self, steps, stats, c_info, sample_time, bonus, defer, both=None):
         def build(s, ci):
@@ -666,9 +674,9 @@ class AgentHandMimic:
 
     def _rollout_stats(self, rewards, flags_all, rinfo_all, masks):
         """hoic_rollout_stats on the rollout's [T, N] storage: the logger's sums (float64 [4 + 9]: sum / min / max of c_reward,
-        finished episodes, the reward terms) and the masks in one launch; None when this is not one rank's float32 CUDA rollout"""
-        if self.distributed or not (rewards.is_cuda and rewards.dtype == torch.float32 and rewards.is_contiguous() and flags_all.is_contiguous()
-                                    and rinfo_all.is_contiguous() and masks.is_contiguous() and masks.dtype == torch.float32):
+        finished episodes, the reward terms) of THIS rank and the masks in one launch; None when this is not a float32 CUDA rollout"""
+        if not (rewards.is_cuda and rewards.dtype == torch.float32 and rewards.is_contiguous() and flags_all.is_contiguous()
+                and rinfo_all.is_contiguous() and masks.is_contiguous() and masks.dtype == torch.float32):
             return None
         L = lib.load()
         if not hasattr(L, "hoic_rollout_stats"):
@@ -738,13 +746,15 @@ class AgentHandMimic:
         # ~25 launch-latency-bound kernels run under the update's GEMMs instead of between the update and the first policy
         # forward (0.3 ms of every iteration, profiles/r05_rollout_trace_2ranges.csv.gz).  Same generators, same call order: the
         # same numbers.  Tensors made there belong to that stream's memory pool; every stream that reads them is recorded.
-        side = self._side() if (self.side_stream and fwd is not None and not self.distributed) else None
+        side = self._side() if (self.side_stream and fwd is not None) else None
         users = ([torch.cuda.current_stream(dev)] + (list(self._streams) if use_streams else [])) if side is not None else []
 
         def on_side(*ts):
             for t_ in ts:
                 for s_ in users:
                     t_.record_stream(s_)
+        if side is not None and getattr(self, "_rollout_done", None) is not None:
+            side.wait_event(self._rollout_done)        # the filter as the previous rollout left it (merge of the forks, ranks' merge)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             # the rollout's N(0, 1) draws in one launch up front: a range's chain then samples inside the action-head kernel
             noise_all = torch.randn(T, N, self.action_dim, device=dev, dtype=dt) if fwd is not None else None
@@ -780,7 +790,7 @@ class AgentHandMimic:
         if use_streams:
             for st_ in self._streams:
                 st_.wait_stream(main)
-            if side is not None:
+            if side is not None and not self.distributed:
                 self.learner.prepack()      # on the main stream, which idles until the ranges are done
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
@@ -857,7 +867,9 @@ class AgentHandMimic:
         # and the update's first GEMM; a float32 learner keeps everything on one stream: its library GEMMs must not meet
         # another library GEMM on a second stream)
         ones = torch.ones(T, N, device=dev, dtype=dt)
-        tail = side if (side is not None and self.learner.update_dtype == "f16x3") else None
+        # (several ranks: the tail holds collectives -- filter merge, logger sums -- which stay on the main stream with the update's
+        #  gradient all-reduces: one communicator, one stream)
+        tail = side if (side is not None and self.learner.update_dtype == "f16x3" and not self.distributed) else None
         if tail is not None:
             tail.wait_stream(main)
             for t_ in (rewards, rinfo_all, flags_all, masks, self.env.get_obs()):
@@ -891,6 +903,8 @@ class AgentHandMimic:
                 log = self._make_log(T * N, rewards, None, None, rinfo_all, None, t0, defer=self.run_ahead, stats_dev=stats_dev)
             else:
                 log = self._make_log(T * N, rewards, flags_all[:, :, 1] != 0, done_all, rinfo_all, None, t0, defer=self.run_ahead)
+        if side is not None:
+            self._rollout_done = torch.cuda.Event(); self._rollout_done.record(main)
         self.last_rollout_steps = T
         return batch, log
 
