@@ -410,3 +410,13 @@ def test_library_reports_the_sources_it_was_built_from():
     for f in hdr + ["hoic_capi.hip", "hoic_mlp.hip"]:
         h.update(open(os.path.join(csrc, f), "rb").read())
     assert lib.build_id() == h.hexdigest()[:16]
+
+
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md maps every entry point include/hoic.h declares to what it replaces in the reference"""
+    import re
+    h = open(os.path.join(ROOT, "include", "hoic.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(hoic_[a-z0-9_]+)\s*\(", h)))
+    assert len(names) >= 57
+    assert [n for n in names if n not in doc] == []
