@@ -790,7 +790,7 @@ class AgentHandMimic:
         if use_streams:
             for st_ in self._streams:
                 st_.wait_stream(main)
-            if side is not None and not self.distributed:
+            if side is not None:
                 self.learner.prepack()      # on the main stream, which idles until the ranges are done
         # rewards off the critical path: a range's next policy forward waits for termination / reset / observation only,
         # its contact classification, residual-force QP and reward run on a side stream (hoic_set_async_reward)
