@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=0, help="1: value-network steps on a side stream under the next rollout (f16x3 only; measured: no gain, the GEMM workgroups take the CUs' LDS); 0: serial")
     ap.add_argument("--rollout-forward", default="tiled", choices=["tiled", "torch"], help="policy body during the rollout: LDS-free f16x3 kernel (with --update-dtype f16x3) or PyTorch float32")
     ap.add_argument("--async-reward", type=int, default=1, help="1: rewards off the sampler's critical path (hoic_set_async_reward); 0: the default step")
-    ap.add_argument("--update-streams", type=int, default=2, choices=[1, 2], help="f16x3 update on one rank: value chain on a side stream (2) or one stream (1)")
+    ap.add_argument("--update-streams", type=int, default=3, choices=[1, 2, 3], help="f16x3 update on one rank: value chain on a side stream (2), one stream (1), or every GEMM on one stream and each chain's small kernels on a stream of its own (3)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=None, help="Newton iteration cap per substep (default: the model's <option iterations>, 20)")

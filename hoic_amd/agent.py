@@ -122,7 +122,7 @@ class PPOLearner:
     Device-agnostic so the multi-rank path can be exercised with gloo on CPU."""
 
     def __init__(self, cfg: Config, state_dim, action_dim, device, dtype=torch.float32, distributed=False,
-                 update_dtype="f32", strict_reference=True, fused_adam=True, update_streams=2):
+                 update_dtype="f32", strict_reference=True, fused_adam=True, update_streams=3):
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.distributed = distributed
         self.world, self.rank = 1, 0
@@ -138,7 +138,8 @@ class PPOLearner:
             for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
                 dist.broadcast(p.data, 0)
         # fused_adam: one kernel per Adam step on the GPU (same arithmetic as the per-tensor form)
-        # update_streams: 2 = the value chain of the f16x3 update on a side stream (one rank), 1 = one stream
+        # update_streams (f16x3 update on one rank): 3 = every GEMM on one stream, each chain's small kernels on a stream of its own
+        # (default), 2 = the value chain on a side stream, 1 = one stream
         self.update_streams = int(update_streams)
         fused = {"fused": True} if (torch.device(device).type == "cuda" and fused_adam) else {}
         self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay, **fused)
@@ -146,6 +147,8 @@ class PPOLearner:
         self.gamma, self.tau, self.clip_epsilon = cfg.gamma, cfg.tau, cfg.clip_epsilon
         self.opt_num_epochs = cfg.num_optim_epoch
         self._losses = None
+        self.aux_stream = None                 # a stream of the caller's that is idle during an update (update_streams=3: the policy chain's small kernels)
+        self._policy_stream = None
         self.on_value_updated = None           # called behind the value network's last optimizer step of an update, on that chain's stream
         self.prepack_weights = True            # f16x3: the next update's packed weights are made during the rollout (prepack)
         self.overlap_value_update = False      # f16x3 only: value phase on a side stream, under the next rollout (AgentHandMimic sets it)
@@ -327,6 +330,71 @@ class PPOLearner:
                 self.on_value_updated()
             policy_step(p_pending)
             self._losses = (value_loss.detach(), surr.detach())
+        elif self.update_streams == 3:
+            # ONE stream for all GEMMs, the two chains' small kernels on a stream each.  Two of the update's GEMMs sharing the GPU
+            # run slower than one after the other (a trace of the two-stream form: 22 ms of an update window with two GEMMs in
+            # flight, 36.5 ms with at least one, against 34.8 ms for the same GEMMs back to back at their isolated rates), but a
+            # chain's small kernels -- weight packing, head + loss + their backward, the gradient's maximum and packing, slab
+            # reductions, Adam: ~35 launches per pass -- want to run beside the OTHER chain's GEMMs.  So: every GEMM of both
+            # networks is enqueued on the current stream (SplitMLP.gemm_stream), a chain's other kernels on the chain's own
+            # stream, with an event each way around every GEMM, and the host alternates the two chains GEMM by GEMM (the engines'
+            # passes are generators that yield after each GEMM launch), so that the GEMM stream always has the other chain's
+            # next GEMM queued behind the one that is running.  Same kernels, same operands, same order within each chain.
+            cur = torch.cuda.current_stream(self.device)
+            if self._value_stream is None:
+                self._value_stream = torch.cuda.Stream(self.device)
+            sp = self.aux_stream
+            if sp is None:
+                if self._policy_stream is None:
+                    self._policy_stream = torch.cuda.Stream(self.device)
+                sp = self._policy_stream
+            out = {}
+
+            def value_chain():
+                loss = None
+                for ep in range(self.opt_num_epochs):
+                    if ep == 0 and v_first is not None and veng.inp is inp:
+                        h = v_first
+                    else:
+                        yield from veng.forward_iter(inp)
+                        h = veng.fwd_out
+                    self.optimizer_value.zero_grad(set_to_none=True)
+                    loss, dh = value_step(h)
+                    yield from veng.backward_iter(dh)
+                    self._allreduce_finish(self._allreduce_start(vparams))
+                    self.optimizer_value.step()
+                    veng.weights_changed()
+                if self.on_value_updated is not None:
+                    self.on_value_updated()
+                out["value"] = loss.detach()
+
+            def policy_chain():
+                fixed_log_probs, loss = None, None
+                for ep in range(self.opt_num_epochs):
+                    yield from peng.forward_iter(inp)
+                    h = peng.fwd_out
+                    self.optimizer_policy.zero_grad(set_to_none=True)
+                    loss, dh, fixed_log_probs = policy_step_head(h, fixed_log_probs)
+                    yield from peng.backward_iter(dh)
+                    policy_step(self._allreduce_start(pparams))
+                out["policy"] = loss.detach()
+
+            chains = [(policy_chain(), sp), (value_chain(), self._value_stream)]
+            for _, st_ in chains:
+                st_.wait_stream(cur)
+            veng.gemm_stream = peng.gemm_stream = cur
+            try:
+                while chains:
+                    for ch in list(chains):
+                        with torch.cuda.stream(ch[1]):
+                            try:
+                                next(ch[0])
+                            except StopIteration:
+                                chains.remove(ch)
+            finally:
+                veng.gemm_stream = peng.gemm_stream = None
+            cur.wait_stream(sp); cur.wait_stream(self._value_stream)
+            self._losses = (out["value"], out["policy"])
         elif self.update_streams == 2:
             # The two networks' chains are independent within an update: the value chain goes to a side stream and the GPU
             # runs workgroups of both.  Unlike the float32 library GEMMs of round 1 (which filled the GPU: no gain), the
@@ -448,7 +516,7 @@ class AgentHandMimic:
                  n_envs=4096, model="box", expert_seqs=None, distributed=False, update_dtype="f32",
                  strict_reference=True, solver_iterations=None, n_groups=None, sample_mode="fixed", eval_envs=None, scaling="weak",
                  start_min=0, overlap_value_update=False, rollout_forward="tiled", async_reward=True, fused_adam=True,
-                 update_streams=2, filter_mode="online", reserve_cus=0, run_ahead=True, side_stream=True):
+                 update_streams=3, filter_mode="online", reserve_cus=0, run_ahead=True, side_stream=True):
         assert sample_mode in ("fixed", "episodes") and scaling in ("weak", "strong")
         # several ranks: "weak" = every rank collects cfg.min_batch_size samples per iteration (the batch grows with the
         # number of GPUs); "strong" = the ranks SHARE the reference's batch (each collects min_batch_size / world)
@@ -540,8 +608,10 @@ class AgentHandMimic:
             #    the other range's queue and the two ranges took turns (measured: rollout 2.16 M -> 1.24 M env-steps/s);
             #  * the last range's stream shares its queue with the update's value stream (created later): the set-up of the next
             #    rollout, enqueued behind the update, then WAITED for the value chain (rocprofv3 trace: it ran after the update).
-            # The first range's queue holds nothing else.
-            return self._streams[0]
+            # The first range's queue holds nothing else.  (With update_streams=3 that stream carries the policy chain's small kernels
+            # for the whole update; the last range's stream -- same queue as the VALUE chain's, which ends a forward pass earlier --
+            # is the one whose queue drains before the update ends.)
+            return self._streams[-1] if (self.learner.update_streams == 3 and len(self._streams) > 1) else self._streams[0]
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(self.device)
             self._side_stream.wait_stream(torch.cuda.current_stream(self.device))      # everything set up so far (filter state, tables)
@@ -736,6 +806,8 @@ class AgentHandMimic:
         groups = self._groups()
         G = len(groups)
         use_streams = G > 1
+        if use_streams:
+            self.learner.aux_stream = self._streams[0]      # idle during an update (its hardware queue holds nothing else)
         # With the f16x3 update the policy body's forward pass runs on the LDS-free tiled GEMM (hoic_amd.mlp.TiledForward):
         # its wavefronts fit beside the other range's substep workgroups, the float32 library GEMMs queue behind them
         # (measured: 6 ms of a 36 ms rollout).  One engine per range (own buffers and exponents: the ranges run concurrently).

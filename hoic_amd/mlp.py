@@ -366,6 +366,9 @@ class SplitMLP:
         self.M = None
         self.first = True
         self.Wp = self.WpT = None
+        self.gemm_stream = None
+        self.slabs_l = None
+        self.fwd_out = None
         self._packed_version = None
         self._pack_event = None
         self.table = ScaleTable(self.dev)         # this network's own exponents; slot 0 mirrors the shared input's
@@ -396,6 +399,7 @@ class SplitMLP:
                                             pick_splits((n // 256) * (k // (256 if k % 256 == 0 else 128)), Mp // 32))
                              for n, k in zip(self.dims_out, self.Kp)]
         self.slabs = torch.empty(max(sp * n * k for sp, n, k in zip(self.layer_splits, self.dims_out, self.Kp)), dtype=torch.float32, device=dev)
+        self.slabs_l = None        # (per-layer slab buffers of the grouped form: made on first use)
         self.first = True
 
     def _weights_version(self):
@@ -430,9 +434,47 @@ class SplitMLP:
         self._pack_event.record(torch.cuda.current_stream(self.dev))
 
     # ------------------------------------------------------------------ forward
-    @_on_device
+    def _gemm(self, fn, *a, sync_in=True, sync_out=True, **kw):
+        """one GEMM launch.  With ``gemm_stream`` set (PPOLearner's update_streams=3) every GEMM of both networks goes to that
+        ONE stream -- behind what this chain has enqueued so far, and this chain continues behind it -- while the chain's small
+        kernels stay on the caller's stream: the matrix-core kernels then run one at a time (two of them sharing the GPU run
+        slower than one after the other) and the small kernels of one network run beside the other network's GEMMs.  GEMMs come
+        in groups with nothing of the chain's between them (the three of a forward pass, the data gradients, the weight gradients):
+        the events are taken at a group's ends only (``sync_in`` / ``sync_out``)."""
+        G = self.gemm_stream
+        cur = torch.cuda.current_stream(self.dev)
+        if G is None or G == cur:
+            fn(*a, **kw)
+            return
+        if sync_in:          # (first GEMM of a group: the group's operands are ready when this chain's stream gets here)
+            G.wait_stream(cur)
+        with torch.cuda.stream(G):
+            fn(*a, **kw)
+        if sync_out:         # (last GEMM of a group: the chain's next kernels read the group's results)
+            cur.wait_stream(G)
+
     def forward(self, inp: PackedInput, need_grad=True):
         """-> float32 [M, out] last hidden activation (a leaf that requires grad when ``need_grad``)."""
+        for _ in self.forward_iter(inp, need_grad):
+            pass
+        return self.fwd_out
+
+    def backward(self, dH):
+        """dH: float32 [M, out] gradient of the loss w.r.t. the last hidden activation.  Fills ``.grad`` of the layers."""
+        for _ in self.backward_iter(dH):
+            pass
+
+    def forward_iter(self, inp: PackedInput, need_grad=True):
+        """``forward`` as a generator that yields after every GEMM launch (the learner alternates the two networks' chains GEMM by
+        GEMM when they share one GEMM stream); the result is ``self.fwd_out`` when it is exhausted."""
+        with torch.cuda.device(self.dev):
+            yield from self._forward_iter(inp, need_grad)
+
+    def backward_iter(self, dH):
+        with torch.cuda.device(self.dev):
+            yield from self._backward_iter(dH)
+
+    def _forward_iter(self, inp, need_grad):
         self._alloc(inp)
         t = self.table
         t.exps[self.SLOT_X:self.SLOT_X + 1].copy_(inp.table.exps[0:1])      # device-side copy, no sync
@@ -454,20 +496,19 @@ class SplitMLP:
         A, sa = inp.P, self.SLOT_X
         for i, l in enumerate(self.layers):
             last = i == L - 1
-            gemm(EPI_FWD, self.M, self.dims_out[i], self.Kp[i], A, self.Wp[i], t, sa, self.SLOT_W0 + i, self.SLOT_H0 + i,
-                 bias=l.bias.detach(), gout=self.G[i] if need_grad else None, hf32=self.Hlast if last else None,
-                 P=None if last else self.Hp[i], PT=None if (last or not need_grad) else self.HpT[i])
+            self._gemm(gemm, EPI_FWD, self.M, self.dims_out[i], self.Kp[i], A, self.Wp[i], t, sa, self.SLOT_W0 + i, self.SLOT_H0 + i,
+                       bias=l.bias.detach(), gout=self.G[i] if need_grad else None, hf32=self.Hlast if last else None,
+                       P=None if last else self.Hp[i], PT=None if (last or not need_grad) else self.HpT[i], sync_in=i == 0, sync_out=last)
             if not last:
                 A, sa = self.Hp[i], self.SLOT_H0 + i
         out = self.Hlast[:inp.M]
         if need_grad:
             out = out.detach().requires_grad_(True)
-        return out
+        self.fwd_out = out
+        yield           # (one group: the forward pass's GEMMs)
 
     # ------------------------------------------------------------------ backward
-    @_on_device
-    def backward(self, dH):
-        """dH: float32 [M, out] gradient of the loss w.r.t. the last hidden activation.  Fills ``.grad`` of the layers."""
+    def _backward_iter(self, dH):
         t, inp, L, Mp = self.table, self.inp, len(self.layers), self.M
         M = inp.M
         if dH.shape[0] != Mp:
@@ -494,28 +535,50 @@ class SplitMLP:
         else:       # last pass's head-room, shifted by how far the (exact) loss-side exponent moved since
             t.update_rel([self.SLOT_DZ0 + i for i in range(L - 1)], s_last, self.ref_prev)
         for i in range(L - 1, 0, -1):          # dZ_{i-1} = (dZ_i W_i) * GELU'(z_{i-1})
-            gemm(EPI_BWD, Mp, self.dims_out[i - 1], self.dims_out[i], self.dZp[i], self.WpT[i], t, self.SLOT_DZ0 + i, self.SLOT_W0 + i,
-                 self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1],       # (rows layout: dZpT entries are None)
-                 colpart=self.colpart[i - 1] if self.rows_layout else None)
-        for i, l in enumerate(self.layers):    # dW_i = dZ_i^T H_{i-1}, db_i = column sums of dZ_i
-            n, kp = self.dims_out[i], self.Kp[i]
-            sp = self.layer_splits[i]
+            self._gemm(gemm, EPI_BWD, Mp, self.dims_out[i - 1], self.dims_out[i], self.dZp[i], self.WpT[i], t, self.SLOT_DZ0 + i, self.SLOT_W0 + i,
+                       self.SLOT_DZ0 + i - 1, gin=self.G[i - 1], P=self.dZp[i - 1], PT=self.dZpT[i - 1],       # (rows layout: dZpT entries are None)
+                       colpart=self.colpart[i - 1] if self.rows_layout else None, sync_in=i == L - 1, sync_out=i == 1)
+        if L > 1:
+            yield       # (one group: the data gradients)
+        # dW_i = dZ_i^T H_{i-1}, db_i = column sums of dZ_i.  With a GEMM stream the three weight-gradient GEMMs are one group too:
+        # each writes its own slab buffer and the reductions follow the group (one shared buffer made every GEMM wait for the
+        # reduction of the one before it)
+        grouped = self.gemm_stream is not None and self.gemm_stream != torch.cuda.current_stream(self.dev)
+        if grouped and self.slabs_l is None:
+            self.slabs_l = [torch.empty(sp * n * k, dtype=torch.float32, device=self.dev) for sp, n, k in zip(self.layer_splits, self.dims_out, self.Kp)]
+        def wgrad_gemm(i, slabs, sync_in, sync_out):
+            n, kp, sp = self.dims_out[i], self.Kp[i], self.layer_splits[i]
             if self.rows_layout:
                 Br, sb = (inp.P, self.SLOT_X) if i == 0 else (self.Hp[i - 1], self.SLOT_H0 + i - 1)
-                gemm_tn(n, kp, Mp, self.dZp[i], Br, t, self.SLOT_DZ0 + i, sb, sp, self.slabs)
+                self._gemm(gemm_tn, n, kp, Mp, self.dZp[i], Br, t, self.SLOT_DZ0 + i, sb, sp, slabs, sync_in=sync_in, sync_out=sync_out)
             else:
                 Bt, sb = (inp.PT, self.SLOT_X) if i == 0 else (self.HpT[i - 1], self.SLOT_H0 + i - 1)
-                gemm(EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=sp, C_out=self.slabs)
+                self._gemm(gemm, EPI_F32, n, kp, Mp, self.dZpT[i], Bt, t, self.SLOT_DZ0 + i, sb, splits=sp, C_out=slabs, sync_in=sync_in, sync_out=sync_out)
+
+        def wgrad_reduce(i, slabs):
+            l, n, kp, sp = self.layers[i], self.dims_out[i], self.Kp[i], self.layer_splits[i]
             if l.weight.grad is None:
                 l.weight.grad = torch.empty_like(l.weight)
                 l.bias.grad = torch.empty_like(l.bias)
-            Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(self.slabs), sp, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
+            Kn.chk(Kn.L.hoic_mlp_slab_reduce(_ptr(slabs), sp, n, kp, _ptr(l.weight.grad), self.dims_in[i], self.dims_in[i], 1.0,
                                              _stream(self.dev)), "hoic_mlp_slab_reduce")
             if self.rows_layout:
                 Kn.chk(Kn.L.hoic_mlp_colpart_finish(_ptr(self.colpart[i]), Mp // 128, n, _ptr(l.bias.grad), _stream(self.dev)), "hoic_mlp_colpart_finish")
             else:
                 Kn.chk(Kn.L.hoic_mlp_rowsum_packed(_ptr(self.dZpT[i]), n, Mp, _ptr(l.bias.grad), _ptr(t.exps), self.SLOT_DZ0 + i, _stream(self.dev)),
                        "hoic_mlp_rowsum_packed")
+
+        if grouped:
+            for i in range(L):
+                wgrad_gemm(i, self.slabs_l[i], i == 0, i == L - 1)
+            yield           # (one group: the weight gradients)
+            for i in range(L):
+                wgrad_reduce(i, self.slabs_l[i])
+        else:
+            for i in range(L):
+                wgrad_gemm(i, self.slabs, True, True)
+                wgrad_reduce(i, self.slabs)
+            yield
 
     _OVERFLOW_MSG = ("f16x3 GEMM path: {n} tensor(s) exceeded the float16 range under their delayed scale exponent; "
                      "the update is not valid (use update_dtype='f32')")

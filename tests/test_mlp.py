@@ -391,6 +391,36 @@ def test_f16x3_overflow_in_either_network_fails_the_update(which):
 
 
 @gpu
+def test_update_stream_layouts_give_identical_parameters():
+    """PPOLearner(update_streams=1 | 2 | 3): one stream; the value chain on a side stream; every GEMM on one stream with each
+    chain's small kernels on a stream of its own (the engines' passes as generators, GEMMs in groups, per-layer slab buffers).
+    Same kernels on the same operands in the same order within each chain: the parameters after two updates are bit-identical."""
+    from types import SimpleNamespace
+    from hoic_amd.agent import PPOLearner
+    from hoic_amd.config import Config, release_cfg_dict
+    d = release_cfg_dict("box"); d["policy_hsize"] = [512, 256, 256]; d["value_hsize"] = [512, 256, 256]
+    cfg = Config("box_future5_light_add_geom", cfg_dict=d)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(5)
+    T, N = 8, 256
+    mk = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    batches = [SimpleNamespace(states=torch.clamp(mk(T, N, 617), -5, 5), actions=mk(T, N, 32) * 0.1, rewards=torch.rand(T, N, device=dev, generator=g),
+                               masks=(torch.rand(T, N, device=dev, generator=g) > 0.05).float(), next_values=mk(N) * 0.1, valid=None) for _ in range(2)]
+    params = {}
+    for streams in (1, 2, 3):
+        torch.manual_seed(0)
+        L = PPOLearner(cfg, 617, 32, dev, update_dtype="f16x3", update_streams=streams)
+        for b in batches:
+            L.update_params(b)
+        L.finish_update()
+        torch.cuda.synchronize()
+        params[streams] = [p.detach().clone() for p in list(L.policy_net.parameters()) + list(L.value_net.parameters())]
+        assert all(torch.isfinite(p).all() for p in params[streams])
+    for streams in (2, 3):
+        assert all(torch.equal(a, b) for a, b in zip(params[1], params[streams])), streams
+
+
+@gpu
 @pytest.mark.parametrize("rows,n_out", [(2048, 32), (96, 32), (64, 1), (1003, 32)])
 def test_action_head_kernel_matches_float64(rows, n_out):
     """hoic_mlp_head (the rollout's action head + Gaussian sample, one LDS-free float32 MFMA launch) against a float64

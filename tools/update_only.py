@@ -1,6 +1,6 @@
 """Run only PPOLearner.update_params (GAE + 5 epochs of value and policy steps on 53248 synthetic samples): development aid
 for rocprofv3 --kernel-trace --stats passes over the update's kernels.
-usage: python3 tools/update_only.py [f16x3|f32|bf16] [reps] [rows] [heads=kernels|autograd] [streams=2|1]"""
+usage: python3 tools/update_only.py [f16x3|f32|bf16] [reps] [rows] [heads=kernels|autograd] [streams=3|2|1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
@@ -12,7 +12,7 @@ dt = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 53248
 heads = sys.argv[4] if len(sys.argv) > 4 else "kernels"      # autograd: nn.Linear-shaped heads through mlp.head_linear + PyTorch's elementwise losses
-streams = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+streams = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 dev = torch.device("cuda")
 if heads == "autograd":
     from hoic_amd import mlp as _M
