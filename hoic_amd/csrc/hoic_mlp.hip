@@ -67,6 +67,36 @@ __device__ __forceinline__ void gelu_pair(float z, float& g, float& dg) {
   g = z * Phi;
   dg = fmaf(z * 0.39894228040143268f, e, Phi);
 }
+// The same pair for TWO values at once on the packed float32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per
+// instruction).  Constants folded: t = 1 / (1 + (p / sqrt 2) |z|), exp(-z^2 / 2) = exp2(-(z sqrt(log2(e) / 2))^2).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_pair2(f2 z, f2& g, f2& dg) {
+  const f2 one = {1.f, 1.f}, half = {0.5f, 0.5f};
+  const f2 az = {fabsf(z.x), fabsf(z.y)};
+  const f2 den = __builtin_elementwise_fma(az, (f2){0.23164190f, 0.23164190f}, one);
+  const f2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  const f2 u = z * (f2){0.84932180028801904f, 0.84932180028801904f};
+  const f2 mu2 = -(u * u);
+  const f2 e = {__builtin_amdgcn_exp2f(mu2.x), __builtin_amdgcn_exp2f(mu2.y)};
+  f2 p = __builtin_elementwise_fma(t, (f2){1.061405429f, 1.061405429f}, (f2){-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(t, p, (f2){1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(t, p, (f2){-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(t, p, (f2){0.254829592f, 0.254829592f});
+  p = p * t;
+  const f2 ea = __builtin_elementwise_fma(-p, e, one);
+  const f2 s = {copysignf(ea.x, z.x), copysignf(ea.y, z.y)};
+  const f2 Phi = __builtin_elementwise_fma(s, half, half);
+  g = z * Phi;
+  dg = __builtin_elementwise_fma(z * (f2){0.39894228040143268f, 0.39894228040143268f}, e, Phi);
+}
+// hi | lo << 16 of y * so (so a power of two: the product is exact), as two v_fma_mix
+__device__ __forceinline__ unsigned pack_hl_scaled(float y, float so) {
+  h2 X;
+  X.x = (_Float16)(y * so);
+  X.y = (_Float16)(y * so - (float)X.x);
+  return __builtin_bit_cast(unsigned, X);
+}
 __device__ __forceinline__ float wave_max_f(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
@@ -195,6 +225,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
 // float32 copy directly, the packed row-major output after an exchange inside each group of 8 lanes (lane q of a group
 // writes dword q of the 32-byte H8L8 group: q < 4 the hi halves of columns 2q, 2q + 1, q >= 4 the lo halves).  No
 // transposed output in this form (the weight-gradient kernel below reads row-major operands).
+// Round 6: the arithmetic runs two rows at a time on the packed float32 pipe (v_pk_fma_f32 / v_pk_mul_f32: consecutive
+// accumulator registers are consecutive rows of one column), the hi | lo word of an element is two v_fma_mix (the output
+// scale folded in), and every access is base (SGPR pair) + one 32-bit byte offset shared by the output arrays -- 21 issue
+// slots per element where the scalar form took 41 (profiles/r06_experiments.json "epilogue_diet").
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc)[TM][TN], int mb, int nb, int lane) {
   const int l31 = lane & 31, hf = lane >> 5;
@@ -204,66 +238,69 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
   const float so = ldexpf(1.f, eo);
   const int src0 = ((lane & ~7) + 2 * (lane & 3)) << 2, src1 = src0 + 4;        // ds_bpermute byte addresses of the two source lanes
   const unsigned sel = (lane & 4) ? 0x07060302u : 0x05040100u;                  // lanes 4..7 of a group assemble the lo halves
-  // addresses: the arrays' base pointers stay in scalar registers, the element offset is ONE 32-bit VGPR chain (outputs are
-  // below 2^32 elements: checked in hoic_mlp_gemm)
-  const unsigned N = (unsigned)a.N;
-  const unsigned lane_off = (unsigned)mb * N + (unsigned)(nb + l31) + 4u * (unsigned)hf * N;
+  // addresses: the arrays' base pointers stay in scalar registers, the BYTE offset of an element is one 32-bit VGPR (outputs are
+  // below 2^30 elements: checked in hoic_mlp_gemm), shared by the packed output, GELU' and the float32 copy (all 4 bytes per element)
+  const unsigned N4 = (unsigned)a.N * 4u;
+  const unsigned lane_ob = (unsigned)mb * N4 + (unsigned)(nb + l31) * 4u + 4u * (unsigned)hf * N4;
   float vmax = 0.f;
-  const float* __restrict__ Gin = a.Gin;
-  float* __restrict__ Gout = a.Gout;
-  float* __restrict__ Hf = a.Hf32;
-  unsigned* __restrict__ P32 = (unsigned*)a.P;
+  const char* __restrict__ Gin = (const char*)a.Gin;
+  char* __restrict__ Gout = (char*)a.Gout;
+  char* __restrict__ Hf = (char*)a.Hf32;
+  char* __restrict__ P32 = (char*)a.P;
+  const f2 alpha2 = {alpha, alpha};
 #pragma unroll
   for (int j = 0; j < TN; j++) {
     const float bj = (EPI == EPI_FWD) ? a.bias[nb + 32 * j + l31] : 0.f;
+    const f2 bj2 = {bj, bj};
     float csum = 0.f;      // this lane's column over the wavefront's 128 rows (its half of them): the bias gradient's partial sum
 #pragma unroll
     for (int i = 0; i < TM; i++) {
-      // half a 32 x 32 tile at a time, in batches: 8 loads in flight, then the arithmetic, then 32 lane exchanges in flight,
+      // half a 32 x 32 tile at a time, in batches: 8 loads in flight, then the arithmetic, then 16 lane exchanges in flight,
       // then the stores (element by element every access would wait for the one before it)
 #pragma unroll
       for (int hb = 0; hb < 2; hb++) {
         __builtin_amdgcn_sched_barrier(0);
         unsigned o[8];
-        float v[8], gq[8];
+        f2 v[4], gq[4];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int r = 8 * hb + q;
-          o[q] = lane_off + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * N + 32u * j;
-          if (EPI == EPI_BWD) gq[q] = Gin[o[q]];
+          o[q] = lane_ob + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * N4 + 128u * j;
+          if (EPI == EPI_BWD) gq[q >> 1][q & 1] = *(const float*)(Gin + o[q]);
         }
         if (EPI == EPI_BWD) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          if (EPI == EPI_FWD) gelu_pair(fmaf(alpha, acc[i][j][8 * hb + q], bj), v[q], gq[q]);
-          else v[q] = alpha * acc[i][j][8 * hb + q] * gq[q];
-          vmax = fmaxf(vmax, fabsf(v[q]));
-          if (EPI == EPI_BWD) csum += v[q];
+        for (int p = 0; p < 4; p++) {
+          const f2 ac = {acc[i][j][8 * hb + 2 * p], acc[i][j][8 * hb + 2 * p + 1]};
+          if (EPI == EPI_FWD) gelu_pair2(__builtin_elementwise_fma(alpha2, ac, bj2), v[p], gq[p]);
+          else v[p] = (alpha2 * ac) * gq[p];
+          vmax = fmaxf(vmax, fmaxf(fabsf(v[p].x), fabsf(v[p].y)));
+          if (EPI == EPI_BWD) { csum += v[p].x; csum += v[p].y; }
         }
         if (P32) {
           unsigned w0[8], w1[8];
 #pragma unroll
           for (int q = 0; q < 8; q++) {
-            const unsigned w = pack_hl(v[q] * so);
+            const unsigned w = pack_hl_scaled(v[q >> 1][q & 1], so);
             w0[q] = (unsigned)__builtin_amdgcn_ds_bpermute(src0, (int)w); w1[q] = (unsigned)__builtin_amdgcn_ds_bpermute(src1, (int)w);
           }
 #pragma unroll
-          for (int q = 0; q < 8; q++) P32[o[q]] = __builtin_amdgcn_perm(w1[q], w0[q], sel);
+          for (int q = 0; q < 8; q++) *(unsigned*)(P32 + o[q]) = __builtin_amdgcn_perm(w1[q], w0[q], sel);
         }
         if (EPI == EPI_FWD && Gout) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) Gout[o[q]] = gq[q];
+          for (int q = 0; q < 8; q++) *(float*)(Gout + o[q]) = gq[q >> 1][q & 1];
         }
         if (Hf) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) Hf[o[q]] = v[q];
+          for (int q = 0; q < 8; q++) *(float*)(Hf + o[q]) = v[q >> 1][q & 1];
         }
       }
     }
     if (EPI == EPI_BWD && a.colpart) {      // TM * 32 = 128 rows per wavefront: chunk mb / 128, fixed order => deterministic
       static_assert(TM == 4, "column partials are per 128-row chunk");
       csum += __shfl_xor(csum, 32);
-      if (hf == 0) a.colpart[(size_t)(mb >> 7) * N + nb + 32 * j + l31] = csum;
+      if (hf == 0) a.colpart[(size_t)(mb >> 7) * a.N + nb + 32 * j + l31] = csum;
     }
   }
   if (a.amax) {
@@ -873,8 +910,8 @@ extern "C" int32_t hoic_mlp_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, c
   if (epi == EPI_FWD && !d_bias) { hoic_set_error("hoic_mlp_gemm: forward epilogue needs the bias"); return HOIC_ERR_ARG; }
   if (epi == EPI_BWD && !d_gin) { hoic_set_error("hoic_mlp_gemm: backward epilogue needs gin"); return HOIC_ERR_ARG; }
   if (epi != EPI_F32 && splits != 1) { hoic_set_error("hoic_mlp_gemm: split-K only with the float32 epilogue"); return HOIC_ERR_ARG; }
-  if ((unsigned long long)M * (unsigned long long)N >= (1ull << 32)) {      // the epilogues index their outputs with 32-bit element offsets
-    hoic_set_error("hoic_mlp_gemm: M x N must stay below 2^32 elements"); return HOIC_ERR_ARG;
+  if ((unsigned long long)M * (unsigned long long)N >= (1ull << 30)) {      // the epilogues address their outputs with 32-bit BYTE offsets
+    hoic_set_error("hoic_mlp_gemm: M x N must stay below 2^30 elements"); return HOIC_ERR_ARG;
   }
   if (d_colpart && !(epi == EPI_BWD && g_gemm_pipeline == 3 && !d_PT)) {
     hoic_set_error("hoic_mlp_gemm: column partial sums come from the data-gradient epilogue in D[m][n] form (pipeline mode 3, no transposed output)");
