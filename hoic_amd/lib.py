@@ -126,6 +126,35 @@ def load():
     return L
 
 
+_hip = None
+
+
+def cu_masked_stream(device, first_cu, n_cus):
+    """A HIP stream whose kernels run on ``n_cus`` compute units only, as a torch stream: CU mask bits [first_cu, first_cu + n_cus) in
+    the order of hoic_set_cu_reserve (bit i = CU i / 8 of XCD i % 8, tools/probe/cu_mask.hip), so that ``cu_masked_stream(dev, 0, k)``
+    is exactly the set ``hoic_set_cu_reserve(k)`` keeps free of substep workgroups.  hipExtStreamCreateWithCUMask of the HIP
+    runtime torch has loaded; the stream lives as long as the process."""
+    global _hip
+    import torch
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        _hip.hipExtStreamCreateWithCUMask.restype = C.c_int
+    dev = torch.device(device)
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    if first_cu < 0 or n_cus <= 0 or first_cu + n_cus > ncu:
+        raise HoicError(f"cu_masked_stream: CUs [{first_cu}, {first_cu + n_cus}) outside the device's {ncu}")
+    words = (C.c_uint32 * ((ncu + 31) // 32))()
+    for i in range(first_cu, first_cu + n_cus):
+        words[i // 32] |= 1 << (i % 32)
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        rc = _hip.hipExtStreamCreateWithCUMask(C.byref(h), len(words), words)
+    if rc != 0 or not h.value:
+        raise HoicError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def build_id() -> str:
     """hoic_build_id(): which sources the loaded library was built from (profiles/ files carry it)"""
     return load().hoic_build_id().decode()

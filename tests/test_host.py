@@ -420,3 +420,39 @@ def test_integration_md_names_every_entry_point():
     names = sorted(set(re.findall(r"\b(hoic_[a-z0-9_]+)\s*\(", h)))
     assert len(names) >= 57
     assert [n for n in names if n not in doc] == []
+
+
+def test_banana_merge_order_matches_the_reference_held_model():
+    """The one merged model the reference keeps in its tree (dataset_model_temp.xml:242-248, written by MujocoXML.merge for the
+    Banana config; names and attributes committed as tests/golden/dataset_model_temp_names.json by gen_golden_model_names.py):
+    body, geom and joint order of the packaged Banana model -- and of a fresh compile when the checkout is present -- are
+    MuJoCo's compile order of that file, and the object geoms carry its contact attributes."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "dataset_model_temp_names.json")))
+    models = [mjcf.load_packaged("banana")]
+    if os.path.exists("/root/reference/assets"):
+        models.append(mjcf.compile_reference_config("/root/reference", "banana"))
+    for m in models:
+        assert m.body_names == g["bodies"]
+        assert m.geom_names == g["geoms"]
+        named = [j["name"] for j in g["joints"] if j["name"]]
+        assert [n for n in m.joint_names if n in named] == named and len(m.joint_names) == len(g["joints"])
+        A = m.arrays
+        assert g["joints"][-1]["type"] == "free" and g["joints"][-1]["body"] == "banana" and m.scalar("nv") == 32
+        # object geoms: ids behind the 21 hand / scene geoms, contact attributes of the file (geom x geom pairs mix them:
+        # the larger condim, friction maximum, solref / solimp of the higher priority -- equal priorities mix by solmix)
+        ids = {n: m.geom_names.index(n) for n in g["banana_geoms"]}
+        assert (A["obj_geom0"][0], A["obj_geom1"][0]) == (ids["C_banana1"], ids["C_banana3"])
+        for name, at in g["banana_geoms"].items():
+            if at.get("contype") == "0":
+                continue          # the visual mesh takes part in no pair
+            gi = ids[name]
+            pairs = [p for p in range(m.scalar("npair")) if A["pair_geom2"][p] == gi and 2 <= A["pair_geom1"][p] <= 20]
+            assert pairs, name
+            for p in pairs:
+                assert A["pair_condim"][p] >= int(at["condim"])
+                fr = [float(v) for v in at["friction"].split()]
+                assert A["pair_friction"][p][0] >= fr[0] - 1e-12 and A["pair_friction"][p][2] >= fr[1] - 1e-12
+                np.testing.assert_allclose(A["pair_solref"][p], [float(v) for v in at["solref"].split()])
+    # the compiled caps against the file's <size>: every row the kernel can hold fits the reference's buffers
+    assert int(g["size"]["nconmax"]) == 100 and int(g["size"]["njmax"]) == 500
