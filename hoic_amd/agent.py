@@ -153,7 +153,6 @@ class PPOLearner:
         self.prepack_weights = True            # f16x3: the next update's packed weights are made during the rollout (prepack)
         self.overlap_value_update = False      # f16x3 only: value phase on a side stream, under the next rollout (AgentHandMimic sets it)
         self._value_stream = self._value_event = self._value_keep = None
-        self.value_cus = int(os.environ.get("HOIC_VALUE_CUS", "0"))      # overlap_value_update: compute units of the value phase's stream (0: all)
         assert update_dtype in ("f32", "bf16", "f16x3")
         self._engines = None             # f16x3: SplitMLP of (value net, policy net)
         # the f16-range check of an update in two halves (mlp._post_overflow): with defer_checks the host does not wait for
@@ -299,11 +298,7 @@ class PPOLearner:
             surr = policy_phase()
             cur = torch.cuda.current_stream(self.device)
             if self._value_stream is None:
-                if self.value_cus > 0:       # the value phase on the compute units the rollout's substep launches leave free
-                    from . import lib as _lib
-                    self._value_stream = _lib.cu_masked_stream(self.device, 0, self.value_cus)
-                else:
-                    self._value_stream = torch.cuda.Stream(self.device)
+                self._value_stream = torch.cuda.Stream(self.device)
             self._value_stream.wait_stream(cur)
             with torch.cuda.stream(self._value_stream):
                 value_loss = value_phase()

@@ -326,14 +326,9 @@ __device__ __forceinline__ void gemm_epilogue_mn(const GemmArgs& a, f32x16 (&acc
 // smem, nkt (EVEN: K and the split sizes are multiples of 32) and MN, then expands K16_MAINLOOP.
 // MFMA k of a step (0..23): product k / 8 (hi.lo, lo.hi, hi.hi), tile (k % 8) / 2, (k % 8) % 2 -- eight different
 // accumulators in a row, so no MFMA waits for the one before it
-#ifndef K16_ORDER
-#define K16_ORDER 0
-#endif
 #define K16_MF(Fx, KK)                                                                                                  \
   {                                                                                                                     \
-    constexpr int p_ = K16_ORDER == 1 ? (KK) % 3 : (KK) / 8;                                                            \
-    constexpr int i_ = K16_ORDER == 1 ? ((KK) / 3) / 2 : K16_ORDER == 2 ? (KK) % 4 : ((KK) % 8) / 2;                      \
-    constexpr int j_ = K16_ORDER == 1 ? ((KK) / 3) % 2 : K16_ORDER == 2 ? ((KK) % 8) / 4 : (KK) % 2;                      \
+    constexpr int p_ = (KK) / 8, i_ = ((KK) % 8) / 2, j_ = (KK) % 2;                                                    \
     const h8 av_ = (p_ == 1) ? Fx.al[i_] : Fx.ah[i_], bv_ = (p_ == 0) ? Fx.bl[j_] : Fx.bh[j_];                            \
     if (MN) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av_, bv_, acc[i_][j_], 0, 0, 0);                          \
     else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv_, av_, acc[i_][j_], 0, 0, 0);                             \

@@ -133,7 +133,10 @@ def cu_masked_stream(device, first_cu, n_cus):
     """A HIP stream whose kernels run on ``n_cus`` compute units only, as a torch stream: CU mask bits [first_cu, first_cu + n_cus) in
     the order of hoic_set_cu_reserve (bit i = CU i / 8 of XCD i % 8, tools/probe/cu_mask.hip), so that ``cu_masked_stream(dev, 0, k)``
     is exactly the set ``hoic_set_cu_reserve(k)`` keeps free of substep workgroups.  hipExtStreamCreateWithCUMask of the HIP
-    runtime torch has loaded; the stream lives as long as the process."""
+    runtime torch has loaded; the stream lives as long as the process.  CAUTION: such a stream is a BLOCKING stream (the call takes
+    no flags): every launch on the legacy default stream -- torch's default current stream -- waits for it and it for them; run the
+    other side on a created stream (tools/probe/overlap_probe.py does).  Used by the probes only (profiles/r06_experiments.json
+    "value_phase_on_masked_cus_under_the_rollout": no configuration won)."""
     global _hip
     import torch
     if _hip is None:

@@ -16,6 +16,10 @@ dev = torch.device("cuda", 0)
 cfg = Config("box_future5_light_add_geom")
 model = mjcf.load_packaged("box")
 expert = motions.synthetic_expert(model, 17, 600)
+# Everything runs on a NON-default stream: a stream from hipExtStreamCreateWithCUMask is a blocking stream, i.e. every launch on the
+# legacy default stream (torch's default "current stream") waits for it and it for every such launch.
+main = torch.cuda.Stream(dev)
+torch.cuda.set_stream(main)
 agent = AgentHandMimic(cfg, device=dev, n_envs=4096, model="box", expert_seqs=expert, update_dtype="f16x3")
 for e in range(3):
     agent.optimize_policy(e, save_model=False)
@@ -57,17 +61,19 @@ for cus in [int(a) for a in sys.argv[1:]] or [0, 64, 128]:
     # the rollouts' own (events on the main stream), the passes are counted by an event behind each
     n_pass = int(NR * t_roll * 2.5 / t_pass) + 3
     torch.cuda.synchronize()
-    e0, er = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     cur = torch.cuda.current_stream(dev)
     st.wait_stream(cur)
-    evs = []
-    passes(n_pass, st, evs)
-    e0.record(cur)
-    rollouts(NR); er.record(cur)
-    torch.cuda.synchronize()
-    tr = e0.elapsed_time(er)
-    ts = [e0.elapsed_time(ev) for ev in evs]
-    inside = [t for t in ts if 0.0 < t <= tr]
-    tail = "" if ts[-1] > tr else " (THE PASSES ENDED FIRST: lower bound)"
-    print(f"pass stream on {cus or 'all'} CUs: pass alone {t_pass:.2f} ms; together: rollout {tr / NR:.2f} ms (+{tr / NR - t_roll:.2f}), "
-          f"{len(inside) / NR:.2f} passes per rollout = {len(inside) / NR * 3.46:.2f} ms of full-chip GEMM time (3.46 ms per pass alone on all CUs){tail}", flush=True)
+    t0 = time.time()
+    passes(n_pass, st)
+    t1 = time.time()
+    rollouts(NR)
+    t2 = time.time()
+    cur.synchronize(); t_roll_end = time.time()
+    st.synchronize(); t_pass_end = time.time()
+    tr = (t_roll_end - t1) * 1e3          # the rollouts' window on the host clock: from their first enqueue to their end
+    done_before = (t1 - t0) * 1e3 / t_pass                      # (upper bound of) passes the GPU finished while the host was still enqueueing them
+    left_after = max(t_pass_end - t_roll_end, 0.0) * 1e3 / t_pass
+    inside = n_pass - left_after - min(done_before, n_pass)
+    print(f"pass stream on {cus or 'all'} CUs: pass alone {t_pass:.2f} ms; host enqueue of {n_pass} passes {1e3 * (t1 - t0):.1f} ms, of {NR} rollouts {1e3 * (t2 - t1):.1f} ms; "
+          f"together: rollout {tr / NR:.2f} ms (+{tr / NR - t_roll:.2f}), >= {inside / NR:.2f} passes per rollout = {inside / NR * 3.46:.2f} ms of full-chip GEMM time "
+          f"(3.46 ms per pass alone on all CUs); passes left after the rollouts: {left_after:.1f}", flush=True)
