@@ -33,10 +33,19 @@ HD void cross3(const float* a, const float* b, float* o) {
 // float32 arithmetic does not need the correctly rounded forms: an IEEE division is ~10 instructions (v_div_scale x2, v_rcp,
 // four fmas, v_div_fmas, v_div_fixup), an IEEE sqrtf ~14; the parity bounds against the float64 oracle are 1e-4 .. 1e-6.
 // (The hardware forms flush denormal arguments: the guards below test against 1e-36, not 1e-40.)
+// -DHOIC_IEEE_DIV (development build ../libhoic_ieee.so): the correctly rounded forms, for the attribution of long-horizon
+// deviations (tools/attribute_bottle_outliers.py).
+#ifdef HOIC_IEEE_DIV
+HD float frcp(float x) { return 1.f / x; }
+HD float fdiv(float a, float b) { return a / b; }
+HD float fsqrt(float x) { return sqrtf(x); }
+HD float frsq(float x) { return 1.f / sqrtf(x); }
+#else
 HD float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 HD float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 HD float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 HD float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
 HD float normalize3(float* a) {
   const float n2 = dot3(a, a);
   if (n2 < 1e-36f) { a[0] = 1.f; a[1] = 0.f; a[2] = 0.f; return 0.f; }

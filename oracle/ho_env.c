@@ -122,6 +122,9 @@ void hoo_env_set_obb_reject(ho_env* e, int on) { e->m.no_obb_reject = on ? 0 : 1
    AABBs; the reject only drops shallow hull contacts of separated geoms) and the unbounded angle wrap of compute_torque.
    tests/test_gpu_parity.py runs whole episodes of the HIP kernel against this mode. */
 void hoo_env_set_reference_faithful(ho_env* e, int on) { e->m.no_obb_reject = on ? 1 : 0; e->m.pd_wrap_cap = on ? 0 : 16; }
+/* Control arm for the whole-episode parity tests: the state is rounded to float32 after every substep (ho_sim.c euler). */
+void hoo_env_set_state_float32(ho_env* e, int on) { e->m.state_float32 = on ? 1 : 0; }
+void hoo_env_set_solver_stop(ho_env* e, double tol, int maxit) { e->m.solver_tol = tol; e->m.solver_maxit = maxit; }
 void hoo_env_destroy(ho_env* e) { if (e) { free_expert(&e->e); free(e); } }
 
 void hoo_env_set_cfg(ho_env* e, const double* jkp, const double* jkd, const double* torque_lim,

@@ -630,7 +630,8 @@ static double total_cost(const ho_model* m, ho_data* d, const double* qacc, doub
  * [MJ-doc: Computation chapter, "Newton solver"]; run to tight convergence (unique optimum). */
 void ho_solve(const ho_model* m, ho_data* d) {
   int nv = m->nv, ne = d->nefc;
-  static const int MAXIT = 100;
+  const int MAXIT = m->solver_maxit > 0 ? m->solver_maxit : 100;
+  const double gtol = m->solver_tol > 0 ? m->solver_tol : 1e-14;
   double qacc[NV], jar[HO_MAXEFC], jv[HO_MAXEFC], grad[NV], search[NV], Mv[NV], H[NV * NV];
   memset(d->qfrc_constraint, 0, sizeof(d->qfrc_constraint));
   d->solver_iter = 0; d->solver_gradnorm = 0;
@@ -665,7 +666,7 @@ void ho_solve(const ho_model* m, ho_data* d) {
     for (int i = 0; i < nv; i++) gn += grad[i] * grad[i];
     gn = sqrt(gn) * scale;
     d->solver_gradnorm = gn; d->solver_iter = it;
-    if (gn < 1e-14) break;
+    if (gn < gtol) break;
     ho_cholesky(H, nv, NV);
     for (int i = 0; i < nv; i++) search[i] = -grad[i];
     ho_cholsolve(H, nv, NV, search);
@@ -824,6 +825,10 @@ static void euler(const ho_model* m, ho_data* d) {
     } else d->qpos[qa] += h * d->qvel[da];
   }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  if (m->state_float32) {      /* control arm: the state a float32 simulator would carry to the next substep */
+    for (int i = 0; i < m->nq; i++) d->qpos[i] = (double)(float)d->qpos[i];
+    for (int i = 0; i < nv; i++) { d->qvel[i] = (double)(float)d->qvel[i]; d->qacc_warmstart[i] = (double)(float)d->qacc_warmstart[i]; }
+  }
 }
 
 void ho_step(const ho_model* m, ho_data* d) {

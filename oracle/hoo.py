@@ -49,6 +49,8 @@ def lib():
         L.hoo_env_set_mesh_single_contact.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_set_obb_reject.argtypes = [C.c_void_p, C.c_int]
         L.hoo_env_set_reference_faithful.argtypes = [C.c_void_p, C.c_int]
+        L.hoo_env_set_state_float32.argtypes = [C.c_void_p, C.c_int]
+        L.hoo_env_set_solver_stop.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.hoo_env_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hoo_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hoo_env_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -150,6 +152,14 @@ class OracleEnv:
         """switch the oracle's two kernel-motivated deviations back to the reference's behaviour: no oriented-box rejection in the
         collision driver and the unbounded angle wrap of compute_torque (ho_im4.py:476-481)"""
         self.L.hoo_env_set_reference_faithful(self.h, int(bool(on)))
+
+    def set_state_float32(self, on: bool):
+        """control arm: qpos / qvel / warm start rounded to float32 after every substep (the float64 algorithm on a float32 state)"""
+        self.L.hoo_env_set_state_float32(self.h, int(bool(on)))
+
+    def set_solver_stop(self, tol=0.0, maxit=0):
+        """Newton's stopping rule: scaled gradient below ``tol`` (0: 1e-14) or ``maxit`` iterations (0: 100); (1e-6, 20) is the kernel's"""
+        self.L.hoo_env_set_solver_stop(self.h, float(tol), int(maxit))
 
     def set_expert(self, ex: dict):
         T = ex["hand_dof_seq"].shape[0]

@@ -241,12 +241,21 @@ STEP_PARITY_BOUND = {"box": [1.7e-5, 1.7e-5, 1.8e-5, 2.1e-5, 2.2e-5, 1.7e-4, 1.7
                      "banana": [3.7e-5, 4.8e-5, 5.0e-5, 5.0e-5, 5.0e-5, 5.0e-5, 5.0e-5, 8.5e-5]}
 
 
-@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
-def test_env_step_parity_short_horizon(obj, oracle_lib):
-    box_blob, cfg, ex, thresh = _obj_setup(obj)
-    N, STEPS = 48, 8
+@pytest.mark.parametrize("obj,mset", [("box", "test"), ("bottle", "test"), ("banana", "test"), ("box", "bench")])
+def test_env_step_parity_short_horizon(obj, mset, oracle_lib):
+    """``mset`` "bench": the 17 x 600 synthetic motion set bench.py and BASELINE.json's configs run on, three
+    envs per sequence with start frames over the whole sequence -- the oracle comparison on the bench workload's own states
+    (VERDICT r5 weak #10); "test": the 4 x 400 set of the other parity tests."""
+    if mset == "bench":
+        import episode_util as E
+        box_blob, cfg, ex, thresh = E.obj_setup(obj, 17, 600)
+        N, STEPS = 51, 8
+        seqs = np.arange(N) % 17; starts = (np.arange(N) * 37) % 560
+    else:
+        box_blob, cfg, ex, thresh = _obj_setup(obj)
+        N, STEPS = 48, 8
+        seqs = np.arange(N) % 4; starts = (np.arange(N) * 7) % 200
     sim = _sim(box_blob, N, cfg, ex, thresh)
-    seqs = np.arange(N) % 4; starts = (np.arange(N) * 7) % 200
     obs = sim.reset(seqs, starts).cpu().numpy()
     tape = motions.action_tape(STEPS, N)
     wk = cfg.reward_wk()
@@ -474,78 +483,110 @@ def test_rltest_streaming_loop(box_blob, box_model, setup):
     print("streaming control step: %.2f ms" % (per_step * 1e3))
 
 
-@pytest.mark.parametrize("obj,faithful", [("box", False), ("bottle", False), ("banana", False), ("bottle", True), ("banana", True)])
-def test_episode_reward_parity(obj, faithful, oracle_lib):
+@pytest.mark.parametrize("obj,faithful,warm", [("box", False, "shifted"), ("bottle", False, "shifted"), ("banana", False, "shifted"),
+                                               ("bottle", True, "shifted"), ("banana", True, "shifted"), ("bottle", False, "plain")])
+def test_episode_reward_parity(obj, faithful, warm, oracle_lib, monkeypatch):
     """North-star parity statement: the same (seeded, randomly initialised) deterministic policy driven through the
     float64 oracle and through the HIP simulator gives the same episode length and the same episode reward within
     float32 tolerance, over whole episodes of several hundred env steps (6000+ substeps with contacts) -- for the Box and for
     the two convex-mesh objects (BASELINE.json configs 2-4), sixteen episodes each.
     ``faithful``: the oracle in its reference-faithful mode (OracleEnv.set_reference_faithful: no oriented-box rejection in the
     collision driver, unbounded angle wrap) -- the kernel keeps its reject, so this pins "oracle with reject" against "oracle
-    without" on whole episodes of the objects where the reject can drop a (shallow, hull-tip) contact.  Same bounds."""
+    without" on whole episodes of the objects where the reject can drop a (shallow, hull-tip) contact.  Same bounds.
+    ``warm``: "plain" = MuJoCo's own warm start (qacc of the last substep: HOIC_PLAIN_WARMSTART=1) instead of the kernel's
+    default a_smooth + last constraint acceleration -- an asserted arm on the reference's rule.
+
+    How many episodes may leave the tight bounds (reward 2e-3, final state 5e-3) is MEASURED, not chosen: the
+    float64 oracle is run against ITSELF on the same sixteen episodes with (a) the initial positions perturbed by 1e-7 and (b)
+    its state rounded to float32 after every substep (episode_util.ARMS) -- (b) is the least a float32 simulator of this
+    algorithm can differ from the float64 one.  Episodes that diverge there are chaotic (a contact that switches one substep
+    apart is a discrete event after which two equally valid trajectories part); the HIP simulator, which also rounds every
+    intermediate, may have twice as many plus one, and its worst deviation may be three times the controls'.  Recorded on the
+    round-6 library: Bottle controls diverge in episodes 10, 11 (state 1.7e-2, reward 5.6e-3; 1e-7 perturbation: 11 at 3.8e-2 /
+    1.8e-2), HIP in 8, 10, 11, 14 (2.8e-2 / 1.6e-2); Box and Banana: no control outlier, control worst 1.3e-4 / 3.3e-4 and 1.8e-4 /
+    2.9e-3, HIP 1.0e-4 / 3.3e-4 and 7.0e-4 / 3.5e-3.  The Newton iteration cap must never bind in these runs (the warm start may
+    change iteration counts, not results)."""
+    import episode_util as E
     from hoic_amd.rl import PolicyGaussian
-    box_blob, cfg, ex, thresh = _obj_setup(obj)
+    blob, cfg, ex, thresh = _obj_setup(obj)
     N = 16
-    sim = _sim(box_blob, N, cfg, ex, thresh)
     torch.manual_seed(3)
     pol = PolicyGaussian(cfg, 32, 617).eval()
-    pol_d = PolicyGaussian(cfg, 32, 617).to("cuda").eval(); pol_d.load_state_dict(pol.state_dict())
-    seqs = np.arange(N) % 4; starts = np.array([0, 40, 120, 200] * 4) + 10 * (np.arange(N) // 4)
-    wk = cfg.reward_wk()
-    # oracle episodes
-    ref = []
-    for i in range(N):
-        o = _oracle(oracle_lib, box_blob, cfg, thresh, ex[seqs[i]])
-        if faithful:
-            o.set_reference_faithful(True)
-        obs = o.reset(int(starts[i]))
-        tot, n = 0.0, 0
-        with torch.no_grad():
-            for _ in range(600):
-                a = pol.select_action(torch.as_tensor(np.clip(obs, -5, 5)[None], dtype=torch.float32), mean_action=True)[0].numpy()
-                obs, info = o.step(a.astype(np.float64)); r, _ = o.reward(wk)
-                tot += r; n += 1
-                if info["done"]:
-                    break
-        ref.append((tot, n, o.get("qpos")[:33].copy()))
-    # the same on the GPU
-    obs = sim.reset(seqs, starts)
-    alive = torch.ones(N, dtype=torch.bool, device="cuda"); tot = torch.zeros(N, device="cuda", dtype=torch.float64); n = torch.zeros(N, device="cuda")
-    qfinal = [None] * N
-    with torch.no_grad():
-        for _ in range(600):
-            a = pol_d.select_action(torch.clamp(obs, -5, 5), mean_action=True)
-            obs, rew, _, flags, _ = sim.step(a)
-            tot += torch.where(alive, rew.double(), torch.zeros_like(tot)); n += alive.float()
-            done = flags[:, 2] != 0
-            if bool((alive & done).any()):
-                q = sim.get_state()[0].cpu().numpy()
-                for i in torch.nonzero(alive & done).flatten().tolist():
-                    qfinal[i] = q[i]
-            alive &= ~done
-            if not bool(alive.any()):
-                break
-    worst_r = max(abs(float(tot[i]) - ref[i][0]) / ref[i][0] for i in range(N))
-    worst_q = max(float(np.abs(qfinal[i][:33] - ref[i][2]).max()) for i in range(N) if int(n[i]) == ref[i][1])
-    print(f"episode parity {obj}{' (reference-faithful oracle)' if faithful else ''}: lengths {[int(x) for x in n.tolist()]}, "
-          f"worst relative reward deviation {worst_r:.2e}, worst final |dq| {worst_q:.2e}")
-    dev_r = [abs(float(tot[i]) - ref[i][0]) / ref[i][0] for i in range(N)]
-    dev_q = [float(np.abs(qfinal[i][:33] - ref[i][2]).max()) for i in range(N)]
+    seqs, starts = E.episode_starts(N)
+    arms = E.oracle_episodes_parallel(obj, N, ["faithful" if faithful else "base", "base", "perturb", "substep32"][0 if faithful else 1:])
+    ref = arms["faithful" if faithful else "base"]
+    if warm == "plain":
+        monkeypatch.setenv("HOIC_PLAIN_WARMSTART", "1")      # read by hoic_create
+    hip, diag = E.hip_episodes(blob, cfg, ex, thresh, seqs, starts, pol)
+    dev_r, dev_q = E.deviations(hip, ref)
+    ctrl = {a: E.deviations(arms[a], arms["base"]) for a in ("perturb", "substep32")}
+    ctrl_out = sorted(set().union(*[E.outliers(*ctrl[a]) for a in ctrl]))
+    ctrl_worst_r = max(max(ctrl[a][0]) for a in ctrl); ctrl_worst_q = max(max(ctrl[a][1]) for a in ctrl)
+    out = E.outliers(dev_r, dev_q)
+    print(f"episode parity {obj}{' (reference-faithful oracle)' if faithful else ''}{' (plain warm start)' if warm == 'plain' else ''}: "
+          f"lengths {[h[1] for h in hip]}, worst relative reward deviation {max(dev_r):.2e}, worst final |dq| {max(dev_q):.2e}, outliers {out}; "
+          f"float64 controls: outliers {ctrl_out}, worst {ctrl_worst_r:.2e} / {ctrl_worst_q:.2e}; Newton cap hits {diag['solver_cap_hits']}")
     print("  per episode: relative reward deviation " + " ".join(f"{x:.1e}" for x in dev_r) + "; final |dq| " + " ".join(f"{x:.1e}" for x in dev_q))
-    # An episode is several thousand substeps of contact dynamics: a contact that switches one substep apart in float32 and
-    # float64 is a discrete event after which the two trajectories are different (equally valid) ones.  Box and Banana: every
-    # episode within the tight bounds (reward 2e-3, final state 5e-3; measured worst 1.0e-4 / 3.3e-4 and 7.0e-4 / 3.5e-3), at
-    # most one outlier admitted.  The Bottle lies on its side and ROLLS on the table: of these sixteen episodes two left the
-    # tight bounds on the round-4 library (a2c62acd02f9f8f5: episodes 8 and 11, reward 2.3e-3, state 1.0e-2) and four on the
-    # round-5 library (8, 10, 11, 14: reward up to 1.6e-2, state up to 2.8e-2) -- which ones and how far changes with every
-    # rounding change in the kernel, the other twelve agree to 1e-4 .. 1e-3.  Asserted for the Bottle: at most four outliers,
-    # and for every object every episode ends at the oracle's step with an episode reward within 5 %.
-    outliers = [i for i in range(N) if not (dev_r[i] < 2e-3 and dev_q[i] < 5e-3)]
     for i in range(N):
-        assert int(n[i]) == ref[i][1], (i, int(n[i]), ref[i][1])
+        assert hip[i][1] == ref[i][1], (i, hip[i][1], ref[i][1])
         assert ref[i][1] > 100
-        assert dev_r[i] < 5e-2, (i, float(tot[i]), ref[i][0])
-    assert len(outliers) <= (4 if obj == "bottle" else 1), (outliers, dev_r, dev_q)
+        assert dev_r[i] < 5e-2, (i, hip[i][0], ref[i][0])
+    assert len(out) <= 2 * len(ctrl_out) + 1, (out, ctrl_out, dev_r, dev_q)
+    assert max(dev_r) <= max(3 * ctrl_worst_r, 2e-3) and max(dev_q) <= max(3 * ctrl_worst_q, 5e-3), (max(dev_r), max(dev_q), ctrl_worst_r, ctrl_worst_q)
+    assert diag["solver_cap_hits"] == 0 and diag["contact_overflow"] == 0, diag
+
+
+@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
+def test_episode_parity_has_no_bias(obj, oracle_lib):
+    """Chaos or bias (VERDICT r5 #4 ii): SIXTY-FOUR whole episodes per object, HIP against the float64 oracle, beside the float64
+    oracle on a float32 state (the control of test_episode_reward_parity) against the same reference.  Signed relative
+    episode-reward deviations d_i (HIP) and c_i (control).  Asserted: |mean d| < 2e-4 over the episodes inside the tight bounds and
+    |median d| < 5e-5 -- three orders below the reward differences that matter to training; the outlier count obeys the control's;
+    every episode ends at the oracle's step; the Newton cap never binds.
+    What is NOT asserted is a sign test against zero: rounding noise is not sign-neutral here.  The imitation reward is a product of
+    exp(-k err^2) terms, a perturbed trajectory tracks slightly WORSE on average (second order), and the float64 control shows the
+    same split as the kernel (Box: 47 of 64 negative in both, medians -1.3e-6 and -1.5e-6).  The test therefore compares the
+    kernel's sign split WITH THE CONTROL'S: a two-sided binomial test of the kernel's negative count against the control's
+    negative fraction must not reject at 1 %, and the two medians agree to 2e-5.
+    Measured on the round-6 library (profiles/r06_episode_parity_statistics.txt): Box no outlier in either, 47 of 64 negative in
+    both; Bottle 11 outliers (worst 1.5e-2) against the control's 9 (1.4e-2), largely the same episodes; Banana 2 (2.8e-3)
+    against 0 (5e-4)."""
+    import math
+    import episode_util as E
+    from hoic_amd.rl import PolicyGaussian
+    blob, cfg, ex, thresh = _obj_setup(obj)
+    N = 64
+    torch.manual_seed(3)
+    pol = PolicyGaussian(cfg, 32, 617).eval()
+    seqs, starts = E.episode_starts(N)
+    arms = E.oracle_episodes_parallel(obj, N, ["base", "substep32"])
+    ref = arms["base"]
+    hip, diag = E.hip_episodes(blob, cfg, ex, thresh, seqs, starts, pol)
+    dev_r, dev_q = E.deviations(hip, ref)
+    c_r, c_q = E.deviations(arms["substep32"], ref)
+    out, ctrl_out = E.outliers(dev_r, dev_q), E.outliers(c_r, c_q)
+    d = np.array([(h[0] - r[0]) / abs(r[0]) for h, r in zip(hip, ref)])
+    dc = np.array([(h[0] - r[0]) / abs(r[0]) for h, r in zip(arms["substep32"], ref)])
+    neg, negc = int((d < 0).sum()), int((dc < 0).sum())
+    p0 = min(max(negc / N, 0.05), 0.95)
+    pmf = [math.comb(N, j) * p0 ** j * (1 - p0) ** (N - j) for j in range(N + 1)]
+    p_split = min(1.0, sum(q for q in pmf if q <= pmf[neg] * (1 + 1e-9)))        # two-sided exact binomial test
+    inside = [i for i in range(N) if i not in out]
+    print(f"episode bias {obj}: {N} episodes, outliers HIP {out} / float32-state control {ctrl_out}; signed relative reward deviation: "
+          f"mean {d.mean():+.2e} (inside the bounds {d[inside].mean():+.2e}), median {np.median(d):+.2e}, {neg} of {N} negative; "
+          f"control: mean {dc.mean():+.2e}, median {np.median(dc):+.2e}, {negc} negative; binomial test of the kernel's split against the "
+          f"control's p = {p_split:.3f}; worst |d| {np.abs(d).max():.2e} (control {np.abs(dc).max():.2e}); Newton cap hits {diag['solver_cap_hits']}")
+    # a diverged (chaotic) episode may also END at another step: counted as an outlier (its state deviation is infinite), admitted
+    # only as often as in the control
+    mism = [i for i in range(N) if hip[i][1] != ref[i][1]]
+    mism_c = [i for i in range(N) if arms["substep32"][i][1] != ref[i][1]]
+    print(f"  episodes ending at another step than the reference: HIP {mism} ({[(hip[i][1], ref[i][1]) for i in mism]}), control {mism_c}")
+    assert len(mism) <= len(mism_c) + 1 and set(mism) <= set(out)
+    assert abs(float(np.median(d))) < 5e-5 and abs(float(np.median(d) - np.median(dc))) < 2e-5
+    assert abs(float(d[inside].mean())) < 2e-4
+    assert p_split > 0.01, (neg, negc, p_split)
+    assert len(out) <= 2 * len(ctrl_out) + 2, (out, ctrl_out)
+    assert diag["solver_cap_hits"] == 0 and diag["contact_overflow"] == 0, diag
 
 
 def test_reset_obs_against_reference_goldens():
