@@ -438,6 +438,7 @@ def main():
     # rollout / update split: the agent's host runs ahead of the GPU, so the two durations are taken between HIP events on the
     # main stream (agent.IterationInfo) and read here, after the timed region; they add up to the region's GPU timeline
     t_sample, t_update = sum(i["T_sample"] for i in infos), sum(i["T_update"] for i in infos)
+    t_tail = sum(i["T_sample_tail"] for i in infos if hasattr(i, "_ready"))      # the rollout's tail beyond the main stream's rollout-end event
     tmax = torch.tensor([elapsed, t_sample, t_update], device="cuda", dtype=torch.float64)
     if distributed:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -487,6 +488,11 @@ def main():
                        "gemm_kernel_selection": "PyTorch TunableOp selections recorded on MI355X (hoic_amd/data/tunableop_gfx950.csv)"
                                                 if agent.tuned_gemms else "library default"},
             "rollout_only_env_steps_per_s": total_env_steps / t_sample if t_sample > 0 else None,
+            # the rollout's tail (last reward parts, masks + statistics, bootstrap values) runs on a side stream beside the update's
+            # first value forward: the part of it that outlasts the main stream's rollout-end event is inside update_s_per_iteration;
+            # rollout_only above is without it, this rate is with it (a complete rollout whatever stream its tail ran on)
+            "rollout_tail_s_per_iteration": t_tail / n_it,
+            "rollout_with_tail_env_steps_per_s": total_env_steps / (t_sample + t_tail) if t_sample > 0 else None,
             "update_s_per_iteration": t_update / n_it, "rollout_s_per_iteration": t_sample / n_it,
             "rollout_host_enqueue_s_per_iteration": host_enqueue / n_it,
             "host_s_per_iteration": ({"enqueue_rollout": host_phases[0] / n_it, "enqueue_update": host_phases[1] / n_it,
@@ -521,7 +527,8 @@ def main():
                     out["other_configs"][name] = {"error": f"{type(e).__name__}: {e}"}
         out["cpu_baseline"] = cpu
         # a cut contact list (more than 32 contacts, or more constraint rows than the solver's 128) is physics the reference does
-        # not have: never observed, and loud if it ever is
+        # not have (its buffers: nconmax 100, njmax 500): never observed, and FATAL if it ever is -- the line is still printed, with
+        # the counts under "warnings", and the process exits with code 3
         over = {"headline": diag["contact_overflow"], **{k: v.get("contact_overflow", 0) for k, v in out.get("other_configs", {}).items()}}
         if any(over.values()):
             out["warnings"] = [f"contact list cut in {n} forward passes of {k} (hoic_get_diagnostics): results differ from the reference's uncapped solve"
@@ -529,8 +536,13 @@ def main():
             sys.stderr.write("bench.py WARNING: " + "; ".join(out["warnings"]) + "\n")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        cut = any(over.values())
+    else:
+        cut = False
     if distributed:
         torch.distributed.destroy_process_group()
+    if cut:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

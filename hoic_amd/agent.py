@@ -103,17 +103,23 @@ class IterationInfo(dict):
     timeline between HIP events of the main stream (iteration start, rollout end, update end); reading one of them waits for
     the iteration's last event, so a loop that wants to stay ahead reads them later (bench.py: after the timed region)."""
 
-    def __init__(self, log, events):
+    def __init__(self, log, events, ready=None):
         super().__init__(log=log)
         self._events = events
+        self._ready = ready
 
     def __missing__(self, k):
-        if k not in ("T_sample", "T_update", "T_total"):
+        if k not in ("T_sample", "T_update", "T_total", "T_sample_tail"):
             raise KeyError(k)
         e0, e1, e2 = self._events
         e2.synchronize()
         self["T_sample"], self["T_update"] = e0.elapsed_time(e1) * 1e-3, e1.elapsed_time(e2) * 1e-3
         self["T_total"] = self["T_sample"] + self["T_update"]
+        # the rollout's tail (wait for the last reward parts, masks + statistics, bootstrap values) runs on the sampler's side
+        # stream beside the update's first value forward: how far it reaches BEYOND the main stream's rollout-end event is booked
+        # under T_update (the learner waits for it before it forms the advantages) and reported here, so that T_sample +
+        # T_sample_tail is a complete rollout whatever stream its tail ran on
+        self["T_sample_tail"] = max(e1.elapsed_time(self._ready) * 1e-3, 0.0) if self._ready is not None else 0.0
         return dict.__getitem__(self, k)
 
 
@@ -205,7 +211,12 @@ class PPOLearner:
         if self.update_dtype == "f16x3" and states.is_cuda and states.dtype == torch.float32:
             from .mlp import PackedInput
             # split once per iteration, shared by both networks and all epochs -- by the rollout's own launches when it could
-            states = getattr(batch, "packed_states", None) or PackedInput(states)
+            # (the packed buffer belongs to the sampler and is rewritten by its next rollout: a batch kept across a later sample()
+            #  -- rollout-only loops, two batches in flight, an external sampler / learner split -- packs its own states again)
+            pin = getattr(batch, "packed_states", None)
+            if pin is not None and getattr(batch, "packed_generation", None) != getattr(pin, "generation", None):
+                pin = None
+            states = pin or PackedInput(states)
             # this forward pass is also the value network's first training pass (the weights do not change in between)
             veng = self._split_engines()[0]
             self._v_first = veng.forward(states)
@@ -783,6 +794,13 @@ class AgentHandMimic:
 
     @torch.no_grad()
     def sample(self, min_batch_size):
+        """One rollout -> (batch, log) (agent_handmimic.py:503-535).  ``batch`` holds [T, N, .] device tensors: states, actions,
+        rewards, masks, exps, next_values (bootstrap values of the final observations), valid (whole-episode mode).  On the GPU
+        with the f16x3 learner the rollout's tail runs on a side stream: ``batch.ready`` is then a HIP event, and a consumer other
+        than PPOLearner.update_params must make its stream wait for it (``torch.cuda.current_stream().wait_event(batch.ready)``, or
+        ``batch.ready.synchronize()`` on the host) BEFORE reading rewards, masks or next_values -- ``.item()`` / ``.cpu()``
+        synchronise the current stream only.  ``batch.packed_states`` is the sampler's own reused buffer (valid until the next
+        sample(); update_params checks ``packed_generation``)."""
         if self.sample_mode == "episodes":
             return self._sample_episodes(min_batch_size)
         t0 = time.time()
@@ -825,8 +843,14 @@ class AgentHandMimic:
             for t_ in ts:
                 for s_ in users:
                     t_.record_stream(s_)
-        if side is not None and getattr(self, "_rollout_done", None) is not None:
-            side.wait_event(self._rollout_done)        # the filter as the previous rollout left it (merge of the forks, ranks' merge)
+        if side is not None:
+            if getattr(self, "_rollout_done", None) is not None:
+                side.wait_event(self._rollout_done)    # the filter as the previous rollout left it (merge of the forks, ranks' merge)
+            else:
+                # first rollout of this agent (or the first after load_checkpoint / set_expert cleared the event): whatever set-up
+                # the main stream still holds -- filter state, expert tables, episode bounds -- comes first.  (_side() may hand
+                # out a range stream that was created by ANOTHER agent: bench.quick_config shares the headline agent's streams.)
+                side.wait_stream(torch.cuda.current_stream(dev))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             # the rollout's N(0, 1) draws in one launch up front: a range's chain then samples inside the action-head kernel
             noise_all = torch.randn(T, N, self.action_dim, device=dev, dtype=dt) if fwd is not None else None
@@ -881,6 +905,8 @@ class AgentHandMimic:
             pin = getattr(self, "_rollout_input", None)
             if pin is None or pin.M != T * N:
                 pin = self._rollout_input = PackedInput.for_rollout(T * N, self.state_dim, getattr(self.running_state, "clip", None), dev)
+            if pin is not None:        # the buffer is the agent's and is reused: a batch may use it only while it holds THAT batch's rows
+                pin.generation = getattr(pin, "generation", 0) + 1
         rows_packed = pin is not None
         gemm_done = None
         t_host0 = time.perf_counter()
@@ -967,10 +993,11 @@ class AgentHandMimic:
             next_values = self._bootstrap_values(obs)
             if tail is not None:
                 next_values.record_stream(main)
-                ready = torch.cuda.Event(); ready.record(tail)
+                ready = torch.cuda.Event(enable_timing=True); ready.record(tail)
             batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=masks,
                                     exps=ones, next_values=next_values, valid=None, ready=ready,
-                                    packed_states=pin if rows_packed else None)
+                                    packed_states=pin if rows_packed else None,
+                                    packed_generation=getattr(pin, "generation", None) if rows_packed else None)
             if stats_dev is not None:
                 log = self._make_log(T * N, rewards, None, None, rinfo_all, None, t0, defer=self.run_ahead, stats_dev=stats_dev)
             else:
@@ -1092,6 +1119,7 @@ class AgentHandMimic:
             batch, log = self.sample(int(math.ceil(self.cfg.min_batch_size / share)))
             ev[1].record(cur)
             h1 = time.perf_counter()
+            ready_ev = getattr(batch, "ready", None)
             self.update_params(batch)
             ev[2].record(cur)
             del batch
@@ -1103,7 +1131,7 @@ class AgentHandMimic:
             self.last_host_phases = (h1 - h0, h2 - h1, time.perf_counter() - h2)
             if self.cfg.end_reward:
                 self.env.end_reward = float(log.avg_c_reward * self.cfg.gamma / (1 - self.cfg.gamma))   # :318-319
-            info = IterationInfo(log, ev)
+            info = IterationInfo(log, ev, ready_ev)
         else:
             t0 = time.time()
             self.per_epoch_update(epoch)
@@ -1256,6 +1284,16 @@ class AgentHandMimic:
             pickle.dump(cp, f)
         return path
 
+    def set_expert(self, expert_seqs):
+        """New reference motions for the training envs (BatchedHandObjMimic.set_expert) -- through the agent, so that the next
+        rollout's side-stream set-up (episode draws against the new sequence bounds) is ordered behind the upload."""
+        self.env.set_expert(expert_seqs)
+        self.expert_seqs = expert_seqs
+        self.seq_num = len(expert_seqs)
+        self._max_start = torch.clamp(self.env.seq_len - 200, min=1)
+        self._obs = None                 # the envs' episodes belong to the old set: the next rollout resets them
+        self._rollout_done = None
+
     def load_checkpoint(self, it, path=None):
         path = path or "%s/iter_%04d.p" % (self.cfg.model_dir, it)
         with open(path, "rb") as f:
@@ -1263,3 +1301,4 @@ class AgentHandMimic:
         self.policy_net.load_state_dict({k: v.to(self.dtype) for k, v in cp["policy_dict"].items()})
         self.value_net.load_state_dict({k: v.to(self.dtype) for k, v in cp["value_dict"].items()})
         self.running_state = BatchZFilter.from_reference(cp["running_state"], device=self.device)
+        self._rollout_done = None        # the next rollout's side-stream set-up waits for what this left on the main stream (sample())

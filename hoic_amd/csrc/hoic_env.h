@@ -73,7 +73,11 @@ __device__ __forceinline__ void dev_pd_torque(const DevModel& m, const DevConfig
   // dofs couple to no hand dof in M (different subtrees: those entries are exact zeros, build_model checks the structure), its
   // own block is positive definite, and its right-hand side and diagonal shift are zero here -- the hand part of the solution
   // is the same, entry by entry, and the 16 masked copies of the accumulator drop out.
-  const float acc = dev_hsolve<false>(m, w, M, kd * dt, (m.nv == NV && n == NV - 6) ? NV : n, rhs);
+  // (A NON-FINITE object pose -- a diverged object: the env is flagged failed by the substep's own check -- would leak through
+  //  0 * NaN of the matrix-core factorisation into the hand's torques and, through them, into this step's recorded contacts and
+  //  reward inputs, which the reference's hand-block solve (ho_im4.py:455-462) keeps clean: such an env takes the masked solve.)
+  const bool obj_finite = __ballot(tid >= n && tid < m.nq && !(fabsf(w.qpos[tid]) < 1e10f)) == 0ull;
+  const float acc = dev_hsolve<false>(m, w, M, kd * dt, (m.nv == NV && n == NV - 6 && obj_finite) ? NV : n, rhs);
   if (tid < NV) {
     float tq = 0.f;
     if (tid < n) {

@@ -1242,31 +1242,40 @@ def test_gae_device_path_is_bit_identical():
     assert torch.equal(a1, a2)              # fixed summation order: the same bits every time
 
 
-def test_diagnostics_guard_the_compiled_caps(box_blob, setup):
-    """hoic_get_diagnostics: the 32-contact cap and the Newton iteration cap are observable.  A contact-rich rollout
-    (starts in the grasp phase, object in the hand on the table side) must not overflow the contact list; with a
-    1-iteration solver cap the cap counter must fire, and reset clears both."""
-    cfg, ex, thresh = setup
+@pytest.mark.parametrize("obj", ["box", "bottle", "banana"])
+def test_diagnostics_guard_the_compiled_caps(obj):
+    """hoic_get_diagnostics: the 32-contact / 128-row caps and the Newton iteration cap are observable, for all three objects
+    (the reference's buffers are nconmax 100 / njmax 500, sphere_mesh_hand_add_geom.xml:8: a cut list would be physics it does not
+    have).  Two contact-rich rollouts must not overflow the contact list: starts around and after the pick-up on the default
+    motions, and the CLOSED-GRASP motions (motions.synthetic_expert(grasp="closed"): five fingers closed onto the object from frame
+    160 on -- the workload of bench.py's box_closed_grasp line, most envs hold hand-object contacts); with a 1-iteration solver cap
+    the cap counter must fire, and reset clears both."""
+    blob, cfg, ex, thresh = _obj_setup(obj)
+    model = mjcf.CompiledModel.from_blob(blob)
     N = 1024
-    sim = _sim(box_blob, N, cfg, ex, thresh)
     rng = np.random.default_rng(5)
-    seqs = rng.integers(0, 4, N); starts = rng.integers(90, 300, N)       # around and after the pick-up at frame 100
-    sim.reset(seqs, starts)
-    assert sim.diagnostics() == {"contact_overflow": 0, "solver_cap_hits": 0, "envs_with_overflow": 0}
-    it_hist = np.zeros(64, dtype=np.int64)
-    for t in range(12):
-        a = torch.as_tensor(rng.normal(size=(N, 32)) * 0.1, dtype=torch.float32)
-        out = sim.step(a, torch.as_tensor(seqs, dtype=torch.int32), torch.as_tensor(starts, dtype=torch.int32))
-        it_hist += np.bincount(out[3][:, 3].cpu().numpy().clip(0, 63), minlength=64)
-    d = sim.diagnostics()
-    assert d["contact_overflow"] == 0 and d["envs_with_overflow"] == 0, d
-    # the cap is the MJCF's 20 iterations (cfg.solver_iterations): report how often the last substep of a step used 8 or more
-    frac_cap = it_hist[8:].sum() / it_hist.sum()
-    print("solver_cap_hits over 12 steps x 15 substeps x 1024 envs:", d["solver_cap_hits"], "| last-substep iteration histogram",
-          it_hist[:10].tolist(), "| fraction with >= 8 iterations", frac_cap)
-    assert d["solver_cap_hits"] <= 0.02 * 12 * 15 * N
-    sim.close()
-    sim = _sim(box_blob, 64, cfg, ex, thresh, solver_iterations=1)
+    for workload, expert, lo, hi in (("default", ex, 90, 300), ("closed-grasp", motions.synthetic_expert(model, 4, 400, grasp="closed"), 150, 330)):
+        sim = _sim(blob, N, cfg, expert, thresh)
+        seqs = rng.integers(0, 4, N); starts = rng.integers(lo, hi, N)
+        sim.reset(seqs, starts)
+        assert sim.diagnostics() == {"contact_overflow": 0, "solver_cap_hits": 0, "envs_with_overflow": 0}
+        it_hist = np.zeros(64, dtype=np.int64)
+        for t in range(12):
+            a = torch.as_tensor(rng.normal(size=(N, 32)) * 0.1, dtype=torch.float32)
+            out = sim.step(a, torch.as_tensor(seqs, dtype=torch.int32), torch.as_tensor(starts, dtype=torch.int32))
+            it_hist += np.bincount(out[3][:, 3].cpu().numpy().clip(0, 63), minlength=64)
+        d = sim.diagnostics()
+        q, v, _ = sim.get_state()
+        pr = sim.probe_forward(q[:256].cpu().numpy(), v[:256].cpu().numpy(), kinematics_only=True)
+        ncon = (pr["contacts"][:, :, 15] > 0).sum(1)
+        # the cap is the MJCF's 20 iterations (cfg.solver_iterations): report how often the last substep of a step used 8 or more
+        print(f"{obj} {workload}: contact_overflow {d['contact_overflow']}, solver_cap_hits {d['solver_cap_hits']} over 12 steps x 15 substeps x {N} envs; "
+              f"contacts per env mean {ncon.mean():.1f} max {ncon.max()} (cap 32); last-substep iteration histogram {it_hist[:10].tolist()}, "
+              f"fraction with >= 8 iterations {it_hist[8:].sum() / it_hist.sum():.4f}")
+        assert d["contact_overflow"] == 0 and d["envs_with_overflow"] == 0, d
+        assert d["solver_cap_hits"] <= 0.02 * 12 * 15 * N
+        sim.close()
+    sim = _sim(blob, 64, cfg, ex, thresh, solver_iterations=1)
     sim.reset(seqs[:64], starts[:64])
     sim.step(torch.as_tensor(rng.normal(size=(64, 32)) * 0.1, dtype=torch.float32))
     d1 = sim.diagnostics(reset=True)
@@ -1451,3 +1460,38 @@ def test_reward_curve_band_after_ten_iterations(box_model):
     assert abs(res["fixed_f16x3"] - 0.7255) < 0.008, res
     assert abs(per_seed["fixed_f16x3"][0] - per_seed["fixed_f16x3"][1]) < 0.02, per_seed
     assert abs(res["fixed_f16x3_frozen"] - 0.7353) < 0.004, res
+
+
+def test_non_finite_object_pose_fails_that_env_only(box_blob, setup):
+    """A diverged object (non-finite pose) must cost its own env the episode and nothing else: the env is flagged failed
+    by the substep's check, its hand torques come from the masked hand-block solve as in the reference (ho_im4.py:455-462: M[:26, :26]
+    only), every OTHER env's observation, reward and flags are bit-identical to a run without the bad envs, and with the next
+    episode given the launch resets the bad envs to finite observations."""
+    cfg, ex, thresh = setup
+    N = 16
+    bad = [2, 5, 11]
+    seqs = np.arange(N) % 4; starts = 40 + 10 * np.arange(N)
+    tape = motions.action_tape(2, N, seed=5)
+    outs = []
+    for poison in (False, True):
+        sim = _sim(box_blob, N, cfg, ex, thresh)
+        sim.reset(seqs, starts)
+        q, v, _ = sim.get_state()
+        if poison:
+            q = q.clone(); v = v.clone()
+            q[bad[0], 27] = float("nan"); q[bad[1], 30] = float("inf"); v[bad[2], 28] = float("nan"); q[bad[2], 26] = float("nan")
+            sim.set_state(q, v)
+        o = sim.step(torch.tensor(tape[0], dtype=torch.float32), torch.as_tensor(seqs, dtype=torch.int32), torch.as_tensor(starts, dtype=torch.int32))
+        o = [x.clone() for x in o]
+        o2 = sim.step(torch.tensor(tape[1], dtype=torch.float32))
+        outs.append((o, [x.clone() for x in o2]))
+        sim.close()
+    (c1, c2), (p1, p2) = outs
+    good = [i for i in range(N) if i not in bad]
+    for a, b in zip(c1, p1):
+        assert torch.equal(a[good], b[good])
+    for a, b in zip(c2, p2):
+        assert torch.equal(a[good], b[good])
+    fl = p1[3].cpu().numpy()
+    assert fl[bad, 0].all() and fl[bad, 2].all() and not c1[3].cpu().numpy()[bad, 0].any()      # fail + done, only when poisoned
+    assert bool(torch.isfinite(p1[0][bad]).all()) and bool(torch.isfinite(p2[0]).all()) and bool(torch.isfinite(p2[1]).all())
