@@ -1434,7 +1434,14 @@ def test_reward_curve_band_after_ten_iterations(box_model):
         0.7353 +- 0.0020 at iteration 10 (5 seeds); the HIP arm 0.7350 +- 0.0015 (5 seeds,
         profiles/r05_reward_curve_box_hip_fixed_f16x3_frozen.json) and stays within 1.4 sigma of the CPU curve at every evaluation
         to iteration 100.  Asserted: the mean of two seeds within 0.004 (2 sigma of both arms) of the CPU value -- the 0.010
-        between this arm and the online one above is the filter's handling, not the simulator."""
+        between this arm and the online one above is the filter's handling, not the simulator;
+      * round 6: the headline arm is pinned to a CPU value too, not to itself.  tools/reward_curve.py's
+        cpu_fixed_online arm is the float64 oracle under the headline sampler's OWN estimator and filter handling (fixed horizon,
+        two range forks of the filter updated step by step, merged after the rollout): 0.7272 +- 0.0018 at iteration 10 (5 seeds,
+        profiles/r06_reward_curve_box_cpu_fixed_online.json), and 0.7276 / 0.7991 / 0.8860 at iterations 30 / 60 / 100 where the
+        headline arm has 0.7284 / 0.7996 / 0.8873 (profiles/r05_reward_curve_box_hip_fixed_f16x3.json): within one standard error of
+        the difference at every one of the 21 evaluations to iteration 100 (worst 0.93).  Asserted: the mean of two seeds of fixed_f16x3 within 0.006 of
+        0.7272."""
     from hoic_amd.agent import AgentHandMimic
     from hoic_amd.config import Config
     ex = motions.synthetic_expert(box_model, 17, 600)
@@ -1457,7 +1464,8 @@ def test_reward_curve_band_after_ten_iterations(box_model):
     print("deterministic reward per step after 10 iterations:", res, per_seed)
     assert abs(res["episodes_frozen"] - 0.7502) < 0.004, res
     assert abs(res["episodes"] - 0.7502) < 0.005, res
-    assert abs(res["fixed_f16x3"] - 0.7255) < 0.008, res
+    assert abs(res["fixed_f16x3"] - 0.7272) < 0.006, res          # cpu_fixed_online: the float64 oracle under the same sampler and filter handling
+    assert abs(res["fixed_f16x3"] - 0.7255) < 0.008, res          # (and its own earlier band: a regression check)
     assert abs(per_seed["fixed_f16x3"][0] - per_seed["fixed_f16x3"][1]) < 0.02, per_seed
     assert abs(res["fixed_f16x3_frozen"] - 0.7353) < 0.004, res
 

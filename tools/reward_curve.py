@@ -9,6 +9,11 @@ Arms
   cpu_fixed      the batched sampler's FIXED-HORIZON scheme on the CPU oracle: `envs` persistent oracle envs spread over
                  the workers, ceil(min_batch / envs) steps of every env per iteration, episodes continue across
                  iterations, value bootstrap at the cut — isolates the simulator from the batching scheme
+  cpu_fixed_online cpu_fixed with the HIP sampler's ONLINE observation filter: the envs step in lockstep, every step's observations
+                 update the filter of their env range (two ranges, each with a fork of the running filter, merged after the
+                 rollout: AgentHandMimic.sample) and are normalised with the statistics after that update, the policy forward runs on
+                 the whole step's batch -- the float64 oracle under EXACTLY the headline sampler's estimator and filter handling
+                 (the value the headline arm hip_fixed_f16x3 is pinned to)
   hip_fixed      the product default: AgentHandMimic(sample_mode="fixed") on the HIP simulator
   hip_episodes   AgentHandMimic(sample_mode="episodes"): the reference's whole-episode batch on the HIP simulator,
                  n_envs = `--episode-workers` playing num_threads
@@ -151,6 +156,28 @@ def worker_main(conn, wid, obj, seed, shared, n_fixed_envs):
                             seq, start = draw(); f[0].set_expert(ex[seq]); nobs = f[0].reset(start)
                         f[1] = nobs
             conn.send((S, A, R, C, M, RAW, np.stack([f[1] for f in fixed]).astype(np.float32)))
+        elif kind == "fixed_obs":        # cpu_fixed_online: the persistent envs' current observations (created on first use)
+            if fixed is None:
+                fixed = []
+                for _ in range(n_fixed_envs):
+                    e = new_env(); seq, start = draw(); e.set_expert(ex[seq])
+                    fixed.append([e, e.reset(start)])
+            conn.send(np.stack([f[1] for f in fixed]).astype(np.float32))
+        elif kind == "fixed_step":       # cpu_fixed_online: one step of every env with the parent's actions
+            _, epoch, act, end_reward = msg
+            cfg.update_adaptive_params(epoch)
+            wk = cfg.reward_wk()
+            E = len(fixed)
+            R = np.zeros(E, np.float32); C = np.zeros(E, np.float32); M = np.zeros(E, np.float32)
+            for i, f in enumerate(fixed):
+                nobs, info = f[0].step(act[i].astype(np.float64))
+                c, _ = f[0].reward(wk)
+                C[i] = c; R[i] = c + end_reward if (end_reward and info["end"]) else c
+                M[i] = 0.0 if info["done"] else 1.0
+                if info["done"]:
+                    seq, start = draw(); f[0].set_expert(ex[seq]); nobs = f[0].reset(start)
+                f[1] = nobs
+            conn.send((R, C, M, np.stack([f[1] for f in fixed]).astype(np.float32)))
         elif kind == "eval":      # deterministic episode on sequence `seq` from frame 0, train-mode termination
             _, epoch, mean, std, seq = msg
             cfg.update_adaptive_params(epoch)
@@ -201,7 +228,7 @@ def run_cpu_arm(args, arm, seed):
     proto = PolicyGaussian(cfg, 32, 617)                  # only for the parameter shapes of the shared buffers
     shared = {k: torch.zeros_like(p.data).share_memory_() for k, p in proto.named_parameters()}
     W = args.workers
-    n_fixed = args.envs // W if arm == "cpu_fixed" else 0
+    n_fixed = args.envs // W if arm in ("cpu_fixed", "cpu_fixed_online") else 0
     # ---- fork the CPU samplers BEFORE anything initialises the GPU in this process (torch is imported, HIP is not)
     ctx = mp.get_context("fork")
     pipes, procs = [], []
@@ -244,7 +271,7 @@ def run_cpu_arm(args, arm, seed):
         return {"reward_per_step": tot / max(n, 1), "mean_len": n / len(res), "mean_percent": float(np.mean([r[3] for r in res]))}
 
     curve, evals, end_reward = [], [], 0.0
-    T_fixed = int(math.ceil(cfg.min_batch_size / max(n_fixed * W, 1))) if arm == "cpu_fixed" else 0
+    T_fixed = int(math.ceil(cfg.min_batch_size / max(n_fixed * W, 1))) if arm in ("cpu_fixed", "cpu_fixed_online") else 0
     per_worker = int(math.floor(cfg.min_batch_size / (W * args.slots)))    # thread_batch_size (:509) of each sampler thread
     t_start = time.time()
     for it in range(args.iters + 1):
@@ -277,6 +304,39 @@ def run_cpu_arm(args, arm, seed):
             learner.policy_net.train(); learner.value_net.train()
             learner.optimize(states, actions, torch.as_tensor(adv, device=dev, dtype=torch.float32)[:, None],
                              torch.as_tensor(ret, device=dev, dtype=torch.float32)[:, None])
+        elif arm == "cpu_fixed_online":
+            # the headline sampler's scheme (AgentHandMimic.sample, fixed horizon): two env ranges, each with a fork of the running
+            # filter that its own observations update step by step; a step's rows are normalised with the statistics AFTER that
+            # update; forks merged after the rollout; bootstrap values of the final observations through the merged filter
+            E = n_fixed * W
+            half = (E // 2 // 64) * 64 if E >= 128 else E // 2
+            ranges = [(0, half), (half, E - half)] if half > 0 else [(0, E)]
+            forks = [filt.fork() for _ in ranges]
+            S = torch.zeros(T_fixed, E, 617, device=dev); A = torch.zeros(T_fixed, E, 32, device=dev)
+            R = np.zeros((T_fixed, E), np.float32); C = np.zeros((T_fixed, E), np.float32); M = np.zeros((T_fixed, E), np.float32)
+            for c in pipes:
+                c.send(("fixed_obs",))
+            obs = np.concatenate([c.recv() for c in pipes])
+            learner.policy_net.eval()
+            for t in range(T_fixed):
+                ob = torch.as_tensor(obs, device=dev)
+                for fk, (first, count) in zip(forks, ranges):
+                    S[t, first:first + count] = fk(ob[first:first + count])
+                with torch.no_grad():
+                    A[t] = learner.policy_net.select_action(S[t])
+                act = A[t].cpu().numpy()
+                for w_, c in enumerate(pipes):
+                    c.send(("fixed_step", it, act[w_ * n_fixed:(w_ + 1) * n_fixed], end_reward))
+                parts = [c.recv() for c in pipes]
+                R[t] = np.concatenate([p_[0] for p_ in parts]); C[t] = np.concatenate([p_[1] for p_ in parts]); M[t] = np.concatenate([p_[2] for p_ in parts])
+                obs = np.concatenate([p_[3] for p_ in parts])
+            t_sample = time.time() - t0
+            filt.absorb(forks)
+            tt = lambda x: torch.as_tensor(x, device=dev)
+            with torch.no_grad():
+                nv = learner.value_net(filt(tt(obs), update=False)).squeeze(1)
+            batch = SimpleNamespace(states=S, actions=A, rewards=tt(R), masks=tt(M), next_values=nv, valid=None)
+            learner.update_params(batch)
         else:
             for c in pipes:
                 c.send(("fixed", it, mean, std, T_fixed, end_reward))
@@ -416,7 +476,7 @@ def main():
     common = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--eval-every", str(args.eval_every),
               "--workers", str(args.workers), "--slots", str(args.slots), "--obj", args.obj, "--envs", str(args.envs), "--episode-workers", str(args.episode_workers)]
     t0 = time.time()
-    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0].split("+")[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3", "hip_fixed_f16x3_frozen")]
+    side, serial = [j for j in jobs if j[0] in ("cpu_episodes", "cpu_fixed", "cpu_fixed_online", "hip_episodes", "hip_episodes_frozen")], [j for j in jobs if j[0].split("+")[0] in ("hip_fixed", "hip_fixed_long", "hip_fixed_f16x3", "hip_fixed_f16x3_frozen")]
     procs = []
     for arm, seed in side:
         f = os.path.join(tmp, f"{arm}_{seed}.json")
@@ -443,6 +503,7 @@ def main():
                    "batch (without the end bonus); the same PPOLearner / schedule / synthetic motions in every arm",
            "arms": {"cpu_episodes": "float64 CPU-oracle envs, whole episodes per worker process (reference-shaped)",
                     "cpu_fixed": "float64 CPU-oracle envs, the batched sampler's fixed-horizon scheme",
+                    "cpu_fixed_online": "cpu_fixed with the headline sampler's online observation filter (two range forks updated step by step, merged after the rollout)",
                     "hip_fixed": "HIP simulator, fixed-horizon batches with value bootstrap (product default)",
                     "hip_episodes": "HIP simulator, whole-episode batches (sample_mode='episodes')",
                     "hip_episodes_frozen": "hip_episodes with the CPU arms' filter handling: statistics frozen during a rollout, merged after it",
