@@ -1,0 +1,6 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06l; mkdir -p $O
+timeout 900 python -m pytest tests/test_mlp.py -m gpu -q -x 2>&1 | tail -3
+J='import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split("/")[-1], round(d["value"]), "rollout", round(d["rollout_only_env_steps_per_s"]), "update_s", round(d["update_s_per_iteration"],5))'
+for i in 1 2 3; do for f in 0 1; do
+HOIC_FUSED_LOSS_PACK=$f timeout 300 python bench.py --no-cpu-baseline --other-configs 0 > $O/f${f}_$i.json 2>$O/err.txt || tail -5 $O/err.txt; python -c "$J" $O/f${f}_$i.json
+done; done
