@@ -269,6 +269,7 @@ def quick_config(obj, args, device, streams=None, value_stream=None, iterations=
         agent.optimize_policy(it, save_model=False)
     agent.env.sim.enable_timing(True)
     agent.env.sim.diagnostics(reset=True)
+    agent.learner.time_allreduce = distributed
     torch.cuda.synchronize()
     t0 = time.time(); k_ms = []; p_ms = []; steps = 0; infos = []
     for it in range(iterations):
@@ -414,6 +415,7 @@ def main():
         agent.optimize_policy(epoch, save_model=False); epoch += 1
     agent.env.sim.enable_timing(True)
     agent.env.sim.diagnostics(reset=True)
+    agent.learner.time_allreduce = distributed
     kernel_ms = []
     post_ms = []
     barrier()
@@ -492,6 +494,9 @@ def main():
             # first value forward: the part of it that outlasts the main stream's rollout-end event is inside update_s_per_iteration;
             # rollout_only above is without it, this rate is with it (a complete rollout whatever stream its tail ran on)
             "rollout_tail_s_per_iteration": t_tail / n_it,
+            # several ranks: how long the two update chains' streams stalled behind their gradient all-reduces (HIP events around
+            # every wait on rank 0; the other chain's GEMMs run during a stall, so this is an upper bound of what is exposed)
+            "allreduce_exposed_ms_per_iteration": (agent.learner.allreduce_wait_ms()[0] / n_it) if distributed else None,
             "rollout_with_tail_env_steps_per_s": total_env_steps / (t_sample + t_tail) if t_sample > 0 else None,
             "update_s_per_iteration": t_update / n_it, "rollout_s_per_iteration": t_sample / n_it,
             "rollout_host_enqueue_s_per_iteration": host_enqueue / n_it,

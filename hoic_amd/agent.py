@@ -136,6 +136,13 @@ class PPOLearner:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.update_dtype, self.strict_reference = update_dtype, strict_reference
+        # several ranks: the gradient all-reduces use the default process group; the few-scalar collectives (advantage statistics,
+        # sample counts; the sampler's filter merge and logger sums) use ``aux_group`` when the owner made one -- a second
+        # communicator with its own stream, so that a small collective issued from another stream never queues behind a gradient
+        # all-reduce (and the reverse).  None = the default group for everything.
+        self.aux_group = None
+        self.time_allreduce = False            # bench.py: events around every gradient all-reduce's wait (allreduce_wait_ms)
+        self._ar_events = []
         self._policy_clip_used = False
         self.policy_net = PolicyGaussian(cfg, action_dim, state_dim).to(self.device, dtype)
         self.value_net = Value(MLP(state_dim, cfg.value_hsize, cfg.value_htype)).to(self.device, dtype)
@@ -179,10 +186,29 @@ class PPOLearner:
         if pending is None:
             return
         grads, flat, work = pending
+        timed = self.time_allreduce and flat.is_cuda
+        if timed:        # how long THIS chain's stream stalls for its gradient's collective (the other chain's GEMMs run meanwhile)
+            cur = torch.cuda.current_stream(self.device)
+            e0 = torch.cuda.Event(enable_timing=True); e0.record(cur)
         work.wait()
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record(cur)
+            self._ar_events.append((e0, e1))
         flat.div_(self.world)
         for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
             g.copy_(f)
+
+    def allreduce_wait_ms(self, reset=True):
+        """(sum of the chains' stalls behind their gradient all-reduces since the last call, number of all-reduces): HIP events
+        around every ``work.wait()`` on the stream that waits (``time_allreduce``).  Synchronises."""
+        tot = 0.0
+        for e0, e1 in self._ar_events:
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        n = len(self._ar_events)
+        if reset:
+            self._ar_events = []
+        return tot, n
 
     def _autocast(self):
         if self.update_dtype == "bf16" and self.device.type == "cuda":
@@ -232,7 +258,7 @@ class PPOLearner:
             torch.cuda.current_stream(self.device).wait_event(ready)
         advantages, returns = estimate_advantages(batch.rewards, batch.masks, values.reshape(T, N), self.gamma, self.tau,
                                                   getattr(batch, "next_values", None),
-                                                  dist_group=True if self.distributed else None, valid=valid)
+                                                  dist_group=(self.aux_group or True) if self.distributed else None, valid=valid)
         advantages = advantages.reshape(T * N, 1); returns = returns.reshape(T * N, 1)
         weight = 1.0
         if valid is not None:
@@ -240,7 +266,7 @@ class PPOLearner:
             if self.distributed:        # ranks hold different sample counts: weight the local means by M_r * world / sum(M)
                 import torch.distributed as dist
                 cnt = torch.tensor([float(states.shape[0])], device=states.device, dtype=torch.float64)
-                tot = cnt.clone(); dist.all_reduce(tot)
+                tot = cnt.clone(); dist.all_reduce(tot, group=self.aux_group)
                 weight = float(cnt * self.world / tot)
         self.optimize(states, actions, advantages, returns, weight)
         return time.time() - t0
@@ -318,7 +344,11 @@ class PPOLearner:
             self._losses = (value_loss, surr)
             peng.check_overflow()          # the policy chain ran on the current stream (the value chain's counter: finish_update)
             return
-        if self.distributed:      # several ranks: interleave the chains so that each gradient all-reduce hides under the other network's pass
+        if self.distributed:
+            # several ranks, one stream: interleave the chains so that each gradient all-reduce hides under the other network's pass.
+            # (Round 6 measured the three-stream form below and the tail on a side stream with a second process group for the small
+            #  collectives on the one-rank RCCL path: 814-816 k against 819-826 k for this form -- the one-rank tax, 862 k without
+            #  RCCL, is not the stream layout; profiles/r06_experiments.json "multi_rank_stream_layouts".)
             fixed_log_probs = None
             p_pending, p_waiting = None, False
             for ep in range(self.opt_num_epochs):
@@ -588,6 +618,10 @@ class AgentHandMimic:
         self.tuned_gemms = tuning.enable_tuned_gemms()      # recorded hipBLASLt kernel selections for the MLP shapes
         self.learner = PPOLearner(cfg, self.state_dim, self.action_dim, self.device, dtype, distributed, update_dtype,
                                   strict_reference, fused_adam=fused_adam, update_streams=update_streams)
+        # a second process group for the sampler's small collectives (filter merge, logger sums) and the learner's advantage
+        # statistics: a communicator and stream of its own.  None = the default group for everything (measured no better with it:
+        # profiles/r06_experiments.json "multi_rank_stream_layouts"); set both attributes to dist.new_group() to use one.
+        self._aux_group = None
         # the value network's five steps on a side stream, under the next iteration's rollout (f16x3 update on the GPU only)
         self.learner.overlap_value_update = bool(overlap_value_update) and update_dtype == "f16x3" and self.device.type == "cuda"
         # run_ahead: optimize_policy enqueues rollout and update back to back and waits for the rollout's statistics only (the
@@ -671,9 +705,9 @@ class AgentHandMimic:
         if self.distributed:
             import torch.distributed as dist
             tot = torch.cat([stats[[0, 3]], c_info, torch.full((1,), float(steps), device=stats.device, dtype=torch.float64)])
-            dist.all_reduce(tot)
-            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, group=self._aux_group)
+            mn = stats[1].clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self._aux_group)
+            mx = stats[2].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._aux_group)
             stats = torch.stack([tot[0], mn, mx, tot[1]]); c_info = tot[2:-1]
             # (fixed horizon: every rank holds the same T x N, no need to read the reduced count back)
             steps = int(tot[-1].item()) if valid is not None else steps * self.world
@@ -966,8 +1000,8 @@ class AgentHandMimic:
         # another library GEMM on a second stream)
         ones = torch.ones(T, N, device=dev, dtype=dt)
         # (several ranks: the tail holds collectives -- filter merge, logger sums -- which stay on the main stream with the update's
-        #  gradient all-reduces: one communicator, one stream)
-        tail = side if (side is not None and self.learner.update_dtype == "f16x3" and not self.distributed) else None
+        #  gradient all-reduces unless the agent was given a second process group for them, `_aux_group`)
+        tail = side if (side is not None and self.learner.update_dtype == "f16x3" and (not self.distributed or self._aux_group is not None)) else None
         if tail is not None:
             tail.wait_stream(main)
             for t_ in (rewards, rinfo_all, flags_all, masks, self.env.get_obs()):
@@ -988,7 +1022,7 @@ class AgentHandMimic:
                     if not self.run_ahead:
                         e.wait_overflow()
             if self.distributed:
-                self.running_state.sync()          # one observation filter for all ranks from here on
+                self.running_state.sync(group=self._aux_group)          # one observation filter for all ranks from here on
             self.learner.wait_value_update()          # the bootstrap below is the first reader of the value network since the update
             next_values = self._bootstrap_values(obs)
             if tail is not None:
@@ -1063,7 +1097,7 @@ class AgentHandMimic:
         if frozen:
             self.running_state.push(torch.stack(RAW)[valid])       # the batch's own observations, after the rollout
         if self.distributed:
-            self.running_state.sync()
+            self.running_state.sync(group=self._aux_group)
         batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=(~done_all).to(dt),
                                 exps=torch.ones(T, N, device=dev, dtype=dt), next_values=None, valid=valid)
         steps = int(valid.sum().item())
