@@ -582,7 +582,9 @@ class AgentHandMimic:
         self.cfg = self.cc_cfg = cfg
         self.sample_mode = sample_mode
         # rollout pipelining: 2 half-batches once a half still fills the GPU's 2048 wavefront slots
-        self.n_groups = int(n_groups) if n_groups is not None else (2 if n_envs >= 4096 and n_envs % 2 == 0 else 1)
+        # env ranges pipelined on their own streams: two from 4096 envs on -- and from 128 on for the whole-episode sampler, whose
+        # launches of a few hundred one-wavefront workgroups leave the GPU to the other range's chain anyway
+        self.n_groups = int(n_groups) if n_groups is not None else (2 if (n_envs >= 4096 or (sample_mode == "episodes" and n_envs >= 128)) and n_envs % 2 == 0 else 1)
         self._streams = None
         self._side_stream = None
         self.pack_in_rollout = True            # the rollout's filter launches also write the update's packed input
@@ -837,6 +839,13 @@ class AgentHandMimic:
         sample(); update_params checks ``packed_generation``)."""
         if self.sample_mode == "episodes":
             return self._sample_episodes(min_batch_size)
+        return self._sample_fixed(min_batch_size)
+
+    @torch.no_grad()
+    def _sample_fixed(self, min_batch_size, chunk=False):
+        """The fixed-horizon rollout (see ``sample``).  ``chunk``: a piece of a WHOLE-EPISODE rollout (_sample_episodes): the same
+        pipelined range chains, no tail (statistics, bootstrap values), no filter push in frozen mode, nothing packed for the
+        update; returns the raw [T, N, .] storage (states, actions, rewards, rinfo, flags, raw observations or None)."""
         t0 = time.time()
         self.env.set_mode("train")
         self.policy_net.eval()
@@ -933,7 +942,7 @@ class AgentHandMimic:
         # over the 53 k x 617 states.  One buffer per agent, reused: the update of an iteration is over (stream order) before the
         # next rollout writes -- unless the value phase runs under the next rollout (overlap_value_update: not used then).
         pin = None
-        if (fwd is not None and direct and not frozen and self.pack_in_rollout and not self.learner.overlap_value_update
+        if (fwd is not None and direct and not frozen and not chunk and self.pack_in_rollout and not self.learner.overlap_value_update
                 and all(e.fused_filter_ok(c) for e, (_, c) in zip(fwd, groups))):
             from .mlp import PackedInput
             pin = getattr(self, "_rollout_input", None)
@@ -987,9 +996,20 @@ class AgentHandMimic:
                 main.wait_stream(st_)
             if not frozen:
                 self.running_state.absorb(forks)
-        if frozen:
+        if frozen and not chunk:
             self.running_state.push(raw_all.view(T * N, self.state_dim))       # the batch's own observations, after the rollout
             del raw_all
+        if chunk:      # a piece of a whole-episode rollout: wait for the reward parts, keep the episodes going, hand the storage back
+            if async_reward:
+                self.env.sim.set_async_reward(False)
+            self._obs = self.env.get_obs()
+            if fwd is not None:
+                for e in fwd:
+                    e.post_overflow(); e.wait_overflow()
+            if side is not None:       # the next piece's side-stream set-up (filter forks) comes behind this piece's merge of the forks
+                self._rollout_done = torch.cuda.Event(); self._rollout_done.record(main)
+            self.last_rollout_steps = T
+            return SimpleNamespace(states=states, actions=actions, rewards=rewards, rinfo=rinfo_all, flags=flags_all, raw=raw_all if frozen else None)
         # The rollout's TAIL -- the wait for the last reward parts, masks + logger statistics (one launch, hoic_rollout_stats),
         # the bootstrap values of the final observations (the value network's body on the tiled forward kernels) -- is needed by
         # the advantages only, and those are formed behind the update's first value forward over the whole batch (1.5 ms of
@@ -1053,7 +1073,58 @@ class AgentHandMimic:
         episodes until it holds ``thread_batch_size = floor(min_batch_size / n_envs)`` steps (:509, :437); a worker
         that has its quota idles (its env keeps being stepped by the launch, its rows are marked invalid).  Nothing is
         bootstrapped: every episode in the batch ends with mask 0.  The observation filter sees every observation of every
-        worker (the reference keeps only worker 0's updates)."""
+        worker (the reference keeps only worker 0's updates).
+        On the GPU (float32) the rollout runs as PIECES of ``sync_every`` steps on the fixed-horizon sampler's machinery
+        (_sample_fixed(chunk=True): env ranges pipelined on their own streams with a filter fork each, LDS-free policy forward,
+        rewards off the critical path, in-launch resets), the workers' quotas are evaluated on the device between pieces and
+        read on the host once per piece (round 6; the serial per-step form below stays for the CPU and as
+        ``episodes_serial=True``: one launch per step of every env, ~30 small kernels and a clone of every output per step)."""
+        if self.device.type == "cuda" and self.dtype == torch.float32 and not getattr(self, "episodes_serial", False):
+            return self._sample_episodes_chunked(min_batch_size, sync_every)
+        return self._sample_episodes_serial(min_batch_size, sync_every)
+
+    @torch.no_grad()
+    def _sample_episodes_chunked(self, min_batch_size, sync_every=8):
+        t0 = time.time()
+        N, dev, dt = self.n_envs, self.device, self.dtype
+        quota = max(1, int(math.floor(min_batch_size / N)))
+        self._obs = None                       # every worker starts a fresh episode (:444-454)
+        active = torch.ones(N, dtype=torch.bool, device=dev)
+        count = torch.zeros(N, dtype=torch.int64, device=dev)
+        steps_t = torch.arange(1, sync_every + 1, device=dev, dtype=torch.int64)[:, None]
+        pieces = []
+        max_pieces = (quota + int(self.env.seq_len.max())) // sync_every + 2
+        for _ in range(max_pieces):
+            pc = self._sample_fixed(sync_every * N, chunk=True)
+            # the piece's valid rows: a worker stays in the batch up to and including the first step that ends an episode with its
+            # quota reached (count after that step >= quota, :437); all of it on the device, one host read per piece
+            done = pc.flags[:, :, 2] != 0
+            hit = done & ((count[None] + steps_t) >= quota) & active[None]
+            first_hit = torch.where(hit.any(0), hit.to(torch.int64).argmax(0), torch.full_like(count, sync_every))
+            pc.valid = active[None] & (steps_t - 1 <= first_hit[None])
+            count = count + pc.valid.sum(0)
+            active = active & (first_hit == sync_every)
+            pieces.append(pc)
+            if not bool(active.any()):
+                break
+        self._obs = None                       # the fixed-horizon sampler must not continue these episodes
+        cat = lambda k: torch.cat([getattr(p_, k) for p_ in pieces])
+        states, actions, rewards, rinfo, flags, valid = cat("states"), cat("actions"), cat("rewards"), cat("rinfo"), cat("flags"), cat("valid")
+        T = states.shape[0]
+        done_all = flags[:, :, 2] != 0
+        if self.filter_mode == "frozen":
+            self.running_state.push(cat("raw")[valid])       # the batch's own observations, after the rollout
+        if self.distributed:
+            self.running_state.sync(group=self._aux_group)
+        batch = SimpleNamespace(states=states, actions=actions, rewards=rewards, masks=(~done_all).to(dt),
+                                exps=torch.ones(T, N, device=dev, dtype=dt), next_values=None, valid=valid)
+        steps = int(valid.sum().item())
+        log = self._make_log(steps, rewards, flags[:, :, 1] != 0, done_all, rinfo, valid, t0)
+        self.last_rollout_steps = T          # step launches made (each one steps every env, idle workers included)
+        return batch, log
+
+    @torch.no_grad()
+    def _sample_episodes_serial(self, min_batch_size, sync_every=8):
         t0 = time.time()
         self.env.set_mode("train")
         self.policy_net.eval()
