@@ -269,7 +269,6 @@ def quick_config(obj, args, device, streams=None, value_stream=None, iterations=
         agent.optimize_policy(it, save_model=False)
     agent.env.sim.enable_timing(True)
     agent.env.sim.diagnostics(reset=True)
-    agent.learner.time_allreduce = distributed
     torch.cuda.synchronize()
     t0 = time.time(); k_ms = []; p_ms = []; steps = 0; infos = []
     for it in range(iterations):

@@ -456,3 +456,38 @@ def test_banana_merge_order_matches_the_reference_held_model():
                 np.testing.assert_allclose(A["pair_solref"][p], [float(v) for v in at["solref"].split()])
     # the compiled caps against the file's <size>: every row the kernel can hold fits the reference's buffers
     assert int(g["size"]["nconmax"]) == 100 and int(g["size"]["njmax"]) == 500
+
+
+def test_bench_and_tools_reference_no_undefined_names():
+    """bench.py runs its secondary configurations inside try/except (the headline line must not die with them), so a NameError
+    there is silent: a small static check -- every name a top-level function of bench.py loads is a parameter, assigned or
+    imported in it, a module-level name or a builtin."""
+    import ast
+    import builtins
+    for rel in ("bench.py", "__graft_entry__.py"):
+        tree = ast.parse(open(os.path.join(ROOT, rel)).read())
+        mod = set()
+        for n in tree.body:
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                mod.add(n.name)
+            elif isinstance(n, ast.Assign):
+                mod |= {a.id for t_ in n.targets for a in ast.walk(t_) if isinstance(a, ast.Name)}
+            elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                mod |= {(a.asname or a.name).split(".")[0] for a in n.names}
+        for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+            local = set()
+            for n in ast.walk(fn):
+                if isinstance(n, (ast.FunctionDef, ast.Lambda)):
+                    a = n.args
+                    local |= {x.arg for x in a.args + a.kwonlyargs + a.posonlyargs} | ({a.vararg.arg} if a.vararg else set()) | ({a.kwarg.arg} if a.kwarg else set())
+                    if isinstance(n, ast.FunctionDef):
+                        local.add(n.name)
+                elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                    local.add(n.id)
+                elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                    local |= {(a.asname or a.name).split(".")[0] for a in n.names}
+                elif isinstance(n, ast.ExceptHandler) and n.name:
+                    local.add(n.name)
+            used = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+            undefined = sorted(u for u in used if u not in local and u not in mod and not hasattr(builtins, u) and u != "__file__")
+            assert not undefined, (rel, fn.name, undefined)
