@@ -477,7 +477,14 @@ class SplitMLP:
     def _forward_iter(self, inp, need_grad):
         self._alloc(inp)
         t = self.table
-        t.exps[self.SLOT_X:self.SLOT_X + 1].copy_(inp.table.exps[0:1])      # device-side copy, no sync
+        # the input's exponent into this network's table: once per input (not per pass), and by a compute kernel -- a 4-byte
+        # device-to-device memcpy goes through the copy engine and took 90-190 us on the chain's stream beside the GEMMs, twelve
+        # times per update (tools/probe/update_copies.py)
+        # (a PackedInput's exponent is fixed when it is made -- measured by its constructor, or the rollout form's constant -- and
+        #  the engine holds the object (self.inp), so identity of the object is identity of the exponent)
+        if getattr(self, "_x_exp_of", None) is not inp:
+            torch.add(inp.table.exps[0:1], 0, out=t.exps[self.SLOT_X:self.SLOT_X + 1])
+            self._x_exp_of = inp
         self.inp = inp
         L = len(self.layers)
         if self.first:
@@ -773,7 +780,7 @@ class TiledForward:
             L = len(self.layers)
             assert share.layers[0] is self.layers[0] and share.WT is not None
             self.WT = share.WT
-            t.exps[self.SLOT_W0:self.SLOT_W0 + L].copy_(share.table.exps[self.SLOT_W0:self.SLOT_W0 + L])
+            torch.add(share.table.exps[self.SLOT_W0:self.SLOT_W0 + L], 0, out=t.exps[self.SLOT_W0:self.SLOT_W0 + L])      # (a kernel, not a copy-engine memcpy)
             return
         if self.WT is None:
             self.WT = [torch.empty(n * kp * 4, dtype=torch.uint8, device=self.dev) for n, kp in zip(self.dims_out, self.Kp)]
