@@ -339,6 +339,10 @@ def main():
     ap.add_argument("--min-iterations", type=int, default=30,
                     help="the timed region holds at least this many PPO iterations whatever --steps asks for (30 iterations = 2 s; a 2-iteration "
                          "region is 0.14 s and a 10-iteration one sits inside the box-to-box spread: not measurements); steps_requested keeps the flag's value")
+    ap.add_argument("--min-warmup-iterations", type=int, default=12,
+                    help="untimed PPO iterations before the timed region, whatever --warmup asks for beyond zero (12 iterations = 0.75 s): the "
+                         "first process on a fresh box measured 1.5 %% low with two (its first rollouts run before the clocks have settled: "
+                         "rollout 2.10 M against 2.18 M env-steps/s, update unchanged)")
     ap.add_argument("--fused-filter", type=int, default=1, help="1 = observation filter, the rollout forward's operand and its exponent refresh in one "
                     "launch per range-step (hoic_zfilter_tiled; default); 0 = the four separate launches (A/B)")
     ap.add_argument("--side-stream", type=int, default=1, help="1 = the rollout's set-up (noise, episode draws, filter forks) and tail (masks, bootstrap "
@@ -396,6 +400,8 @@ def main():
     share = world if args.scaling == "strong" else 1
     steps_per_iter = int(math.ceil(math.ceil(cfg.min_batch_size / share) / args.envs))
     n_warm_it = int(math.ceil(args.warmup / steps_per_iter)) if args.warmup > 0 else 0
+    if args.warmup > 0:       # (untimed; `warmup` of the line reports what was run, `warmup_requested` the flag)
+        n_warm_it = max(n_warm_it, args.min_warmup_iterations)
     n_it = max(1, args.min_iterations, int(math.ceil(args.steps / steps_per_iter)))
     if args.sample_mode == "episodes":      # an iteration is >= 50000 / envs steps of whole episodes per env: a few iterations are seconds already
         n_it = max(1, min(n_it, 3)); n_warm_it = min(n_warm_it, 1)
