@@ -241,7 +241,7 @@ STEP_PARITY_BOUND = {"box": [1.7e-5, 1.7e-5, 1.8e-5, 2.1e-5, 2.2e-5, 1.7e-4, 1.7
                      "banana": [3.7e-5, 4.8e-5, 5.0e-5, 5.0e-5, 5.0e-5, 5.0e-5, 5.0e-5, 8.5e-5]}
 
 
-@pytest.mark.parametrize("obj,mset", [("box", "test"), ("bottle", "test"), ("banana", "test"), ("box", "bench")])
+@pytest.mark.parametrize("obj,mset", [("box", "test"), ("bottle", "test"), ("banana", "test"), ("box", "bench"), ("bottle", "bench"), ("banana", "bench")])
 def test_env_step_parity_short_horizon(obj, mset, oracle_lib):
     """``mset`` "bench": the 17 x 600 synthetic motion set bench.py and BASELINE.json's configs run on, three
     envs per sequence with start frames over the whole sequence -- the oracle comparison on the bench workload's own states
