@@ -72,9 +72,9 @@ def _worker(rank, world, port, q, episodes=False):
 import pytest
 
 
-@pytest.mark.parametrize("world,episodes", [(2, False), (4, False), (2, True)])
+@pytest.mark.parametrize("world,episodes", [(2, False), (4, False), (8, False), (2, True)])
 def test_ranks_equal_one_process(world, episodes):
-    """world 2 and 4, fixed-horizon batches (equal shares) and whole-episode batches (unequal sample counts per rank:
+    """world 2, 4 and 8 (BASELINE.json config 5's rank count: one env per rank here), fixed-horizon batches (equal shares) and whole-episode batches (unequal sample counts per rank:
     the local means are weighted by M_r * world / sum M).  PPOLearner.optimize starts each gradient all-reduce
     asynchronously and finishes it after the OTHER network's pass; the result must still be the single-process one."""
     ctx = mp.get_context("spawn")
