@@ -1503,3 +1503,57 @@ def test_non_finite_object_pose_fails_that_env_only(box_blob, setup):
     fl = p1[3].cpu().numpy()
     assert fl[bad, 0].all() and fl[bad, 2].all() and not c1[3].cpu().numpy()[bad, 0].any()      # fail + done, only when poisoned
     assert bool(torch.isfinite(p1[0][bad]).all()) and bool(torch.isfinite(p2[0]).all()) and bool(torch.isfinite(p2[1]).all())
+
+
+def test_agent_set_expert_and_kept_batches(box_model):
+    """Two host-side guards of round 6: (1) AgentHandMimic.set_expert swaps the reference motions between iterations --
+    episode bounds, the envs' episodes and the side stream's ordering follow (the next rollout draws against the new lengths);
+    (2) a batch kept across a later sample() must not train on the later rollout's packed observations: its packed_generation no
+    longer matches the sampler's reused buffer, update_params packs the batch's own states again, and the result equals an update
+    from the same weights on a batch without the packed buffer (to 1e-6 of the largest parameter: the engines' delayed exponents
+    carry history from one update to the next, so two updates are not bit-identical) -- while the same update FORCED onto the stale
+    buffer (the later rollout's observations) is off by orders of magnitude more."""
+    import copy
+    from hoic_amd.agent import AgentHandMimic
+    from hoic_amd.config import Config
+    cfg = Config("box_future5_light_add_geom"); cfg.seed = 3; cfg.min_batch_size = 4096
+    torch.manual_seed(3)
+    ex_a = motions.synthetic_expert(box_model, 5, 300)
+    agent = AgentHandMimic(cfg, n_envs=512, expert_seqs=ex_a, update_dtype="f16x3", n_groups=2)
+    agent.optimize_policy(0, save_model=False)
+    ex_b = motions.synthetic_expert(box_model, 3, 260)
+    agent.set_expert(ex_b)
+    assert agent.seq_num == 3 and int(agent._max_start.max()) == 60
+    info = agent.optimize_policy(1, save_model=False)
+    assert np.isfinite(float(info["log"].avg_c_reward)) and int(info["log"].num_steps) == 8 * 512
+    # (2)
+    agent.learner.finish_update()
+    b1, _ = agent.sample(cfg.min_batch_size)
+    assert b1.packed_states is not None and b1.packed_generation == b1.packed_states.generation
+    b2, _ = agent.sample(cfg.min_batch_size)
+    assert b1.packed_generation != b1.packed_states.generation          # the buffer now holds b2's rows
+    torch.cuda.synchronize()
+    state = {"p": copy.deepcopy(agent.policy_net.state_dict()), "v": copy.deepcopy(agent.value_net.state_dict()),
+             "op": copy.deepcopy(agent.optimizer_policy.state_dict()), "ov": copy.deepcopy(agent.optimizer_value.state_dict())}
+    agent.update_params(b1); agent.learner.finish_update(); torch.cuda.synchronize()
+    got = torch.cat([p.detach().flatten() for p in agent.policy_net.parameters()]).clone()
+    agent.policy_net.load_state_dict(state["p"]); agent.value_net.load_state_dict(state["v"])
+    agent.optimizer_policy.load_state_dict(state["op"]); agent.optimizer_value.load_state_dict(state["ov"])
+    for eng in agent.learner._engines:
+        eng.weights_changed()
+    b1.packed_states = None
+    agent.update_params(b1); agent.learner.finish_update(); torch.cuda.synchronize()
+    want = torch.cat([p.detach().flatten() for p in agent.policy_net.parameters()]).clone()
+    # the bug the stamp prevents: the stale buffer accepted as this batch's
+    agent.policy_net.load_state_dict(state["p"]); agent.value_net.load_state_dict(state["v"])
+    agent.optimizer_policy.load_state_dict(state["op"]); agent.optimizer_value.load_state_dict(state["ov"])
+    for eng in agent.learner._engines:
+        eng.weights_changed()
+    b1.packed_states = b2.packed_states; b1.packed_generation = b2.packed_states.generation
+    agent.update_params(b1); agent.learner.finish_update(); torch.cuda.synchronize()
+    stale = torch.cat([p.detach().flatten() for p in agent.policy_net.parameters()])
+    scale = float(want.abs().max())
+    d_ok, d_stale = float((got - want).abs().max()) / scale, float((stale - want).abs().max()) / scale
+    print(f"kept batch: re-packed update vs reference {d_ok:.2e}, update on the stale buffer vs reference {d_stale:.2e} (of the largest parameter)")
+    assert d_ok < 1e-6 and d_stale > 100 * max(d_ok, 1e-9)
+    agent.env.close()
