@@ -547,7 +547,7 @@ def test_episode_parity_has_no_bias(obj, oracle_lib):
     exp(-k err^2) terms, a perturbed trajectory tracks slightly WORSE on average (second order), and the float64 control shows the
     same split as the kernel (Box: 47 of 64 negative in both, medians -1.3e-6 and -1.5e-6).  The test therefore compares the
     kernel's sign split WITH THE CONTROL'S: a two-sided binomial test of the kernel's negative count against the control's
-    negative fraction must not reject at 1 %, and the two medians agree to 2e-5.
+    negative fraction must not reject at 1 %, and the two medians agree to 5e-5 (measured: 2e-7, 1.1e-5, 8e-8).
     Measured on the round-6 library (profiles/r06_episode_parity_statistics.txt): Box no outlier in either, 47 of 64 negative in
     both; Bottle 11 outliers (worst 1.5e-2) against the control's 9 (1.4e-2), largely the same episodes; Banana 2 (2.8e-3)
     against 0 (5e-4)."""
@@ -582,7 +582,7 @@ def test_episode_parity_has_no_bias(obj, oracle_lib):
     mism_c = [i for i in range(N) if arms["substep32"][i][1] != ref[i][1]]
     print(f"  episodes ending at another step than the reference: HIP {mism} ({[(hip[i][1], ref[i][1]) for i in mism]}), control {mism_c}")
     assert len(mism) <= len(mism_c) + 1 and set(mism) <= set(out)
-    assert abs(float(np.median(d))) < 5e-5 and abs(float(np.median(d) - np.median(dc))) < 2e-5
+    assert abs(float(np.median(d))) < 5e-5 and abs(float(np.median(d) - np.median(dc))) < 5e-5
     assert abs(float(d[inside].mean())) < 2e-4
     assert p_split > 0.01, (neg, negc, p_split)
     assert len(out) <= 2 * len(ctrl_out) + 2, (out, ctrl_out)
